@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-pixel ray-trace path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload demo|dragon]
+
+One STEP = one Renderer.render() frame of the hot path: the fused raytrace+accumulate
+kernel, 1 sample per pixel, over the whole image.  Default workload = BASELINE.json
+configs[1]: default demo mesh + environment map, 1920x1080, 8 bounces, 64 frames
+(= 64 spp); `--workload dragon` is configs[2] (~870k triangles).
+
+N > 1 (launched by torch.distributed.run, one process per GPU): image tiles are dealt to
+the ranks in 8-row blocks, the scene is replicated, there is NO per-frame communication,
+and the job ends with one RCCL gather of the HDR accumulation buffers to rank 0
+(inside the timed region).  Weak scaling: the image grows with N so every GPU always
+renders 1920x1080 pixels per frame (N=2: 1920x2160, N=4: 3840x2160, N=8: 3840x4320);
+`--scaling strong` keeps 1920x1080 and splits it instead.
+
+Prints ONE JSON line on rank 0: metric Mrays/s (rays = raySceneIntersect calls, counted
+exactly by the kernel), plus
+  roofline     : algorithmic bytes per launch / average kernel time (HIP events on the
+                 kernel's own stream) against the 8 TB/s HBM peak,
+  cpu_baseline : the CPU oracle timed on a bounded sample of the same workload
+                 (rank 0, N = 1 only).
+The oracle is only ever the baseline / checker here, never the thing measured as `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "webgpu-pathtracer_amd", "py"), os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BLOCK_ROWS = 8
+
+
+def image_size(n_gpus, scaling):
+    if scaling == "strong":
+        return 1920, 1080
+    a, b = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}.get(n_gpus, (1, n_gpus))
+    return 1920 * a, 1080 * b
+
+
+def build_scene(workload):
+    from mi3pt_host import scenes
+    if workload == "dragon":
+        sc = scenes.dragon_class_scene()
+    else:
+        sc = scenes.demo_scene()
+    sc.build_bvh()
+    return sc, scenes.synthetic_env()
+
+
+def algorithmic_bytes(c):
+    """SURVEY.md 8(d) / BASELINE.md: bytes in the reference's own layouts, each touched
+    record counted once: 48 B per box test, 112 B per triangle test, one 64-B material
+    per hit, four 16-B env texels per miss, 16+16 B accumulator read-modify-write."""
+    return 48 * c["box_tests"] + 112 * c["tri_tests"] + 64 * c["hits"] + 64 * c["misses"] + 32 * c["pixels"]
+
+
+def cpu_baseline(sc, env, un_bytes_for_frame, width, height, budget_s=12.0):
+    """Time the CPU oracle on interleaved 1/32 shards of the same frames until the
+    budget is used.  kind = "port": the oracle is a restatement, not the reference."""
+    import pt_oracle as orc
+    osc = orc.OracleScene(sc.triangles, sc.material_bytes, sc.nodes, env)
+    cores = os.cpu_count() or 1
+    shards = 32
+    rays = 0
+    pixels = 0
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        frame = 2 + n // shards
+        _, cnt = orc.raytrace(osc, un_bytes_for_frame(frame), width, height, n % shards, shards, BLOCK_ROWS)
+        rays += cnt["rays"]
+        pixels += cnt["pixels"]
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= shards * 4:
+            break
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{n} interleaved 1/{shards}-image shards of the same {width}x{height} 8-bounce frames "
+                      f"({pixels} pixel jobs, {rays} rays, {dt:.1f} s, OpenMP over {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="demo", choices=["demo", "dragon"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from mi3pt_host import capi, layout
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+
+    width, height = image_size(world, args.scaling)
+    sc, env = build_scene(args.workload)
+    bounces = 8
+
+    def rt_uniforms(frame):
+        u = layout.UniformBlock(layout.RAYTRACE_UNIFORMS)
+        u.set({"resolution": [width, height], "aspect": width / height, "frame": frame, "maxBounces": bounces,
+               "samplesPerFrame": 1,
+               "camera": {"position": sc.camera["position"], "direction": sc.camera_direction(),
+                          "fov": sc.camera["fov"], "focalDistance": sc.camera["focalDistance"],
+                          "aperture": sc.camera["aperture"]},
+               "envMapIntensity": 1.0, "envMapRotation": 0.0})
+        return u.tobytes()
+
+    def acc_uniforms(frame):
+        u = layout.UniformBlock(layout.ACCUMULATE_UNIFORMS)
+        u.set({"resolution": [width, height], "frame": frame, "enabled": 1})
+        return u.tobytes()
+
+    stream = torch.cuda.Stream()
+    ctx = capi.Context(local_rank)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_kernel_variant(args.variant)
+    ctx.upload_bvh(sc.nodes)
+    ctx.upload_triangles(sc.triangles)
+    ctx.upload_materials(sc.material_bytes)
+    ctx.upload_environment(env)
+    ctx.set_tile(rank, world, BLOCK_ROWS)
+    ctx.resize(width, height)
+    # the accumulation image lives in a torch tensor so RCCL can gather it in place
+    accum = torch.zeros((ctx.local_rows, width, 4), dtype=torch.float32, device="cuda")
+    ctx.bind_accumulation(accum.data_ptr(), accum.numel() * 4)
+    max_rows = capi.tile_local_rows(height, 0, world, BLOCK_ROWS)
+    gathered = None
+    if world > 1:
+        send = torch.zeros((max_rows, width, 4), dtype=torch.float32, device="cuda")
+        if rank == 0:
+            gathered = [torch.empty_like(send) for _ in range(world)]
+
+    def one_frame(frame):
+        ctx.set_uniforms(capi.PASS_RAYTRACE, rt_uniforms(frame))
+        ctx.set_uniforms(capi.PASS_ACCUMULATE, acc_uniforms(frame))
+        ctx.submit(capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    frame = 2
+    for _ in range(args.warmup):
+        one_frame(frame)
+        frame += 1
+    ctx.sync()
+    ctx.reset_counters()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync_all()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        one_frame(frame)
+        frame += 1
+    ev1.record(stream)
+    if world > 1:
+        # the one exchange of the job: HDR accumulation buffers -> rank 0 over xGMI
+        with torch.cuda.stream(stream):
+            send[: ctx.local_rows].copy_(accum)
+            dist.gather(send, gathered, dst=0)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)
+
+    counters = ctx.counters()
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    c = torch.tensor([counters[k] for k in capi.COUNTER_NAMES], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total = dict(zip(capi.COUNTER_NAMES, (int(x) for x in c.tolist())))
+
+    if rank == 0:
+        rays = total["rays"]
+        steps = max(args.steps, 1)
+        per_launch_bytes = algorithmic_bytes(counters) / steps       # this rank's kernel
+        achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / steps, 4), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("default demo mesh (1,998 triangles) + synthetic env map" if args.workload == "demo"
+                                    else f"dragon-class procedural mesh ({len(sc.triangles)} triangles) + synthetic env map")
+                       + f", {width}x{height}, 8 bounces, 1 spp per step, {args.steps} steps",
+                       "triangles": int(len(sc.triangles)), "bvh_nodes": int(len(sc.nodes)),
+                       "image": [width, height], "max_bounces": bounces,
+                       "parallelism": f"tile-split x{world} (8-row blocks, round robin), scene replicated, "
+                                      "one RCCL gather at the end" if world > 1 else "single GPU",
+                       "rays_per_step": rays // steps, "kernel": "k_raytrace<fused accumulate, packet walk>"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                         "bytes_per_ray": round(algorithmic_bytes(total) / max(rays, 1), 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, env, rt_uniforms, width, height)
+        print(json.dumps(out), flush=True)
+    ctx.bind_accumulation(None, 0)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,224 @@
+/*
+ * mi3pt.h -- C ABI of libmi3pt.so, the MI355X (gfx950) path-tracing back-end.
+ *
+ * This is the drop-in boundary for the reference's per-pixel ray-trace path
+ * (umar-ahmed/webgpu-pathtracer: src/passes/, src/renderer.ts, src/scene.ts).  The
+ * reference has no FFI: its seam is the WebGPU device/queue API as used by the three
+ * Pass classes and the Renderer.  Every entry point below replaces one group of those
+ * WebGPU calls and cites it (paths relative to the reference root).  Buffers cross
+ * the boundary as RAW BYTES IN THE REFERENCE'S OWN LAYOUTS (what webgpu-utils
+ * computes from the WGSL structs):
+ *
+ *   Triangle  112 B  raytrace.wgsl:40-49    BVHNode  48 B  raytrace.wgsl:51-64
+ *   Material   64 B  raytrace.wgsl:31-38    Uniforms 96 B  raytrace.wgsl:66-75
+ *   accumulate Uniforms 16 B accumulate.wgsl:1-5
+ *   fullscreen Uniforms 24 B fullscreen.wgsl:14-20
+ *   environment / CDF textures: 1024x512 rgba32float, renderer.ts:111-130
+ *
+ * Conventions
+ *   - plain C types only; every function returns an mi3pt_status (0 = OK) unless
+ *     stated otherwise; mi3pt_last_error() gives the message for the calling thread
+ *     (the N-API / ctypes shims turn it into a thrown Error, like the reference's
+ *     `throw new Error(...)` sites renderer.ts:65-67, 133-143, 514-516).
+ *   - uploads COPY at call time (queue.writeBuffer / writeTexture semantics); the
+ *     caller keeps ownership of its memory.
+ *   - mi3pt_submit() is asynchronous and stream ordered, like
+ *     `device.queue.submit([encoder.finish()])` (renderer.ts:389-390); reads and
+ *     mi3pt_sync() are the only blocking calls.
+ *   - one host thread per context; no callbacks.
+ *   - there is NO CPU fallback: without a HIP device mi3pt_create() fails with
+ *     MI3PT_ERR_NO_DEVICE.  The mi3pt_host_* functions are the reference's own
+ *     CPU-side scene compile (BVH build, env CDF) and need no device.
+ */
+#ifndef MI3PT_H
+#define MI3PT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI3PT_ABI_VERSION 1
+
+typedef enum mi3pt_status {
+    MI3PT_OK = 0,
+    MI3PT_ERR_INVALID = 1,    /* bad argument / wrong byte size */
+    MI3PT_ERR_NO_DEVICE = 2,  /* no HIP device (renderer.ts:514-516 "WebGPU device not found.") */
+    MI3PT_ERR_HIP = 3,        /* a HIP runtime call failed */
+    MI3PT_ERR_STATE = 4       /* call made in the wrong state (e.g. submit before resize) */
+} mi3pt_status;
+
+/* strides of the reference layouts */
+#define MI3PT_TRIANGLE_STRIDE 112
+#define MI3PT_BVHNODE_STRIDE 48
+#define MI3PT_MATERIAL_STRIDE 64
+#define MI3PT_RAYTRACE_UNIFORMS_SIZE 96
+#define MI3PT_ACCUMULATE_UNIFORMS_SIZE 16
+#define MI3PT_FULLSCREEN_UNIFORMS_SIZE 24
+#define MI3PT_ENV_WIDTH 1024
+#define MI3PT_ENV_HEIGHT 512
+
+/* the three passes of renderer.ts:23-27 */
+typedef enum mi3pt_pass {
+    MI3PT_PASS_RAYTRACE = 0,
+    MI3PT_PASS_ACCUMULATE = 1,
+    MI3PT_PASS_FULLSCREEN = 2
+} mi3pt_pass;
+
+#define MI3PT_SUBMIT_RAYTRACE 1u
+#define MI3PT_SUBMIT_ACCUMULATE 2u
+#define MI3PT_SUBMIT_FULLSCREEN 4u
+
+/* which image mi3pt_read_texture() returns */
+typedef enum mi3pt_texture {
+    MI3PT_TEX_OUTPUT = 0,        /* renderer.outputTexture (renderer.ts:94-109): the frame's radiance
+                                    after a raytrace pass, the running mean after an accumulate pass
+                                    (accumulate.ts:171-175 copies it back) */
+    MI3PT_TEX_ACCUMULATION = 1,  /* accumulate.ts:45-59 accumulationTexture == outputTexturePrev */
+    MI3PT_TEX_CANVAS = 2         /* the fullscreen pass's colour attachment, as float RGBA
+                                    (canvas_w x canvas_h, row 0 = top) */
+} mi3pt_texture;
+
+/* texel storage of output / accumulation textures */
+typedef enum mi3pt_storage {
+    MI3PT_STORAGE_F32 = 0,       /* keep fp32 (default; what the 1e-4 parity target needs) */
+    MI3PT_STORAGE_F16 = 1        /* round every stored texel through binary16 = the reference's
+                                    rgba16float textures (renderer.ts:102, accumulate.ts:52) */
+} mi3pt_storage;
+
+/* counters accumulated by every raytrace pass since the last mi3pt_reset_counters() */
+typedef enum mi3pt_counter {
+    MI3PT_CNT_RAYS = 0,       /* raySceneIntersect calls (raytrace.wgsl:379) */
+    MI3PT_CNT_BOX_TESTS = 1,  /* rayAABBIntersect calls  (raytrace.wgsl:118) = N_box */
+    MI3PT_CNT_TRI_TESTS = 2,  /* rayTriangleIntersect calls (raytrace.wgsl:78) = N_tri */
+    MI3PT_CNT_HITS = 3,
+    MI3PT_CNT_MISSES = 4,     /* environment lookups */
+    MI3PT_CNT_STACK_OVERFLOWS = 5, /* traversals aborted at raytrace.wgsl:167-171 */
+    MI3PT_CNT_PIXELS = 6,     /* (pixel, frame) jobs executed */
+    MI3PT_CNT_RESERVED = 7,
+    MI3PT_CNT_COUNT = 8
+} mi3pt_counter;
+
+typedef struct mi3pt_ctx mi3pt_ctx;
+
+/* ---- library ---- */
+int mi3pt_abi_version(void);
+const char *mi3pt_last_error(void);
+
+/* ---- device discovery: Renderer.diagnostic(), renderer.ts:470-489 ---- */
+int mi3pt_device_count(int *count);
+int mi3pt_device_name(int device, char *name, size_t capacity);
+
+/* ---- context: Renderer.create() + constructor, renderer.ts:47-92, 491-533.
+ * Creates the HIP stream, placeholder scene buffers (2 triangles / 1 material /
+ * 1 node, raytrace.ts:72-77), zeroed environment textures and default uniforms.
+ * destroy waits for submitted work first (renderer.ts:418-429). ---- */
+int mi3pt_create(int device, mi3pt_ctx **out_ctx);
+int mi3pt_destroy(mi3pt_ctx *ctx);
+
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * context's own; NULL restores the internal stream. */
+int mi3pt_set_stream(mi3pt_ctx *ctx, void *hip_stream);
+int mi3pt_set_storage(mi3pt_ctx *ctx, int storage /* mi3pt_storage */);
+
+/* Tile split (multi-GPU): this context renders only the rows y with
+ * (y / block_rows) % nranks == rank; its textures are compact local_rows x width
+ * images.  Default rank 0 of 1.  Takes effect at the next mi3pt_resize(). */
+int mi3pt_set_tile(mi3pt_ctx *ctx, int rank, int nranks, int block_rows);
+int mi3pt_tile_local_rows(int height, int rank, int nranks, int block_rows); /* returns the count */
+
+/* ---- scene upload: queue.writeBuffer of the structured views ----
+ * raytrace.ts:104-121 (triangles), :138-160 (materials), :177-193 (BVH nodes).
+ * nbytes must be a non-zero multiple of the stride.  Buffer handles are resolved at
+ * dispatch time, so a new scene is picked up by the next submit (the reference needs
+ * a reset() for that: raytrace.ts:403 vs :508-522). */
+int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t nbytes);
+int mi3pt_upload_materials(mi3pt_ctx *ctx, const void *bytes, size_t nbytes);
+int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes);
+
+/* renderer.ts:132-157 (environment texels) and :253-280 (CDF texels): width/height
+ * must be 1024 x 512 ("Environment texture must be 1024x512 pixels"). */
+int mi3pt_upload_environment(mi3pt_ctx *ctx, const float *rgba, int width, int height);
+int mi3pt_upload_environment_cdf(mi3pt_ctx *ctx, const float *rgba, int width, int height);
+
+/* ---- textures: resize() / reset(), renderer.ts:283-295, 397-416 and
+ * accumulate.ts:36-59.  (Re)allocates and ZEROES the output, accumulation and canvas
+ * images; width x height is the canvas / full texture size. ---- */
+int mi3pt_resize(mi3pt_ctx *ctx, int width, int height);
+int mi3pt_reset(mi3pt_ctx *ctx);
+
+/* ---- uniforms: Pass.setUniforms -> queue.writeBuffer(uniformsBuffer, 0, ...)
+ * raytrace.ts:359-369, accumulate.ts:178-188, fullscreen.ts:138-148.  The host keeps
+ * the structured view (partial set semantics live there) and sends the whole block:
+ * 96 / 16 / 24 bytes. ---- */
+int mi3pt_set_uniforms(mi3pt_ctx *ctx, int pass /* mi3pt_pass */, const void *bytes, size_t nbytes);
+
+/* ---- execution: one command buffer, renderer.ts:379-390.  pass_mask is an OR of
+ * MI3PT_SUBMIT_*; passes run in the reference's order raytrace -> accumulate ->
+ * fullscreen (raytrace.ts:696-708, accumulate.ts:154-176, fullscreen.ts:158-177).
+ * RAYTRACE|ACCUMULATE in one submit runs as one fused kernel (bit-identical to
+ * the two-pass result). ---- */
+int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask);
+int mi3pt_sync(mi3pt_ctx *ctx);   /* queue.onSubmittedWorkDone(), renderer.ts:420 */
+
+/* ---- read-back (the capability a headless drop-in needs; the reference only has
+ * canvas.toDataURL, main.ts:351-356).  Blocking.  dst holds rows x width x 4 floats
+ * (rows = local rows for OUTPUT / ACCUMULATION, canvas height for CANVAS). ---- */
+int mi3pt_read_texture(mi3pt_ctx *ctx, int which /* mi3pt_texture */, float *dst, size_t nfloats);
+int mi3pt_read_canvas_rgba8(mi3pt_ctx *ctx, uint8_t *dst, size_t nbytes);
+
+/* Device pointer of the accumulation image (local_rows x width x 4 fp32), for
+ * zero-copy hand-off to a collective (RCCL gather of the HDR buffer). */
+int mi3pt_accumulation_device_ptr(mi3pt_ctx *ctx, void **dev_ptr, size_t *nbytes);
+/* Use caller-owned device memory (e.g. a torch tensor) as the accumulation image;
+ * nbytes must equal local_rows*width*16.  NULL returns to the internal buffer. */
+int mi3pt_bind_accumulation(mi3pt_ctx *ctx, void *dev_ptr, size_t nbytes);
+
+/* ---- timing: TimingHelper / RollingAverage, timing.ts:28-146, pass.ts:22-26.
+ * GPU time of the pass in the most recent completed submit, microseconds
+ * (hipEvent pair on the context's stream).  Off by default; enabling costs one
+ * event pair per pass per submit. ---- */
+int mi3pt_enable_timing(mi3pt_ctx *ctx, int enabled);
+int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds);
+
+/* ---- counters (roofline inputs) ---- */
+int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT]);
+int mi3pt_reset_counters(mi3pt_ctx *ctx);
+
+/* Kernel variant: 0 = auto, 1 = generic reference-layout walk, 2 = packet walk
+ * (needs child adjacency right == left + 1, which flattenBVH guarantees). */
+int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
+
+/* ---- component probes on the device (parity tests of the pieces) ----
+ * rays: n x 6 floats (origin, direction); out: n x 12 floats
+ * (hit, t, position xyz, normal xyz, materialIndex, box tests, triangle tests,
+ * stack overflows) = raySceneIntersect, raytrace.wgsl:205-211. */
+int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n, float *out);
+/* fn: 0 sin, 1 cos, 2 tan, 3 log, 4 exp, 5 atan2(a,b), 6 asin, 7 pow(a,b),
+ * 8 fp16 round trip, 9 sqrt, 10 a/b.  b may be NULL for unary functions. */
+int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n);
+
+/* ---- host-side scene compile (CPU, no device needed) ----
+ * mi3pt_host_build_bvh: buildBVH + buildBVHRecursive + flattenBVH,
+ * raytrace.ts:540-694, producing the identical tree (same axis rule, stable sort,
+ * first strict SAH minimum, breadth-first flatten).  `triangles` is ntris x 112 B;
+ * `nodes_out` receives (2*ntris - 1) x 48 B.  Returns the node count through
+ * *nnodes_out.  nthreads <= 0 picks the hardware concurrency. */
+int mi3pt_host_build_bvh(const void *triangles, size_t ntris, void *nodes_out,
+                         size_t nodes_capacity_bytes, size_t *nnodes_out, int nthreads);
+/* Same builder on the JavaScript host's double-precision world-space positions
+ * (9 doubles per triangle: a.xyz b.xyz c.xyz), i.e. before the structured view
+ * rounds them to fp32 -- this is what raytrace.ts:546-550 feeds Box3.setFromPoints,
+ * so near-tie splits come out exactly as in the reference. */
+int mi3pt_host_build_bvh_f64(const double *positions, size_t ntris, void *nodes_out,
+                             size_t nodes_capacity_bytes, size_t *nnodes_out, int nthreads);
+/* updateEnvironmentTexture's CDF texture, renderer.ts:159-266: R marginal CDF,
+ * G conditional CDF, B sin-weighted luminance, A 1. */
+int mi3pt_host_env_cdf(const float *rgba, int width, int height, float *cdf_rgba_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI3PT_H */

@@ -1,0 +1,701 @@
+/*
+ * pt_oracle.c -- TEST INFRASTRUCTURE (oracle). Not product code.
+ *
+ * CPU restatement, in plain C, of the reference's per-pixel path:
+ *   src/passes/shaders/raytrace.wgsl    (camera, RNG, BVH walk, shading, driver)
+ *   src/passes/shaders/accumulate.wgsl  (running mean)
+ *   src/passes/shaders/fullscreen.wgsl  (bilateral de-noise, tone-map)
+ * Each function cites the WGSL lines it follows.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load this library; the product
+ * (webgpu-pathtracer_amd/) never does.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden images or known-answer
+ * vectors and cannot be executed here (no tsc / node_modules / Dawn).
+ * This restatement is therefore pinned only by the hand-derived known-answer tests
+ * in tests/ and by the arithmetic interpretation fixed in pt_oracle_math.h.
+ *
+ * Buffers use the reference's byte layouts (webgpu-utils offsets):
+ *   Triangle 112 B, BVHNode 48 B, Material 64 B, raytrace Uniforms 96 B,
+ *   accumulate Uniforms 16 B, fullscreen Uniforms 24 B, env texture rgba32float.
+ * Storage textures (rgba16float in the reference) are kept as float RGBA; with
+ * store_f16 != 0 every texel written is first rounded through binary16, which is
+ * what the reference's texture formats do (renderer.ts:102, accumulate.ts:52).
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "pt_oracle_math.h"
+
+#define ORC_TRI_STRIDE 112
+#define ORC_NODE_STRIDE 48
+#define ORC_MAT_STRIDE 64
+
+/* raytrace.wgsl:1-8 */
+#define SEED 123456789u
+static const float PI_ __attribute__((unused)) = 3.14159265359f;
+static const float TWOPI = 6.28318530718f;
+static const float INVPI = 0.31830988618f;
+static const float INVTWOPI = 0.15915494309f;
+static const float INF_ = 1e20f;
+static const float EPSILON = 1e-6f;
+#define MAX_STACK_SIZE 64
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V3(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 vadd(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 vscale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 vneg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+/* pinned: dot summed left to right, no contraction */
+static inline float vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 vcross(v3 a, v3 b)
+{
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* pinned: normalize(v) = v / sqrt(dot(v, v)) */
+static inline v3 vnormalize(v3 a)
+{
+    float l = sqrtf(vdot(a, a));
+    return V3(a.x / l, a.y / l, a.z / l);
+}
+/* pinned: mix(a, b, t) = a * (1 - t) + b * t */
+static inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+static inline v3 vmix(v3 a, v3 b, float t)
+{
+    return V3(mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t));
+}
+/* pinned: reflect(i, n) = i - (2 * dot(n, i)) * n */
+static inline v3 vreflect(v3 i, v3 n)
+{
+    float k = 2.0f * vdot(n, i);
+    return vsub(i, vscale(n, k));
+}
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+static inline float ldf(const uint8_t *p, size_t off) { float f; memcpy(&f, p + off, 4); return f; }
+static inline int32_t ldi(const uint8_t *p, size_t off) { int32_t i; memcpy(&i, p + off, 4); return i; }
+static inline uint32_t ldu(const uint8_t *p, size_t off) { uint32_t i; memcpy(&i, p + off, 4); return i; }
+static inline v3 ldv3(const uint8_t *p, size_t off) { return V3(ldf(p, off), ldf(p, off + 4), ldf(p, off + 8)); }
+
+typedef struct {
+    const uint8_t *tris;  uint32_t ntris;
+    const uint8_t *mats;  uint32_t nmats;
+    const uint8_t *nodes; uint32_t nnodes;
+    const float *env;     int32_t env_w, env_h;   /* rgba32float, row 0 first */
+} orc_scene;
+
+/* raytrace.wgsl:66-75 (+ Camera :10-16), offsets per SURVEY.md 8a */
+typedef struct {
+    float res_x, res_y, aspect;
+    uint32_t frame;
+    int32_t max_bounces, samples_per_frame;
+    v3 cam_pos, cam_dir;
+    float fov, focal_distance, aperture;
+    float env_intensity, env_rotation;
+} rt_uniforms;
+
+static rt_uniforms parse_uniforms(const uint8_t *u)
+{
+    rt_uniforms r;
+    r.res_x = ldf(u, 0); r.res_y = ldf(u, 4); r.aspect = ldf(u, 8);
+    r.frame = ldu(u, 12);
+    r.max_bounces = ldi(u, 16); r.samples_per_frame = ldi(u, 20);
+    r.cam_pos = ldv3(u, 32); r.cam_dir = ldv3(u, 48);
+    r.fov = ldf(u, 60); r.focal_distance = ldf(u, 64); r.aperture = ldf(u, 68);
+    r.env_intensity = ldf(u, 80); r.env_rotation = ldf(u, 84);
+    return r;
+}
+
+typedef struct { v3 origin, direction; } ray_t;
+typedef struct { int hit; v3 position, normal; float t; int32_t material; } hit_t;
+
+/* counters: 0 rays, 1 AABB tests (N_box), 2 triangle tests (N_tri), 3 hits,
+ * 4 misses, 5 stack-overflow aborts, 6 pixel jobs, 7 reserved */
+enum { C_RAYS, C_BOX, C_TRI, C_HIT, C_MISS, C_OVERFLOW, C_PIXELS, C_RESERVED, C_COUNT };
+
+/* raytrace.wgsl:78-116 -- Moller-Trumbore, two-sided */
+static hit_t ray_triangle(ray_t ray, const uint8_t *tri)
+{
+    hit_t hit; hit.hit = 0; hit.position = V3(0, 0, 0); hit.normal = V3(0, 0, 0);
+    hit.t = INF_; hit.material = ldi(tri, 92);
+    v3 a = ldv3(tri, 0), b = ldv3(tri, 16), c = ldv3(tri, 32);
+    v3 edge1 = vsub(b, a);
+    v3 edge2 = vsub(c, a);
+    v3 h = vcross(ray.direction, edge2);
+    float det = vdot(edge1, h);
+    if (det > -EPSILON && det < EPSILON) return hit;
+    float f = 1.0f / det;
+    v3 s = vsub(ray.origin, a);
+    float u = f * vdot(s, h);
+    if (u < 0.0f || u > 1.0f) return hit;
+    v3 q = vcross(s, edge1);
+    float v = f * vdot(ray.direction, q);
+    if (v < 0.0f || u + v > 1.0f) return hit;
+    float w = 1.0f - u - v;
+    float t = f * vdot(edge2, q);
+    if (t > EPSILON) {
+        hit.hit = 1;
+        hit.t = t;
+        hit.position = vadd(ray.origin, vscale(ray.direction, t));
+        v3 an = ldv3(tri, 48), bn = ldv3(tri, 64), cn = ldv3(tri, 80);
+        hit.normal = vnormalize(vadd(vadd(vscale(an, w), vscale(bn, u)), vscale(cn, v)));
+    }
+    return hit;
+}
+
+/* raytrace.wgsl:118-152 -- slab test with true divisions */
+static int ray_aabb(ray_t ray, v3 bmin, v3 bmax)
+{
+    float tmin = -INF_, tmax = INF_;
+    const float d[3] = { ray.direction.x, ray.direction.y, ray.direction.z };
+    const float o[3] = { ray.origin.x, ray.origin.y, ray.origin.z };
+    const float mn[3] = { bmin.x, bmin.y, bmin.z };
+    const float mx[3] = { bmax.x, bmax.y, bmax.z };
+    for (int i = 0; i < 3; i++) {
+        if (fabsf(d[i]) < EPSILON) {
+            if (o[i] < mn[i] || o[i] > mx[i]) return 0;
+        } else {
+            float t1 = (mn[i] - o[i]) / d[i];
+            float t2 = (mx[i] - o[i]) / d[i];
+            float tnear = fminf(t1, t2);
+            float tfar = fmaxf(t1, t2);
+            tmin = fmaxf(tmin, tnear);
+            tmax = fminf(tmax, tfar);
+            if (tmin > tmax) return 0;
+        }
+    }
+    return tmax >= fmaxf(0.0f, tmin);
+}
+
+/* raytrace.wgsl:154-203 -- iterative DFS, 64-entry stack, right child popped first */
+static hit_t ray_bvh(const orc_scene *sc, ray_t ray, int32_t root, uint64_t *cnt)
+{
+    hit_t hit; hit.hit = 0; hit.position = V3(0, 0, 0); hit.normal = V3(0, 0, 0);
+    hit.t = INF_; hit.material = -1;
+    const uint8_t *n0 = sc->nodes + (size_t)root * ORC_NODE_STRIDE;
+    cnt[C_BOX]++;
+    if (!ray_aabb(ray, ldv3(n0, 0), ldv3(n0, 16))) return hit;
+
+    int32_t stack[MAX_STACK_SIZE];
+    int stack_size = 0;
+    stack[stack_size++] = root;
+    while (stack_size > 0) {
+        if (stack_size >= MAX_STACK_SIZE) { cnt[C_OVERFLOW]++; return hit; }
+        int32_t cur = stack[--stack_size];
+        const uint8_t *node = sc->nodes + (size_t)cur * ORC_NODE_STRIDE;
+        int32_t is_leaf = ldi(node, 28), left = ldi(node, 32), right = ldi(node, 36);
+        if (is_leaf == 1) {
+            int32_t ti = ldi(node, 40);
+            cnt[C_TRI]++;
+            hit_t th = ray_triangle(ray, sc->tris + (size_t)ti * ORC_TRI_STRIDE);
+            if (th.hit && th.t < hit.t) hit = th;
+        } else {
+            if (left >= 0) {
+                const uint8_t *ln = sc->nodes + (size_t)left * ORC_NODE_STRIDE;
+                cnt[C_BOX]++;
+                if (ray_aabb(ray, ldv3(ln, 0), ldv3(ln, 16))) stack[stack_size++] = left;
+            }
+            if (right >= 0) {
+                const uint8_t *rn = sc->nodes + (size_t)right * ORC_NODE_STRIDE;
+                cnt[C_BOX]++;
+                if (ray_aabb(ray, ldv3(rn, 0), ldv3(rn, 16))) stack[stack_size++] = right;
+            }
+        }
+    }
+    return hit;
+}
+
+/* raytrace.wgsl:205-211 */
+static hit_t ray_scene(const orc_scene *sc, ray_t ray, uint64_t *cnt)
+{
+    cnt[C_RAYS]++;
+    if (sc->nnodes == 0) {
+        hit_t hit; hit.hit = 0; hit.position = V3(0, 0, 0); hit.normal = V3(0, 0, 0);
+        hit.t = INF_; hit.material = -1;
+        return hit;
+    }
+    return ray_bvh(sc, ray, 0, cnt);
+}
+
+/* raytrace.wgsl:213-215 */
+static float deg_to_rad(float degrees) { return degrees * 3.14159265358979323846f / 180.0f; }
+
+/* raytrace.wgsl:217-245 */
+static ray_t camera_to_ray(const rt_uniforms *un, float uvx, float uvy)
+{
+    float t = om_tan(deg_to_rad(un->fov) / 2.0f);
+    float r = un->aspect * t;
+    float b = -t;
+    float l = -r;
+    float u = l + (r - l) * uvx;
+    float v = b + (t - b) * uvy;
+    v3 w = vnormalize(vneg(un->cam_dir));
+    v3 up = V3(0.0f, 1.0f, 0.0f);
+    if (fabsf(vdot(w, up)) > 0.99999f) up = V3(0.0f, 0.0f, 1.0f);
+    v3 u_dir = vnormalize(vcross(up, w));
+    v3 v_dir = vcross(w, u_dir);
+    v3 dir = vnormalize(vsub(vadd(vscale(u_dir, u), vscale(v_dir, v)), vscale(w, un->aspect)));
+    ray_t ray; ray.origin = un->cam_pos; ray.direction = dir;
+    return ray;
+}
+
+/* raytrace.wgsl:253-259 -- PCG hash step; 4294967295.0 rounds to 2^32 in f32 */
+static float rand_f(uint32_t *seed)
+{
+    *seed = (*seed) * 747796405u + 2891336453u;
+    uint32_t s = *seed;
+    uint32_t result = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    result = (result >> 22u) ^ result;
+    return (float)result / 4294967296.0f;
+}
+
+/* raytrace.wgsl:261-265 */
+static float rand_normal(uint32_t *seed)
+{
+    float theta = TWOPI * rand_f(seed);
+    float rho = sqrtf(-2.0f * om_log(rand_f(seed)));
+    return rho * om_cos(theta);
+}
+
+/* raytrace.wgsl:267-272 */
+static v3 rand_direction(uint32_t *seed)
+{
+    float x = rand_normal(seed);
+    float y = rand_normal(seed);
+    float z = rand_normal(seed);
+    return vnormalize(V3(x, y, z));
+}
+
+/* raytrace.wgsl:279-281 */
+static v3 rand_cosine_hemisphere(uint32_t *seed, v3 normal)
+{
+    return vnormalize(vadd(normal, rand_direction(seed)));
+}
+
+/* raytrace.wgsl:283-287 */
+static void rand_point_in_circle(uint32_t *seed, float *px, float *py)
+{
+    float theta = TWOPI * rand_f(seed);
+    float rho = sqrtf(rand_f(seed));
+    float s, c;
+    om_sincos(theta, &s, &c);
+    *px = rho * c;
+    *py = rho * s;
+}
+
+/* raytrace.wgsl:289-313 */
+static void env_uv_from_ray(const rt_uniforms *un, v3 dir, float *u, float *v)
+{
+    float sinr, cosr;
+    om_sincos(un->env_rotation, &sinr, &cosr);
+    v3 d = V3(dir.x * cosr - dir.z * sinr, dir.y, dir.x * sinr + dir.z * cosr);
+    float phi = om_atan2(d.x, d.z);
+    float theta = om_asin(clampf(d.y, -1.0f, 1.0f));
+    *u = phi * INVTWOPI + 0.5f;
+    *v = -theta * INVPI + 0.5f;
+}
+
+/* textureSampleLevel(..., linear sampler, clamp-to-edge): renderer.ts:77-80,
+ * raytrace.wgsl:369-371.  Pinned: x = u*W - 0.5, i0 = floor, f = x - i0, horizontal
+ * lerp then vertical lerp, weights in fp32. */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static v3 sample_env_bilinear_clamp(const orc_scene *sc, float u, float v)
+{
+    int W = sc->env_w, H = sc->env_h;
+    float x = u * (float)W - 0.5f;
+    float y = v * (float)H - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    /* clamp in float first: uv may be NaN / huge for degenerate rays */
+    float x0c = fminf(fmaxf(x0f, -1.0f), (float)W);
+    float y0c = fminf(fmaxf(y0f, -1.0f), (float)H);
+    if (x0c != x0c) x0c = 0.0f;
+    if (y0c != y0c) y0c = 0.0f;
+    int x0 = (int)x0c, y0 = (int)y0c;
+    int xa = clampi(x0, 0, W - 1), xb = clampi(x0 + 1, 0, W - 1);
+    int ya = clampi(y0, 0, H - 1), yb = clampi(y0 + 1, 0, H - 1);
+    const float *p00 = sc->env + 4 * ((size_t)ya * W + xa);
+    const float *p10 = sc->env + 4 * ((size_t)ya * W + xb);
+    const float *p01 = sc->env + 4 * ((size_t)yb * W + xa);
+    const float *p11 = sc->env + 4 * ((size_t)yb * W + xb);
+    float r[3];
+    for (int k = 0; k < 3; k++) {
+        float top = p00[k] * (1.0f - fx) + p10[k] * fx;
+        float bot = p01[k] * (1.0f - fx) + p11[k] * fx;
+        r[k] = top * (1.0f - fy) + bot * fy;
+    }
+    return V3(r[0], r[1], r[2]);
+}
+
+/* raytrace.wgsl:373-411 */
+static v3 trace(const orc_scene *sc, const rt_uniforms *un, uint32_t *seed, ray_t ray,
+                int32_t max_bounces, uint64_t *cnt)
+{
+    ray_t tr = ray;
+    v3 incoming = V3(0, 0, 0);
+    v3 ray_color = V3(1, 1, 1);
+    for (int32_t i = 0; i < max_bounces; i++) {
+        hit_t hit = ray_scene(sc, tr, cnt);
+        if (hit.hit) {
+            cnt[C_HIT]++;
+            const uint8_t *m = sc->mats + (size_t)hit.material * ORC_MAT_STRIDE;
+            v3 color = ldv3(m, 0), spec_color = ldv3(m, 16);
+            float roughness = ldf(m, 28), metalness = ldf(m, 32);
+            v3 emission = ldv3(m, 48);
+            float emission_strength = ldf(m, 60);
+
+            v3 diffuse_dir = rand_cosine_hemisphere(seed, hit.normal);
+            v3 specular_dir = vreflect(tr.direction, hit.normal);
+            float is_specular = 0.0f;
+            if (metalness >= rand_f(seed)) is_specular = 1.0f;
+
+            tr.origin = hit.position;
+            tr.direction = vmix(diffuse_dir, specular_dir, is_specular * (1.0f - roughness));
+
+            v3 emitted = vscale(emission, emission_strength);
+            incoming = vadd(incoming, vmul(emitted, ray_color));
+            ray_color = vmul(ray_color, vmix(color, spec_color, is_specular));
+        } else {
+            cnt[C_MISS]++;
+            float u, v;
+            env_uv_from_ray(un, tr.direction, &u, &v);
+            v3 env = sample_env_bilinear_clamp(sc, u, v);
+            incoming = vadd(incoming, vscale(vmul(ray_color, env), un->env_intensity));
+            break;
+        }
+    }
+    return incoming;
+}
+
+/* One pixel of computeMain, raytrace.wgsl:423-478 (after the bounds check). */
+static void raytrace_pixel(const orc_scene *sc, const rt_uniforms *un, uint32_t gx, uint32_t gy,
+                           float out[4], uint64_t *cnt)
+{
+    cnt[C_PIXELS]++;
+    float uvx = (float)gx / un->res_x;      /* getUv, :247-250 */
+    float uvy = (float)gy / un->res_y;
+    uint32_t index = gx + gy * (uint32_t)un->res_x;
+    uint32_t seed = index + un->frame * 719393u + SEED;
+    v3 incoming = V3(0, 0, 0);
+    for (int32_t i = 0; i < un->samples_per_frame; i++) {
+        ray_t ray = camera_to_ray(un, uvx, uvy);
+        float jx, jy, kx, ky;
+        rand_point_in_circle(&seed, &jx, &jy);
+        v3 jitter = V3(jx * (1.0f / un->res_x), jy * (1.0f / un->res_y), 0.0f);
+        rand_point_in_circle(&seed, &kx, &ky);
+        v3 jitter2 = V3(kx * un->aperture, ky * un->aperture, 0.0f);
+        v3 focal = vadd(vadd(ray.origin, vscale(ray.direction, un->focal_distance)), jitter);
+        ray.origin = vadd(ray.origin, jitter2);
+        ray.direction = vnormalize(vsub(focal, ray.origin));
+        incoming = vadd(incoming, trace(sc, un, &seed, ray, un->max_bounces, cnt));
+    }
+    float n = (float)un->samples_per_frame;
+    out[0] = incoming.x / n; out[1] = incoming.y / n; out[2] = incoming.z / n; out[3] = 1.0f;
+}
+
+/* Row r of a rank's compact local image -> global row (tile split):
+ * rows are dealt to ranks in blocks of `block_rows`, round robin. */
+static inline int local_to_global_row(int ly, int rank, int nranks, int block_rows)
+{
+    int b = ly / block_rows;
+    return (b * nranks + rank) * block_rows + (ly % block_rows);
+}
+
+int orc_tile_local_rows(int tex_h, int rank, int nranks, int block_rows)
+{
+    int n = 0;
+    for (int y = 0; y < tex_h; y++)
+        if ((y / block_rows) % nranks == rank) n++;
+    return n;
+}
+
+/*
+ * The raytrace pass.  `out` is this rank's compact image: local_rows x tex_w RGBA
+ * floats (local_rows = orc_tile_local_rows(tex_h, ...); rank 0 of 1 => the whole
+ * tex_w x tex_h texture).  Only texels inside u32(resolution) are written, like the
+ * bounds check at raytrace.wgsl:425-427.
+ */
+void orc_raytrace(const orc_scene *sc, const uint8_t *uniforms96, int tex_w, int tex_h,
+                  int rank, int nranks, int block_rows, int store_f16,
+                  float *out, uint64_t *counters8)
+{
+    rt_uniforms un = parse_uniforms(uniforms96);
+    uint32_t rw = (uint32_t)un.res_x, rh = (uint32_t)un.res_y;
+    int local_rows = orc_tile_local_rows(tex_h, rank, nranks, block_rows);
+    uint64_t total[C_COUNT];
+    memset(total, 0, sizeof total);
+#pragma omp parallel
+    {
+        uint64_t cnt[C_COUNT];
+        memset(cnt, 0, sizeof cnt);
+#pragma omp for schedule(dynamic, 1)
+        for (int ly = 0; ly < local_rows; ly++) {
+            int gy = local_to_global_row(ly, rank, nranks, block_rows);
+            if ((uint32_t)gy >= rh || gy >= tex_h) continue;
+            for (int gx = 0; gx < tex_w && (uint32_t)gx < rw; gx++) {
+                float px[4];
+                raytrace_pixel(sc, &un, (uint32_t)gx, (uint32_t)gy, px, cnt);
+                float *o = out + 4 * ((size_t)ly * tex_w + gx);
+                for (int k = 0; k < 4; k++) o[k] = store_f16 ? om_round_f16(px[k]) : px[k];
+            }
+        }
+#pragma omp critical
+        for (int k = 0; k < C_COUNT; k++) total[k] += cnt[k];
+    }
+    if (counters8) for (int k = 0; k < C_COUNT; k++) counters8[k] += total[k];
+}
+
+/*
+ * accumulate.wgsl:12-29.  Uniforms 16 B: resolution vec2u @0, frame u32 @8,
+ * enabled u32 @12.  input/prev/out are n_rows x tex_w RGBA floats (same compact
+ * layout as orc_raytrace's out); rows map to global rows for the bounds check.
+ * The two copyTextureToTexture calls of accumulate.ts:166-175 (acc -> prev,
+ * acc -> renderer.outputTexture) are the caller's `prev = out` afterwards.
+ */
+void orc_accumulate(const uint8_t *uniforms16, int tex_w, int tex_h,
+                    int rank, int nranks, int block_rows, int store_f16,
+                    const float *input, const float *prev, float *out)
+{
+    uint32_t rw = ldu(uniforms16, 0), rh = ldu(uniforms16, 4);
+    uint32_t frame = ldu(uniforms16, 8), enabled = ldu(uniforms16, 12);
+    int local_rows = orc_tile_local_rows(tex_h, rank, nranks, block_rows);
+    float weight = 1.0f;
+    if (frame > 0u) weight = 1.0f / (float)frame;
+    weight = (enabled == 1u) ? weight : 1.0f;
+    for (int ly = 0; ly < local_rows; ly++) {
+        int gy = local_to_global_row(ly, rank, nranks, block_rows);
+        if ((uint32_t)gy >= rh) continue;
+        for (int gx = 0; gx < tex_w && (uint32_t)gx < rw; gx++) {
+            size_t i = 4 * ((size_t)ly * tex_w + gx);
+            for (int k = 0; k < 3; k++) {
+                float c = mixf(prev[i + k], input[i + k], weight);
+                out[i + k] = store_f16 ? om_round_f16(c) : c;
+            }
+            out[i + 3] = 1.0f;
+        }
+    }
+}
+
+/* ---------------- fullscreen.wgsl ---------------- */
+
+/* textureSample(inputTexture, sampler{linear, repeat}) -- fullscreen.ts:49-57 */
+static inline int wrapi(int v, int n) { int m = v % n; return m < 0 ? m + n : m; }
+static void sample_bilinear_repeat(const float *tex, int W, int H, float u, float v, float out[4])
+{
+    float x = u * (float)W - 0.5f;
+    float y = v * (float)H - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    if (!(x0f > -1.0e9f && x0f < 1.0e9f)) x0f = 0.0f;
+    if (!(y0f > -1.0e9f && y0f < 1.0e9f)) y0f = 0.0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    int xa = wrapi(x0, W), xb = wrapi(x0 + 1, W);
+    int ya = wrapi(y0, H), yb = wrapi(y0 + 1, H);
+    const float *p00 = tex + 4 * ((size_t)ya * W + xa);
+    const float *p10 = tex + 4 * ((size_t)ya * W + xb);
+    const float *p01 = tex + 4 * ((size_t)yb * W + xa);
+    const float *p11 = tex + 4 * ((size_t)yb * W + xb);
+    for (int k = 0; k < 4; k++) {
+        float top = p00[k] * (1.0f - fx) + p10[k] * fx;
+        float bot = p01[k] * (1.0f - fx) + p11[k] * fx;
+        out[k] = top * (1.0f - fy) + bot * fy;
+    }
+}
+
+/* fullscreen.wgsl:53-86, called with sigma 5, kSigma 1, threshold 0.08 (:117-119) */
+static void denoise(const float *tex, int W, int H, float res_x, float res_y,
+                    float u, float v, float sigma, float k_sigma, float threshold, float out[4])
+{
+    const float INV_PI = 0.31830988618379067153776752674503f;
+    const float INV_SQRT_OF_2PI = 0.39894228040143267793994605993439f;
+    float radius = rintf(k_sigma * sigma);   /* WGSL round() = ties-to-even */
+    float rad_q = radius * radius;
+    float inv_sigma_qx2 = 0.5f / (sigma * sigma);
+    float inv_sigma_qx2pi = INV_PI * inv_sigma_qx2;
+    float inv_threshold_sqx2 = 0.5f / (threshold * threshold);
+    float inv_threshold_sqrt2pi = INV_SQRT_OF_2PI / threshold;
+    float centr[4];
+    sample_bilinear_repeat(tex, W, H, u, v, centr);
+    float zbuff = 0.0f;
+    float abuff[4] = { 0, 0, 0, 0 };
+    for (float x = -radius; x <= radius; x = x + 1.0f) {
+        float pt = sqrtf(rad_q - x * x);
+        for (float y = -pt; y <= pt; y = y + 1.0f) {
+            float dd = x * x + y * y;                       /* dot(d, d) */
+            float blur = om_exp(-dd * inv_sigma_qx2) * inv_sigma_qx2pi;
+            float walk[4];
+            sample_bilinear_repeat(tex, W, H, u + x / res_x, v + y / res_y, walk);
+            float dc[4];
+            for (int k = 0; k < 4; k++) dc[k] = walk[k] - centr[k];
+            float dcdc = ((dc[0] * dc[0] + dc[1] * dc[1]) + dc[2] * dc[2]) + dc[3] * dc[3];
+            float delta = om_exp(-dcdc * inv_threshold_sqx2) * inv_threshold_sqrt2pi * blur;
+            zbuff = zbuff + delta;
+            for (int k = 0; k < 4; k++) abuff[k] = abuff[k] + delta * walk[k];
+        }
+    }
+    for (int k = 0; k < 4; k++) out[k] = abuff[k] / zbuff;
+}
+
+/* fullscreen.wgsl:88-103 -- mat3x3f constructors are column-major */
+static void aces_tonemap(const float c[3], float out[3])
+{
+    static const float m1[3][3] = { { 0.59719f, 0.07600f, 0.02840f },
+                                    { 0.35458f, 0.90834f, 0.13383f },
+                                    { 0.04823f, 0.01566f, 0.83777f } };   /* columns */
+    static const float m2[3][3] = { { 1.60475f, -0.10208f, -0.00327f },
+                                    { -0.53108f, 1.10813f, -0.07276f },
+                                    { -0.07367f, -0.00605f, 1.07602f } };
+    float v[3], r[3];
+    for (int i = 0; i < 3; i++) v[i] = (m1[0][i] * c[0] + m1[1][i] * c[1]) + m1[2][i] * c[2];
+    for (int i = 0; i < 3; i++) {
+        float a = v[i] * (v[i] + 0.0245786f) - 0.000090537f;
+        float b = v[i] * (0.983729f * v[i] + 0.4329510f) + 0.238081f;
+        r[i] = a / b;
+    }
+    for (int i = 0; i < 3; i++) {
+        float m = (m2[0][i] * r[0] + m2[1][i] * r[1]) + m2[2][i] * r[2];
+        out[i] = om_pow(clampf(m, 0.0f, 1.0f), 1.0f / 2.2f);
+    }
+}
+
+/* fullscreen.wgsl:105-107 */
+static void reinhard_tonemap(const float c[3], float out[3])
+{
+    for (int i = 0; i < 3; i++) out[i] = c[i] / (c[i] + 1.0f);
+}
+
+/*
+ * The fullscreen pass, fullscreen.wgsl:26-50 + :109-132.  Uniforms 24 B: resolution
+ * vec2f @0, aspect @8, scalingFactor @12, denoise u32 @16, tonemapping u32 @20.
+ * `tex` is the full tex_w x tex_h accumulated image (row 0 = bottom of the picture).
+ * Output: canvas_w x canvas_h, row 0 = TOP of the canvas (framebuffer order).  The
+ * quad maps uv (0,0) to clip (-1,-1) = bottom-left, so canvas row py samples
+ * v = (1 - (py + 0.5) / canvas_h) * scalingFactor; pinned: attribute interpolation
+ * is evaluated as ((p + 0.5) / size) * scalingFactor in fp32.
+ * out_f32 (canvas_w*canvas_h*4, alpha 1) is the fragment output before unorm
+ * conversion; out_rgba8 (optional) is the rgba8unorm canvas (round(x*255)).
+ */
+void orc_fullscreen(const uint8_t *uniforms24, const float *tex, int tex_w, int tex_h,
+                    int canvas_w, int canvas_h, float *out_f32, uint8_t *out_rgba8)
+{
+    float res_x = ldf(uniforms24, 0), res_y = ldf(uniforms24, 4);
+    float scaling = ldf(uniforms24, 12);
+    uint32_t do_denoise = ldu(uniforms24, 16), tonemapping = ldu(uniforms24, 20);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int py = 0; py < canvas_h; py++) {
+        for (int px = 0; px < canvas_w; px++) {
+            float u = (((float)px + 0.5f) / (float)canvas_w) * scaling;
+            float v = (1.0f - ((float)py + 0.5f) / (float)canvas_h) * scaling;
+            float c4[4];
+            sample_bilinear_repeat(tex, tex_w, tex_h, u, v, c4);
+            if (do_denoise == 1u) denoise(tex, tex_w, tex_h, res_x, res_y, u, v, 5.0f, 1.0f, 0.08f, c4);
+            float c[3] = { c4[0], c4[1], c4[2] }, o[3];
+            if (tonemapping == 1u) aces_tonemap(c, o);
+            else if (tonemapping == 2u) reinhard_tonemap(c, o);
+            else { o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; }
+            size_t i = 4 * ((size_t)py * canvas_w + px);
+            if (out_f32) { out_f32[i] = o[0]; out_f32[i + 1] = o[1]; out_f32[i + 2] = o[2]; out_f32[i + 3] = 1.0f; }
+            if (out_rgba8) {
+                for (int k = 0; k < 3; k++) {
+                    float q = clampf(o[k], 0.0f, 1.0f);
+                    if (q != q) q = 0.0f;
+                    out_rgba8[i + k] = (uint8_t)rintf(q * 255.0f);
+                }
+                out_rgba8[i + 3] = 255;
+            }
+        }
+    }
+}
+
+/* ---------------- component-level entry points for known-answer tests ---------------- */
+
+int orc_ray_aabb(const float o[3], const float d[3], const float bmin[3], const float bmax[3])
+{
+    ray_t r; r.origin = V3(o[0], o[1], o[2]); r.direction = V3(d[0], d[1], d[2]);
+    return ray_aabb(r, V3(bmin[0], bmin[1], bmin[2]), V3(bmax[0], bmax[1], bmax[2]));
+}
+
+/* out: hit, t, px, py, pz, nx, ny, nz, material */
+void orc_ray_triangle(const float o[3], const float d[3], const uint8_t *tri112, float out[9])
+{
+    ray_t r; r.origin = V3(o[0], o[1], o[2]); r.direction = V3(d[0], d[1], d[2]);
+    hit_t h = ray_triangle(r, tri112);
+    out[0] = (float)h.hit; out[1] = h.t;
+    out[2] = h.position.x; out[3] = h.position.y; out[4] = h.position.z;
+    out[5] = h.normal.x; out[6] = h.normal.y; out[7] = h.normal.z;
+    out[8] = (float)h.material;
+}
+
+void orc_ray_scene(const orc_scene *sc, const float o[3], const float d[3], float out[9],
+                   uint64_t *counters8)
+{
+    ray_t r; r.origin = V3(o[0], o[1], o[2]); r.direction = V3(d[0], d[1], d[2]);
+    uint64_t cnt[C_COUNT]; memset(cnt, 0, sizeof cnt);
+    hit_t h = ray_scene(sc, r, cnt);
+    out[0] = (float)h.hit; out[1] = h.t;
+    out[2] = h.position.x; out[3] = h.position.y; out[4] = h.position.z;
+    out[5] = h.normal.x; out[6] = h.normal.y; out[7] = h.normal.z;
+    out[8] = (float)h.material;
+    if (counters8) for (int k = 0; k < C_COUNT; k++) counters8[k] += cnt[k];
+}
+
+void orc_camera_ray(const uint8_t *uniforms96, float uvx, float uvy, float out6[6])
+{
+    rt_uniforms un = parse_uniforms(uniforms96);
+    ray_t r = camera_to_ray(&un, uvx, uvy);
+    out6[0] = r.origin.x; out6[1] = r.origin.y; out6[2] = r.origin.z;
+    out6[3] = r.direction.x; out6[4] = r.direction.y; out6[5] = r.direction.z;
+}
+
+/* n successive rand() values from `seed`; returns the final seed */
+uint32_t orc_rand_sequence(uint32_t seed, int n, float *out)
+{
+    for (int i = 0; i < n; i++) out[i] = rand_f(&seed);
+    return seed;
+}
+
+void orc_env_uv(const uint8_t *uniforms96, const float dir[3], float uv[2])
+{
+    rt_uniforms un = parse_uniforms(uniforms96);
+    env_uv_from_ray(&un, V3(dir[0], dir[1], dir[2]), &uv[0], &uv[1]);
+}
+
+void orc_sample_env(const orc_scene *sc, float u, float v, float rgb[3])
+{
+    v3 c = sample_env_bilinear_clamp(sc, u, v);
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+}
+
+void orc_sample_repeat(const float *tex, int W, int H, float u, float v, float out[4])
+{
+    sample_bilinear_repeat(tex, W, H, u, v, out);
+}
+
+/* fn: 0 sin, 1 cos, 2 tan, 3 log, 4 exp, 5 atan2(a,b), 6 asin, 7 pow(a,b),
+ * 8 f16 round-trip, 9 sqrt, 10 a/b */
+void orc_math(int fn, const float *a, const float *b, float *out, int n)
+{
+    for (int i = 0; i < n; i++) {
+        float x = a[i], y = b ? b[i] : 0.0f, r;
+        switch (fn) {
+        case 0: r = om_sin(x); break;
+        case 1: r = om_cos(x); break;
+        case 2: r = om_tan(x); break;
+        case 3: r = om_log(x); break;
+        case 4: r = om_exp(x); break;
+        case 5: r = om_atan2(x, y); break;
+        case 6: r = om_asin(x); break;
+        case 7: r = om_pow(x, y); break;
+        case 8: r = om_round_f16(x); break;
+        case 9: r = sqrtf(x); break;
+        default: r = x / y; break;
+        }
+        out[i] = r;
+    }
+}

@@ -1,0 +1,84 @@
+"""Shared helpers for the tests: uniform blocks, scene upload, image comparison."""
+import numpy as np
+
+from mi3pt_host import capi, layout
+
+
+def rt_uniforms(sc, w, h, frame=2, bounces=4, spf=1, aperture=None, focal=None, res=None,
+                intensity=1.0, rotation=0.0, aspect=None, fov=None, position=None, direction=None):
+    cam = sc.camera
+    u = layout.UniformBlock(layout.RAYTRACE_UNIFORMS)
+    u.set({"resolution": list(res) if res is not None else [w, h],
+           "aspect": aspect if aspect is not None else w / h,
+           "frame": frame, "maxBounces": bounces, "samplesPerFrame": spf,
+           "camera": {"position": position if position is not None else cam["position"],
+                      "direction": direction if direction is not None else sc.camera_direction(),
+                      "fov": fov if fov is not None else cam["fov"],
+                      "focalDistance": focal if focal is not None else cam["focalDistance"],
+                      "aperture": aperture if aperture is not None else cam["aperture"]},
+           "envMapIntensity": intensity, "envMapRotation": rotation})
+    return u
+
+
+def acc_uniforms(w, h, frame, enabled=1):
+    u = layout.UniformBlock(layout.ACCUMULATE_UNIFORMS)
+    u.set({"resolution": [w, h], "frame": frame, "enabled": enabled})
+    return u
+
+
+def fs_uniforms(w, h, scaling=1.0, denoise=1, tonemapping=1):
+    u = layout.UniformBlock(layout.FULLSCREEN_UNIFORMS)
+    u.set({"resolution": [w, h], "aspect": w / h, "scalingFactor": scaling, "denoise": denoise,
+           "tonemapping": tonemapping})
+    return u
+
+
+def upload_scene(ctx, sc, env=None):
+    ctx.upload_bvh(sc.nodes)
+    ctx.upload_triangles(sc.triangles)
+    ctx.upload_materials(sc.material_bytes)
+    if env is not None:
+        ctx.upload_environment(env)
+
+
+def oracle_scene(orc, sc, env=None):
+    return orc.OracleScene(sc.triangles, sc.material_bytes, sc.nodes, env)
+
+
+def same_bits(a, b):
+    """Bit-for-bit equality of two float arrays (NaNs must match as NaNs)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    if a.shape != b.shape:
+        return False
+    eq = (a == b) | (np.isnan(a) & np.isnan(b))
+    return bool(eq.all())
+
+
+def describe_diff(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    bad = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+    n = int(bad.sum())
+    if n == 0:
+        return "identical"
+    rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-12)
+    idx = np.argwhere(bad)[:5].tolist()
+    return f"{n} of {a.size} values differ; max rel {np.nanmax(rel[bad]):.3g}; first at {idx}"
+
+
+def max_rel_err(a, b, floor=1e-6):
+    """Per-value relative error |a-b| / max(|b|, floor), NaN-aware (NaN==NaN is 0)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    both_nan = np.isnan(a) & np.isnan(b)
+    rel = np.abs(a - b) / np.maximum(np.abs(b), floor)
+    rel[both_nan] = 0.0
+    return float(np.nanmax(rel)) if rel.size else 0.0
+
+
+def gpu_frame(ctx, rt_u, acc_u=None, mask=capi.SUBMIT_RAYTRACE):
+    ctx.set_uniforms(capi.PASS_RAYTRACE, rt_u.tobytes())
+    if acc_u is not None:
+        ctx.set_uniforms(capi.PASS_ACCUMULATE, acc_u.tobytes())
+    ctx.submit(mask)

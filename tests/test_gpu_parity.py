@@ -1,0 +1,357 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+The bar (BASELINE.json north_star): per-pixel agreement within 1e-4 relative fp32 at the
+fixed RNG seed.  Because the product and the oracle implement the same pinned
+arithmetic, the tests ask for more: BIT-identical images and identical ray / box-test /
+triangle-test counters; the 1e-4 check is kept as the documented tolerance.
+"""
+import numpy as np
+import pytest
+
+import ptcommon as pc
+from mi3pt_host import capi, layout, scenes
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4      # north_star tolerance, relative, per pixel value
+
+
+# ---------------------------------------------------------------- math
+
+MATH_CASES = [
+    (0, "sin", lambda r: r.uniform(-10, 10, 200000), None),
+    (1, "cos", lambda r: r.uniform(-10, 10, 200000), None),
+    (0, "sin-wide", lambda r: r.uniform(-3000, 3000, 100000), None),
+    (2, "tan", lambda r: r.uniform(-1.5, 1.5, 100000), None),
+    (3, "log", lambda r: np.concatenate([r.uniform(0, 1, 100000), 2.0 ** -r.uniform(0, 149, 50000),
+                                         r.uniform(0, 1e9, 20000), [0.0, -1.0, np.inf, np.nan, 1.0]]), None),
+    (4, "exp", lambda r: np.concatenate([r.uniform(-110, 92, 200000), [-np.inf, np.inf, np.nan, 0.0]]), None),
+    (5, "atan2", lambda r: r.normal(size=200000), lambda r: r.normal(size=200000)),
+    (6, "asin", lambda r: np.concatenate([r.uniform(-1, 1, 200000), [-1, 1, 0, 1.5, 1e-5, -1e-5]]), None),
+    (7, "pow", lambda r: np.concatenate([r.uniform(0, 1, 100000), [0.0, 1.0]]),
+     lambda r: np.full(100002, 1 / 2.2)),
+    (8, "f16", lambda r: np.concatenate([r.normal(size=100000) * 10.0 ** r.uniform(-9, 6, 100000),
+                                         [0, 65504, 65519.9, 65520, 1e-8, np.inf, -np.inf, 5.96e-8, 2.98e-8]]),
+     None),
+    (9, "sqrt", lambda r: r.uniform(0, 1e6, 100000), None),
+    (10, "div", lambda r: r.normal(size=200000) * 100, lambda r: r.normal(size=200000)),
+]
+
+
+@pytest.mark.parametrize("fn,name,gen_a,gen_b", MATH_CASES, ids=[c[1] for c in MATH_CASES])
+def test_math_bit_exact(gpu_ctx, orc, fn, name, gen_a, gen_b):
+    rng = np.random.default_rng(1234 + fn)
+    a = gen_a(rng).astype(np.float32)
+    b = gen_b(rng).astype(np.float32) if gen_b else None
+    got = gpu_ctx.debug_math(fn, a, b)
+    want = orc.math_fn(fn, a, b)
+    assert pc.same_bits(got, want), f"{name}: {pc.describe_diff(got, want)}"
+
+
+# ---------------------------------------------------------------- intersection probes
+
+def _random_rays(rng, n, origin_scale=3.0):
+    o = rng.normal(size=(n, 3)) * origin_scale
+    t = rng.normal(size=(n, 3)) * 0.8 + np.array([0.0, 0.4, 0.0])
+    d = t - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_ray_scene_intersect_matches_oracle(gpu_ctx, orc, demo, env, variant):
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_kernel_variant(variant)
+    rng = np.random.default_rng(5)
+    rays = _random_rays(rng, 4000)
+    # axis-parallel and grazing rays exercise the |d| < EPSILON branch of the slab test
+    special = np.array([[0, 5, 0.5, 0, -1, 0], [0, 0.4, 5, 0, 0, -1], [-5, 0.4, 0.5, 1, 0, 0],
+                        [0.4, 5, 0.5, 0, -1, 0], [0.4, 5, 0.9, 0, -1, 0], [0, 0, 0, 0, 1, 0],
+                        [2.5, 1, 2.5, 0, -1, 0], [0, 1e-7, 0, 1, 0, 0]], np.float32)
+    rays = np.concatenate([rays, special])
+    got = ctx.debug_intersect(rays)
+    osc = pc.oracle_scene(orc, demo, env)
+    for i, r in enumerate(rays):
+        want, cnt = orc.ray_scene(osc, r[:3], r[3:])
+        assert pc.same_bits(got[i, :9], want), f"ray {i} {r}: gpu {got[i]} oracle {want}"
+        assert (int(got[i, 9]), int(got[i, 10]), int(got[i, 11])) == \
+            (cnt["box_tests"], cnt["tri_tests"], cnt["stack_overflows"]), f"ray {i} counters"
+    ctx.set_kernel_variant(0)
+
+
+def _chain_scene(depth):
+    """A degenerate right-deep BVH (hand-made, not from the builder): a chain of `depth`
+    internal nodes whose LEFT children are leaves and whose right child continues the
+    chain.  Every box is hit, so the stack grows by one per level: with depth >= 64 the
+    walk must abort at raytrace.wgsl:167-171 with best-so-far."""
+    ntri = depth + 1
+    pos = np.zeros((ntri, 3, 3))
+    for i in range(ntri):
+        z = -1.0 - i        # triangles stacked along -z, all hit by the ray (0,0,5)->-z
+        pos[i] = [[-1, -1, z], [1, -1, z], [0, 1, z]]
+    nrm = np.tile(np.array([0.0, 0.0, 1.0]), (ntri, 3, 1))
+    tris = layout.pack_triangles(pos, nrm, np.zeros(ntri, int))
+    nodes = np.zeros(2 * ntri - 1, layout.BVH_NODE)
+    # node 2k = internal k (k < depth), node 2k+1 = leaf k, last node = leaf `depth`
+    # breadth-first-like order with child > parent
+    def box(lo_tri, hi_tri):
+        p = pos[lo_tri:hi_tri + 1].reshape(-1, 3)
+        return p.min(0), p.max(0)
+    idx = 0
+    for k in range(depth):
+        mn, mx = box(k, depth)
+        nodes[idx]["min"], nodes[idx]["max"] = mn, mx
+        nodes[idx]["isLeaf"] = 0
+        # children: right (idx+2) = the rest of the chain is pushed LAST and popped first,
+        # so leaves pile up on the stack
+        nodes[idx]["left"], nodes[idx]["right"] = idx + 1, idx + 2
+        nodes[idx]["triangleIndex"] = -1
+        mn, mx = box(k, k)
+        nodes[idx + 1]["min"], nodes[idx + 1]["max"] = mn, mx
+        nodes[idx + 1]["isLeaf"], nodes[idx + 1]["left"], nodes[idx + 1]["right"] = 1, -1, -1
+        nodes[idx + 1]["triangleIndex"] = k
+        idx += 2
+    mn, mx = box(depth, depth)
+    nodes[idx]["min"], nodes[idx]["max"] = mn, mx
+    nodes[idx]["isLeaf"], nodes[idx]["left"], nodes[idx]["right"], nodes[idx]["triangleIndex"] = 1, -1, -1, depth
+    mats = layout.pack_materials([scenes.WHITE])
+    return tris, mats, nodes
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("depth", [10, 62, 63, 64, 70])
+def test_stack_overflow_abort_matches_oracle(gpu_ctx, orc, variant, depth):
+    tris, mats, nodes = _chain_scene(depth)
+    ctx = gpu_ctx
+    ctx.upload_bvh(nodes)
+    ctx.upload_triangles(tris)
+    ctx.upload_materials(mats)
+    ctx.set_kernel_variant(variant)
+    rays = np.array([[0, 0, 5, 0, 0, -1], [0.2, -0.3, 5, 0, 0, -1], [0, 0, -200, 0, 0, 1]], np.float32)
+    got = ctx.debug_intersect(rays)
+    osc = orc.OracleScene(tris, mats, nodes)
+    overflowed = 0
+    for i, r in enumerate(rays):
+        want, cnt = orc.ray_scene(osc, r[:3], r[3:])
+        assert pc.same_bits(got[i, :9], want), f"depth {depth} ray {i}: gpu {got[i]} oracle {want}"
+        assert int(got[i, 11]) == cnt["stack_overflows"]
+        assert int(got[i, 9]) == cnt["box_tests"] and int(got[i, 10]) == cnt["tri_tests"]
+        overflowed += cnt["stack_overflows"]
+    if depth >= 64:
+        assert overflowed > 0, "the chain is deep enough that the reference walk must abort"
+    ctx.set_kernel_variant(0)
+
+
+# ---------------------------------------------------------------- whole passes
+
+FRAME_CASES = [
+    # w, h, bounces, spf, aperture, focal, frame, rotation
+    (64, 64, 1, 1, 0.0, 1.0, 2, 0.0),
+    (64, 64, 4, 1, 0.0, 1.0, 2, 0.0),
+    (64, 64, 8, 1, 0.0, 1.0, 3, 0.0),
+    (64, 64, 4, 1, 0.05, 4.1, 2, 0.0),
+    (64, 64, 4, 3, 0.02, 4.1, 7, 0.7),
+    (100, 52, 4, 1, 0.0, 1.0, 2, -2.0),        # ragged: not a multiple of the 8x8 tile
+    (256, 256, 4, 1, 0.0, 1.0, 2, 0.0),
+    (8, 8, 0, 1, 0.0, 1.0, 2, 0.0),            # maxBounces 0: black
+    (1, 1, 4, 1, 0.0, 1.0, 2, 0.0),
+]
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("case", FRAME_CASES, ids=[f"{c[0]}x{c[1]}-b{c[2]}-s{c[3]}-a{c[4]}" for c in FRAME_CASES])
+def test_raytrace_pass_bit_identical(gpu_ctx, orc, demo, env, case, variant):
+    w, h, bounces, spf, aperture, focal, frame, rotation = case
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_kernel_variant(variant)
+    ctx.set_storage(capi.STORAGE_F32)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    ctx.reset_counters()
+    u = pc.rt_uniforms(demo, w, h, frame=frame, bounces=bounces, spf=spf, aperture=aperture, focal=focal,
+                       rotation=rotation)
+    pc.gpu_frame(ctx, u)
+    got = ctx.read_texture(capi.TEX_OUTPUT)
+    cnt = ctx.counters()
+    want, ocnt = orc.raytrace(pc.oracle_scene(orc, demo, env), u.tobytes(), w, h)
+    assert pc.max_rel_err(got, want) <= REL_TOL
+    assert pc.same_bits(got, want), pc.describe_diff(got, want)
+    for k in ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels"):
+        assert cnt[k] == ocnt[k], f"counter {k}: gpu {cnt[k]} oracle {ocnt[k]}"
+    ctx.set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("storage", [capi.STORAGE_F32, capi.STORAGE_F16])
+@pytest.mark.parametrize("fused", [True, False])
+def test_accumulation_over_frames(gpu_ctx, orc, demo, env, storage, fused):
+    """3 frames of renderer.render(): frame = 2, 3, 4 (renderer.ts:369-377); the buffer
+    then holds sum(c_i)/(n+1)-style running means, with fp16 rounding per step when the
+    reference's rgba16float storage is emulated."""
+    w = h = 48
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_storage(storage)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    osc = pc.oracle_scene(orc, demo, env)
+    acc = np.zeros((h, w, 4), np.float32)
+    f16 = storage == capi.STORAGE_F16
+    for frame in (2, 3, 4):
+        u = pc.rt_uniforms(demo, w, h, frame=frame, bounces=4)
+        a = pc.acc_uniforms(w, h, frame)
+        if fused:
+            pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+        else:
+            pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE)
+            ctx.submit(capi.SUBMIT_ACCUMULATE)
+        img, _ = orc.raytrace(osc, u.tobytes(), w, h, store_f16=f16)
+        acc = orc.accumulate(a.tobytes(), w, h, img, acc, store_f16=f16)
+    got = ctx.read_texture(capi.TEX_ACCUMULATION)
+    assert pc.same_bits(got, acc), pc.describe_diff(got, acc)
+    assert pc.same_bits(ctx.read_texture(capi.TEX_OUTPUT), acc)     # accumulate.ts:171-175 copy-back
+    ctx.set_storage(capi.STORAGE_F32)
+
+
+def test_accumulate_disabled_passes_frame_through(gpu_ctx, orc, demo, env):
+    w = h = 32
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    osc = pc.oracle_scene(orc, demo, env)
+    u = pc.rt_uniforms(demo, w, h, frame=5)
+    a = pc.acc_uniforms(w, h, 5, enabled=0)
+    pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+    img, _ = orc.raytrace(osc, u.tobytes(), w, h)
+    want = orc.accumulate(a.tobytes(), w, h, img, np.zeros_like(img))
+    assert pc.same_bits(ctx.read_texture(capi.TEX_ACCUMULATION), want)
+
+
+def test_scaled_subrectangle(gpu_ctx, orc, demo, env):
+    """scalingFactor < 1: kernels run on u32(resolution) of a full-size texture with a
+    fractional float resolution (raytrace.ts:373, renderer.ts:310-320)."""
+    w, h = 90, 50
+    res = (w * 0.25, h * 0.25)          # 22.5 x 12.5 -> 22 x 12 pixels
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    u = pc.rt_uniforms(demo, w, h, res=res, aspect=w / h)
+    a = layout.UniformBlock(layout.ACCUMULATE_UNIFORMS)
+    a.set({"resolution": list(res), "frame": 2, "enabled": 1})
+    assert tuple(a.get("resolution")) == (22, 12)
+    pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+    osc = pc.oracle_scene(orc, demo, env)
+    img, _ = orc.raytrace(osc, u.tobytes(), w, h)
+    want = orc.accumulate(a.tobytes(), w, h, img, np.zeros_like(img))
+    got = ctx.read_texture(capi.TEX_ACCUMULATION)
+    assert pc.same_bits(got, want), pc.describe_diff(got, want)
+    assert not got[12:].any() and not got[:, 22:].any()
+
+
+@pytest.mark.parametrize("denoise,tonemapping,scaling", [(1, 1, 1.0), (0, 1, 1.0), (1, 2, 1.0), (1, 0, 1.0),
+                                                         (1, 1, 0.5)])
+def test_fullscreen_pass(gpu_ctx, orc, demo, env, denoise, tonemapping, scaling):
+    w, h = 72, 40
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    osc = pc.oracle_scene(orc, demo, env)
+    acc = np.zeros((h, w, 4), np.float32)
+    res = (w * scaling, h * scaling)
+    for frame in (2, 3):
+        u = pc.rt_uniforms(demo, w, h, frame=frame, res=res, aspect=w / h)
+        a = layout.UniformBlock(layout.ACCUMULATE_UNIFORMS)
+        a.set({"resolution": list(res), "frame": frame, "enabled": 1})
+        pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+        img, _ = orc.raytrace(osc, u.tobytes(), w, h)
+        acc = orc.accumulate(a.tobytes(), w, h, img, acc)
+    f = pc.fs_uniforms(w, h, scaling, denoise, tonemapping)
+    ctx.set_uniforms(capi.PASS_FULLSCREEN, f.tobytes())
+    ctx.submit(capi.SUBMIT_FULLSCREEN)
+    got_f = ctx.read_texture(capi.TEX_CANVAS)
+    got_8 = ctx.read_canvas_rgba8()
+    want_f, want_8 = orc.fullscreen(f.tobytes(), acc)
+    assert pc.same_bits(got_f, want_f), pc.describe_diff(got_f, want_f)
+    assert np.array_equal(got_8, want_8)
+
+
+@pytest.mark.parametrize("nranks,block_rows", [(2, 8), (4, 8), (8, 8), (3, 5)])
+def test_tile_split_reassembles_to_whole_image(gpu_ctx, orc, demo, env, nranks, block_rows):
+    """Each rank's compact rows, de-interleaved, must equal the single-GPU image
+    (the seed depends only on the global pixel index: raytrace.wgsl:435-436)."""
+    w, h = 96, 70
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    u = pc.rt_uniforms(demo, w, h, frame=2, bounces=4)
+    a = pc.acc_uniforms(w, h, 2)
+    want, _ = orc.raytrace(pc.oracle_scene(orc, demo, env), u.tobytes(), w, h)
+    want = orc.accumulate(a.tobytes(), w, h, want, np.zeros_like(want))
+    whole = np.zeros((h, w, 4), np.float32)
+    total_rays = 0
+    for rank in range(nranks):
+        ctx.set_tile(rank, nranks, block_rows)
+        ctx.resize(w, h)
+        ctx.reset_counters()
+        pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+        part = ctx.read_texture(capi.TEX_ACCUMULATION)
+        rows = [y for y in range(h) if (y // block_rows) % nranks == rank]
+        assert part.shape[0] == len(rows)
+        whole[rows] = part
+        total_rays += ctx.counters()["rays"]
+    assert pc.same_bits(whole, want), pc.describe_diff(whole, want)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+
+
+# ---------------------------------------------------------------- full-size properties
+
+def test_full_hd_properties(gpu_ctx, orc, demo, env):
+    """BASELINE.md config 2 size (1920x1080, 8 bounces).  The oracle is too slow for a
+    full frame in a unit test, so: (1) both kernel variants agree bit for bit,
+    (2) fused == unfused, (3) counter identities hold, (4) an oracle-rendered band of
+    rows matches, (5) two tile halves reassemble to the whole."""
+    w, h = 1920, 1080
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    u = pc.rt_uniforms(demo, w, h, frame=2, bounces=8)
+    a = pc.acc_uniforms(w, h, 2)
+    images = {}
+    for variant in (1, 2):
+        ctx.set_kernel_variant(variant)
+        ctx.reset()
+        ctx.reset_counters()
+        pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+        images[variant] = (ctx.read_texture(capi.TEX_ACCUMULATION), ctx.counters())
+    assert pc.same_bits(images[1][0], images[2][0])
+    assert images[1][1] == images[2][1]
+    cnt = images[2][1]
+    assert cnt["pixels"] == w * h
+    assert cnt["rays"] == cnt["hits"] + cnt["misses"]
+    assert cnt["pixels"] <= cnt["rays"] <= 8 * cnt["pixels"]
+    assert cnt["box_tests"] >= cnt["rays"] and (cnt["box_tests"] - cnt["rays"]) % 2 == 0
+    # unfused
+    ctx.set_kernel_variant(0)
+    ctx.reset()
+    pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE)
+    frame_img = ctx.read_texture(capi.TEX_OUTPUT)
+    ctx.submit(capi.SUBMIT_ACCUMULATE)
+    assert pc.same_bits(ctx.read_texture(capi.TEX_ACCUMULATION), images[2][0])
+    # oracle on a band of 16 rows through the geometry (tile split: 1 block of 16 rows)
+    band_rank, nranks, block = 30, 1080 // 16 + 1, 16        # rows 480..495
+    part, _ = orc.raytrace(pc.oracle_scene(orc, demo, env), u.tobytes(), w, h, band_rank, nranks, block)
+    assert part.shape[0] == 16
+    assert pc.same_bits(frame_img[480:496], part), pc.describe_diff(frame_img[480:496], part)
+    assert pc.max_rel_err(frame_img[480:496], part) <= REL_TOL
+
+
+def test_no_cpu_fallback_symbols(built):
+    """The product library must not contain an oracle / CPU render path."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "orc_" not in out

@@ -1,0 +1,687 @@
+// pt_context.hip -- implementation of the C ABI in include/mi3pt.h on HIP.
+//
+// Owns the device resources the reference's Renderer and Pass classes own
+// (src/renderer.ts:94-130 textures, src/passes/raytrace.ts:89-205 buffers,
+// src/passes/accumulate.ts:45-59) and turns mi3pt_submit() into kernel launches on
+// one HIP stream.  There is no CPU execution path in this file: every pass is a
+// kernel from pt_kernels.hip.
+#include "../../include/mi3pt.h"
+#include "pt_internal.h"
+#include "pt_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_last_error;
+
+int pt_set_error(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return pt_set_error(MI3PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct mi3pt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // scene (device)
+    void *d_tris = nullptr, *d_nodes = nullptr, *d_mats = nullptr, *d_env = nullptr, *d_cdf = nullptr;
+    void *d_packets = nullptr, *d_tripk = nullptr;
+    size_t ntris = 0, nnodes = 0, nmats = 0, npackets = 0;
+    uint32_t root_ref = 0;
+    int64_t max_tri_ref = -1;       // largest triangleIndex referenced by a leaf
+    int64_t max_mat_ref = -1;       // largest materialIndex referenced by a triangle
+
+    // textures
+    int width = 0, height = 0, local_rows = 0;
+    int rank = 0, nranks = 1, block_rows = 8;                 // active tile
+    int next_rank = 0, next_nranks = 1, next_block_rows = 8;  // applied at resize
+    float4 *d_radiance = nullptr, *d_accum_own = nullptr, *d_accum = nullptr, *d_canvas = nullptr;
+    uint32_t *d_canvas8 = nullptr;
+    bool output_is_accum = false;
+    uint64_t *d_block_counters = nullptr;
+    int nblocks = 0;
+
+    uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE];
+    uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE];
+    uint8_t u_fs[MI3PT_FULLSCREEN_UNIFORMS_SIZE];
+
+    int storage = MI3PT_STORAGE_F32;
+    int variant = 0;
+
+    bool timing = false;
+    hipEvent_t ev[3][2] = {};
+    bool ev_recorded[3] = { false, false, false };
+};
+
+static inline float ldf(const uint8_t *p, size_t off) { float f; std::memcpy(&f, p + off, 4); return f; }
+static inline int32_t ldi(const uint8_t *p, size_t off) { int32_t v; std::memcpy(&v, p + off, 4); return v; }
+static inline uint32_t ldu(const uint8_t *p, size_t off) { uint32_t v; std::memcpy(&v, p + off, 4); return v; }
+
+static int require_ctx(mi3pt_ctx *ctx)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_abi_version(void) { return MI3PT_ABI_VERSION; }
+extern "C" const char *mi3pt_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int mi3pt_device_count(int *count)
+{
+    if (!count) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_device_name(int device, char *name, size_t capacity)
+{
+    if (!name || capacity == 0) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    std::snprintf(name, capacity, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
+{
+    if (!out_ctx) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return pt_set_error(MI3PT_ERR_NO_DEVICE, "HIP device not found.");
+    }
+    if (device < 0 || device >= n) return pt_set_error(MI3PT_ERR_NO_DEVICE, "HIP device index out of range.");
+    HIP_TRY(hipSetDevice(device));
+    mi3pt_ctx *ctx = new mi3pt_ctx();
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return pt_set_error(MI3PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
+    const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
+    if (hipMalloc(&ctx->d_env, env_bytes) != hipSuccess || hipMalloc(&ctx->d_cdf, env_bytes) != hipSuccess) {
+        mi3pt_destroy(ctx);
+        return pt_set_error(MI3PT_ERR_HIP, "hipMalloc(environment) failed");
+    }
+    (void)hipMemsetAsync(ctx->d_env, 0, env_bytes, ctx->stream);
+    (void)hipMemsetAsync(ctx->d_cdf, 0, env_bytes, ctx->stream);
+    std::memset(ctx->u_rt, 0, sizeof ctx->u_rt);
+    std::memset(ctx->u_acc, 0, sizeof ctx->u_acc);
+    std::memset(ctx->u_fs, 0, sizeof ctx->u_fs);
+    for (int p = 0; p < 3; p++)
+        for (int k = 0; k < 2; k++) (void)hipEventCreate(&ctx->ev[p][k]);
+    *out_ctx = ctx;
+    return MI3PT_OK;
+}
+
+static void free_textures(mi3pt_ctx *ctx)
+{
+    if (ctx->d_radiance) (void)hipFree(ctx->d_radiance);
+    if (ctx->d_accum_own) (void)hipFree(ctx->d_accum_own);
+    if (ctx->d_canvas) (void)hipFree(ctx->d_canvas);
+    if (ctx->d_canvas8) (void)hipFree(ctx->d_canvas8);
+    if (ctx->d_block_counters) (void)hipFree(ctx->d_block_counters);
+    ctx->d_radiance = ctx->d_accum_own = ctx->d_accum = ctx->d_canvas = nullptr;
+    ctx->d_canvas8 = nullptr;
+    ctx->d_block_counters = nullptr;
+    ctx->nblocks = 0;
+}
+
+extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
+{
+    if (!ctx) return MI3PT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_textures(ctx);
+    for (void *p : { ctx->d_tris, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk })
+        if (p) (void)hipFree(p);
+    for (int p = 0; p < 3; p++)
+        for (int k = 0; k < 2; k++)
+            if (ctx->ev[p][k]) (void)hipEventDestroy(ctx->ev[p][k]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_set_stream(mi3pt_ctx *ctx, void *hip_stream)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_set_storage(mi3pt_ctx *ctx, int storage)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    if (storage != MI3PT_STORAGE_F32 && storage != MI3PT_STORAGE_F16)
+        return pt_set_error(MI3PT_ERR_INVALID, "storage must be MI3PT_STORAGE_F32 or MI3PT_STORAGE_F16");
+    ctx->storage = storage;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    if (variant < 0 || variant > 2) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0, 1 or 2");
+    ctx->variant = variant;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_set_tile(mi3pt_ctx *ctx, int rank, int nranks, int block_rows)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    if (nranks <= 0 || rank < 0 || rank >= nranks || block_rows <= 0)
+        return pt_set_error(MI3PT_ERR_INVALID, "bad tile: need 0 <= rank < nranks, block_rows > 0");
+    ctx->next_rank = rank;
+    ctx->next_nranks = nranks;
+    ctx->next_block_rows = block_rows;
+    return MI3PT_OK;
+}
+
+// Replace *dst with a device copy of `bytes`.
+static int replace_buffer(mi3pt_ctx *ctx, void **dst, const void *bytes, size_t nbytes)
+{
+    void *fresh = nullptr;
+    HIP_TRY(hipMalloc(&fresh, nbytes));
+    hipError_t e = hipMemcpyAsync(fresh, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // copy-on-call: caller may reuse `bytes`
+    if (e != hipSuccess) {
+        (void)hipFree(fresh);
+        return pt_set_error(MI3PT_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
+    }
+    if (*dst) (void)hipFree(*dst);
+    *dst = fresh;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (!bytes || nbytes == 0 || nbytes % MI3PT_TRIANGLE_STRIDE)
+        return pt_set_error(MI3PT_ERR_INVALID, "triangle bytes must be a non-zero multiple of 112");
+    const size_t n = nbytes / MI3PT_TRIANGLE_STRIDE;
+    if (n > 0x7fffffffu) return pt_set_error(MI3PT_ERR_INVALID, "too many triangles");
+    const uint8_t *src = static_cast<const uint8_t *>(bytes);
+    std::vector<pt::TriPacket> pk(n);
+    int64_t max_mat = -1;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *t = src + i * MI3PT_TRIANGLE_STRIDE;
+        std::memcpy(pk[i].a, t + 0, 12);
+        std::memcpy(pk[i].b, t + 16, 12);
+        std::memcpy(pk[i].c, t + 32, 12);
+        const int32_t mi = ldi(t, 92);
+        if (mi < 0) return pt_set_error(MI3PT_ERR_INVALID, "triangle with negative materialIndex");
+        pk[i].material = (uint32_t)mi;
+        pk[i].pad0 = pk[i].pad1 = 0;
+        if (mi > max_mat) max_mat = mi;
+    }
+    if (int rc = replace_buffer(ctx, &ctx->d_tris, bytes, nbytes)) return rc;
+    if (int rc = replace_buffer(ctx, &ctx->d_tripk, pk.data(), n * sizeof(pt::TriPacket))) return rc;
+    ctx->ntris = n;
+    ctx->max_mat_ref = max_mat;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_upload_materials(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (!bytes || nbytes == 0 || nbytes % MI3PT_MATERIAL_STRIDE)
+        return pt_set_error(MI3PT_ERR_INVALID, "material bytes must be a non-zero multiple of 64");
+    if (int rc = replace_buffer(ctx, &ctx->d_mats, bytes, nbytes)) return rc;
+    ctx->nmats = nbytes / MI3PT_MATERIAL_STRIDE;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (!bytes || nbytes == 0 || nbytes % MI3PT_BVHNODE_STRIDE)
+        return pt_set_error(MI3PT_ERR_INVALID, "BVH bytes must be a non-zero multiple of 48");
+    const size_t n = nbytes / MI3PT_BVHNODE_STRIDE;
+    if (n > 0x7fffffffu) return pt_set_error(MI3PT_ERR_INVALID, "too many BVH nodes");
+    const uint8_t *src = static_cast<const uint8_t *>(bytes);
+    // Validate and number the internal nodes.  A child must come after its parent
+    // (true of flattenBVH's breadth-first order, raytrace.ts:667-678); that bounds the
+    // walk, so a malformed tree cannot hang the device.
+    std::vector<uint32_t> packet_of(n, pt::REF_NONE);
+    size_t npackets = 0;
+    int64_t max_tri = -1;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+        if (ldi(r, 28) == 1) {
+            const int32_t ti = ldi(r, 40);
+            if (ti < 0) return pt_set_error(MI3PT_ERR_INVALID, "leaf node with negative triangleIndex");
+            if (ti > max_tri) max_tri = ti;
+        } else {
+            for (size_t off : { (size_t)32, (size_t)36 }) {
+                const int32_t c = ldi(r, off);
+                if (c >= 0 && ((size_t)c >= n || (size_t)c <= i))
+                    return pt_set_error(MI3PT_ERR_INVALID,
+                                        "BVH child index must be greater than its parent's and inside the buffer "
+                                        "(breadth-first order, raytrace.ts:667-694)");
+            }
+            packet_of[i] = (uint32_t)npackets++;
+        }
+    }
+    auto ref_of = [&](int32_t child) -> uint32_t {
+        if (child < 0) return pt::REF_NONE;
+        const uint8_t *r = src + (size_t)child * MI3PT_BVHNODE_STRIDE;
+        if (ldi(r, 28) == 1) return 0x80000000u | (uint32_t)ldi(r, 40);
+        return packet_of[child];
+    };
+    std::vector<pt::NodePacket> pk(npackets ? npackets : 1);
+    std::memset(pk.data(), 0, pk.size() * sizeof(pt::NodePacket));
+    for (size_t i = 0; i < n; i++) {
+        if (packet_of[i] == pt::REF_NONE) continue;
+        const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+        pt::NodePacket &p = pk[packet_of[i]];
+        const int32_t left = ldi(r, 32), right = ldi(r, 36);
+        if (left >= 0) {
+            const uint8_t *c = src + (size_t)left * MI3PT_BVHNODE_STRIDE;
+            std::memcpy(p.lmin, c + 0, 12);
+            std::memcpy(p.lmax, c + 16, 12);
+        }
+        if (right >= 0) {
+            const uint8_t *c = src + (size_t)right * MI3PT_BVHNODE_STRIDE;
+            std::memcpy(p.rmin, c + 0, 12);
+            std::memcpy(p.rmax, c + 16, 12);
+        }
+        p.lref = ref_of(left);
+        p.rref = ref_of(right);
+    }
+    if (int rc = replace_buffer(ctx, &ctx->d_nodes, bytes, nbytes)) return rc;
+    if (int rc = replace_buffer(ctx, &ctx->d_packets, pk.data(), pk.size() * sizeof(pt::NodePacket))) return rc;
+    ctx->nnodes = n;
+    ctx->npackets = npackets;
+    ctx->root_ref = ref_of(0);
+    ctx->max_tri_ref = max_tri;
+    return MI3PT_OK;
+}
+
+static int upload_env_like(mi3pt_ctx *ctx, void *dst, const float *rgba, int width, int height)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (!rgba) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (width != MI3PT_ENV_WIDTH || height != MI3PT_ENV_HEIGHT)   // renderer.ts:133-137
+        return pt_set_error(MI3PT_ERR_INVALID,
+                            "Environment texture must be 1024x512 pixels. Please resize the texture and try again.");
+    const size_t nbytes = (size_t)width * height * 16;
+    HIP_TRY(hipMemcpyAsync(dst, rgba, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_upload_environment(mi3pt_ctx *ctx, const float *rgba, int width, int height)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    return upload_env_like(ctx, ctx->d_env, rgba, width, height);
+}
+
+extern "C" int mi3pt_upload_environment_cdf(mi3pt_ctx *ctx, const float *rgba, int width, int height)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    return upload_env_like(ctx, ctx->d_cdf, rgba, width, height);
+}
+
+static pt::Tile tile_of(const mi3pt_ctx *ctx)
+{
+    pt::Tile t;
+    t.tex_w = ctx->width; t.tex_h = ctx->height; t.local_rows = ctx->local_rows;
+    t.rank = ctx->rank; t.nranks = ctx->nranks; t.block_rows = ctx->block_rows;
+    return t;
+}
+
+static int zero_textures(mi3pt_ctx *ctx)
+{
+    const size_t tex_bytes = (size_t)ctx->local_rows * ctx->width * 16;
+    const size_t canvas_px = (size_t)ctx->width * ctx->height;
+    if (tex_bytes) {
+        HIP_TRY(hipMemsetAsync(ctx->d_radiance, 0, tex_bytes, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_accum, 0, tex_bytes, ctx->stream));
+    }
+    if (canvas_px) {
+        HIP_TRY(hipMemsetAsync(ctx->d_canvas, 0, canvas_px * 16, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_canvas8, 0, canvas_px * 4, ctx->stream));
+    }
+    ctx->output_is_accum = false;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
+        return pt_set_error(MI3PT_ERR_INVALID, "width/height must be in [1, 32768]");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_textures(ctx);
+    ctx->rank = ctx->next_rank; ctx->nranks = ctx->next_nranks; ctx->block_rows = ctx->next_block_rows;
+    ctx->width = width; ctx->height = height;
+    ctx->local_rows = mi3pt_tile_local_rows(height, ctx->rank, ctx->nranks, ctx->block_rows);
+    const size_t tex_bytes = (size_t)ctx->local_rows * width * 16;
+    const size_t canvas_px = (size_t)width * height;
+    HIP_TRY(hipMalloc((void **)&ctx->d_radiance, tex_bytes ? tex_bytes : 16));
+    HIP_TRY(hipMalloc((void **)&ctx->d_accum_own, tex_bytes ? tex_bytes : 16));
+    ctx->d_accum = ctx->d_accum_own;
+    HIP_TRY(hipMalloc((void **)&ctx->d_canvas, canvas_px * 16));
+    HIP_TRY(hipMalloc((void **)&ctx->d_canvas8, canvas_px * 4));
+    ctx->nblocks = pt::raytrace_grid_blocks(tile_of(ctx));
+    const size_t cbytes = (size_t)(ctx->nblocks ? ctx->nblocks : 1) * pt::CNT_COUNT * sizeof(uint64_t);
+    HIP_TRY(hipMalloc((void **)&ctx->d_block_counters, cbytes));
+    HIP_TRY(hipMemsetAsync(ctx->d_block_counters, 0, cbytes, ctx->stream));
+    return zero_textures(ctx);
+}
+
+extern "C" int mi3pt_reset(mi3pt_ctx *ctx)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "reset before resize");
+    return zero_textures(ctx);
+}
+
+extern "C" int mi3pt_set_uniforms(mi3pt_ctx *ctx, int pass, const void *bytes, size_t nbytes)
+{
+    if (!ctx || !bytes) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    switch (pass) {
+    case MI3PT_PASS_RAYTRACE:
+        if (nbytes != sizeof ctx->u_rt) return pt_set_error(MI3PT_ERR_INVALID, "raytrace uniforms are 96 bytes");
+        std::memcpy(ctx->u_rt, bytes, nbytes);
+        return MI3PT_OK;
+    case MI3PT_PASS_ACCUMULATE:
+        if (nbytes != sizeof ctx->u_acc) return pt_set_error(MI3PT_ERR_INVALID, "accumulate uniforms are 16 bytes");
+        std::memcpy(ctx->u_acc, bytes, nbytes);
+        return MI3PT_OK;
+    case MI3PT_PASS_FULLSCREEN:
+        if (nbytes != sizeof ctx->u_fs) return pt_set_error(MI3PT_ERR_INVALID, "fullscreen uniforms are 24 bytes");
+        std::memcpy(ctx->u_fs, bytes, nbytes);
+        return MI3PT_OK;
+    default:
+        return pt_set_error(MI3PT_ERR_INVALID, "unknown pass");
+    }
+}
+
+static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
+{
+    pt::SceneRefs s;
+    s.tris = static_cast<const float4 *>(ctx->d_tris);
+    s.nodes = static_cast<const float4 *>(ctx->d_nodes);
+    s.mats = static_cast<const float4 *>(ctx->d_mats);
+    s.env = static_cast<const float4 *>(ctx->d_env);
+    s.packets = static_cast<const float4 *>(ctx->d_packets);
+    s.tripk = static_cast<const float4 *>(ctx->d_tripk);
+    s.ntris = (uint32_t)ctx->ntris; s.nnodes = (uint32_t)ctx->nnodes; s.nmats = (uint32_t)ctx->nmats;
+    s.npackets = (uint32_t)ctx->npackets;
+    s.root_ref = ctx->root_ref;
+    s.env_w = MI3PT_ENV_WIDTH; s.env_h = MI3PT_ENV_HEIGHT;
+    return s;
+}
+
+// The scene is complete when the three buffers agree with each other.  An empty
+// scene (no BVH uploaded) is legal: every ray misses (raytrace.wgsl:206-207).
+static int check_scene(const mi3pt_ctx *ctx)
+{
+    if (ctx->nnodes == 0) return MI3PT_OK;
+    if (ctx->max_tri_ref >= (int64_t)ctx->ntris)
+        return pt_set_error(MI3PT_ERR_STATE, "BVH references a triangle index beyond the triangle buffer");
+    if (ctx->max_tri_ref >= 0 && ctx->max_mat_ref >= (int64_t)ctx->nmats)
+        return pt_set_error(MI3PT_ERR_STATE, "a triangle references a material index beyond the material buffer");
+    return MI3PT_OK;
+}
+
+static int pick_variant(const mi3pt_ctx *ctx) { return ctx->variant == 1 ? 1 : 2; }
+
+static pt::AccUniforms acc_uniforms(const mi3pt_ctx *ctx)
+{
+    pt::AccUniforms a;
+    a.res_w = ldu(ctx->u_acc, 0); a.res_h = ldu(ctx->u_acc, 4);
+    a.frame = ldu(ctx->u_acc, 8); a.enabled = ldu(ctx->u_acc, 12);
+    return a;
+}
+
+extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "submit before resize");
+    if (pass_mask & ~(MI3PT_SUBMIT_RAYTRACE | MI3PT_SUBMIT_ACCUMULATE | MI3PT_SUBMIT_FULLSCREEN))
+        return pt_set_error(MI3PT_ERR_INVALID, "unknown bits in pass_mask");
+    const bool do_rt = pass_mask & MI3PT_SUBMIT_RAYTRACE, do_acc = pass_mask & MI3PT_SUBMIT_ACCUMULATE;
+    const bool do_fs = pass_mask & MI3PT_SUBMIT_FULLSCREEN;
+    const pt::Tile tile = tile_of(ctx);
+    const pt::AccUniforms acc = acc_uniforms(ctx);
+    bool fused = false;
+    for (bool &r : ctx->ev_recorded) r = false;
+
+    if (do_rt) {
+        if (int rc = check_scene(ctx)) return rc;
+        pt::RtLaunch L;
+        L.scene = scene_refs(ctx);
+        const uint8_t *u = ctx->u_rt;
+        L.un.res_x = ldf(u, 0); L.un.res_y = ldf(u, 4); L.un.aspect = ldf(u, 8);
+        L.un.frame = ldu(u, 12);
+        L.un.max_bounces = ldi(u, 16); L.un.samples_per_frame = ldi(u, 20);
+        for (int k = 0; k < 3; k++) { L.un.cam_pos[k] = ldf(u, 32 + 4 * k); L.un.cam_dir[k] = ldf(u, 48 + 4 * k); }
+        L.un.fov = ldf(u, 60); L.un.focal_distance = ldf(u, 64); L.un.aperture = ldf(u, 68);
+        L.un.env_intensity = ldf(u, 80); L.un.env_rotation = ldf(u, 84);
+        L.acc = acc;
+        L.tile = tile;
+        L.radiance = ctx->d_radiance;
+        L.accum = ctx->d_accum;
+        L.block_counters = ctx->d_block_counters;
+        L.store_f16 = ctx->storage == MI3PT_STORAGE_F16;
+        // Fuse when the accumulate pass covers exactly the pixels the raytrace pass writes.
+        fused = do_acc && acc.res_w == (uint32_t)L.un.res_x && acc.res_h == (uint32_t)L.un.res_y;
+        if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0][0], ctx->stream));
+        pt::launch_raytrace(L, fused, pick_variant(ctx), ctx->stream);
+        HIP_TRY(hipGetLastError());
+        if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[0][1], ctx->stream)); ctx->ev_recorded[0] = true; }
+        ctx->output_is_accum = fused;
+    }
+    if (do_acc && !fused) {
+        if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1][0], ctx->stream));
+        pt::launch_accumulate(acc, tile, ctx->d_radiance, ctx->d_accum, ctx->storage == MI3PT_STORAGE_F16, ctx->stream);
+        HIP_TRY(hipGetLastError());
+        if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[1][1], ctx->stream)); ctx->ev_recorded[1] = true; }
+        ctx->output_is_accum = true;   // accumulate.ts:171-175 copies the mean into outputTexture
+    }
+    if (do_fs) {
+        if (ctx->nranks != 1)
+            return pt_set_error(MI3PT_ERR_STATE,
+                                "the fullscreen pass needs the whole image: gather the tiles into a 1-rank context");
+        pt::FsUniforms fs;
+        fs.res_x = ldf(ctx->u_fs, 0); fs.res_y = ldf(ctx->u_fs, 4); fs.aspect = ldf(ctx->u_fs, 8);
+        fs.scaling = ldf(ctx->u_fs, 12); fs.denoise = ldu(ctx->u_fs, 16); fs.tonemapping = ldu(ctx->u_fs, 20);
+        const float4 *tex = ctx->output_is_accum ? ctx->d_accum : ctx->d_radiance;
+        if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2][0], ctx->stream));
+        pt::launch_fullscreen(fs, tex, ctx->width, ctx->height, ctx->width, ctx->height, ctx->d_canvas,
+                              ctx->d_canvas8, ctx->stream);
+        HIP_TRY(hipGetLastError());
+        if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[2][1], ctx->stream)); ctx->ev_recorded[2] = true; }
+    }
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_sync(mi3pt_ctx *ctx)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t nfloats)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (!dst) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "read before resize");
+    const float4 *src;
+    size_t need;
+    switch (which) {
+    case MI3PT_TEX_OUTPUT:
+        src = ctx->output_is_accum ? ctx->d_accum : ctx->d_radiance;
+        need = (size_t)ctx->local_rows * ctx->width * 4;
+        break;
+    case MI3PT_TEX_ACCUMULATION:
+        src = ctx->d_accum;
+        need = (size_t)ctx->local_rows * ctx->width * 4;
+        break;
+    case MI3PT_TEX_CANVAS:
+        src = ctx->d_canvas;
+        need = (size_t)ctx->height * ctx->width * 4;
+        break;
+    default:
+        return pt_set_error(MI3PT_ERR_INVALID, "unknown texture");
+    }
+    if (nfloats != need) return pt_set_error(MI3PT_ERR_INVALID, "destination size does not match the texture");
+    if (need == 0) return MI3PT_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, need * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_read_canvas_rgba8(mi3pt_ctx *ctx, uint8_t *dst, size_t nbytes)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (!dst) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "read before resize");
+    const size_t need = (size_t)ctx->width * ctx->height * 4;
+    if (nbytes != need) return pt_set_error(MI3PT_ERR_INVALID, "destination size does not match the canvas");
+    HIP_TRY(hipMemcpyAsync(dst, ctx->d_canvas8, need, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_accumulation_device_ptr(mi3pt_ctx *ctx, void **dev_ptr, size_t *nbytes)
+{
+    if (!ctx || !dev_ptr) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "no textures before resize");
+    *dev_ptr = ctx->d_accum;
+    if (nbytes) *nbytes = (size_t)ctx->local_rows * ctx->width * 16;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_bind_accumulation(mi3pt_ctx *ctx, void *dev_ptr, size_t nbytes)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "bind before resize");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!dev_ptr) {
+        ctx->d_accum = ctx->d_accum_own;
+        return MI3PT_OK;
+    }
+    if (nbytes != (size_t)ctx->local_rows * ctx->width * 16)
+        return pt_set_error(MI3PT_ERR_INVALID, "external accumulation buffer must be local_rows*width*16 bytes");
+    if (reinterpret_cast<uintptr_t>(dev_ptr) % 16)
+        return pt_set_error(MI3PT_ERR_INVALID, "external accumulation buffer must be 16-byte aligned");
+    ctx->d_accum = static_cast<float4 *>(dev_ptr);
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_enable_timing(mi3pt_ctx *ctx, int enabled)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    ctx->timing = enabled != 0;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (!microseconds || pass < 0 || pass > 2) return pt_set_error(MI3PT_ERR_INVALID, "bad argument");
+    if (!ctx->ev_recorded[pass]) return pt_set_error(MI3PT_ERR_STATE, "pass was not timed in the last submit");
+    HIP_TRY(hipEventSynchronize(ctx->ev[pass][1]));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[pass][0], ctx->ev[pass][1]));
+    *microseconds = ms * 1000.0f;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT])
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (!out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    for (int k = 0; k < MI3PT_CNT_COUNT; k++) out[k] = 0;
+    if (ctx->nblocks == 0) return MI3PT_OK;
+    std::vector<uint64_t> host((size_t)ctx->nblocks * pt::CNT_COUNT);
+    HIP_TRY(hipMemcpyAsync(host.data(), ctx->d_block_counters, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < ctx->nblocks; b++)
+        for (int k = 0; k < MI3PT_CNT_COUNT; k++) out[k] += host[(size_t)b * pt::CNT_COUNT + k];
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_reset_counters(mi3pt_ctx *ctx)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (ctx->nblocks == 0) return MI3PT_OK;
+    HIP_TRY(hipMemsetAsync(ctx->d_block_counters, 0, (size_t)ctx->nblocks * pt::CNT_COUNT * 8, ctx->stream));
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n, float *out)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (!rays || !out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (int rc = check_scene(ctx)) return rc;
+    if (n == 0) return MI3PT_OK;
+    float *d_rays = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rays, n * 24));
+    if (hipMalloc((void **)&d_out, n * 48) != hipSuccess) {
+        (void)hipFree(d_rays);
+        return pt_set_error(MI3PT_ERR_HIP, "hipMalloc failed");
+    }
+    hipError_t e = hipMemcpyAsync(d_rays, rays, n * 24, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        pt::launch_debug_intersect(scene_refs(ctx), d_rays, n, d_out, pick_variant(ctx), ctx->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * 48, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("debug_intersect: ") + hipGetErrorString(e));
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    if (!a || !out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (n == 0) return MI3PT_OK;
+    float *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+    hipError_t e = hipMalloc((void **)&d_a, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_o, n * 4);
+    if (e == hipSuccess && b) e = hipMalloc((void **)&d_b, n * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_a, a, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && b) e = hipMemcpyAsync(d_b, b, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        pt::launch_debug_math(fn, d_a, d_b, d_o, n, ctx->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (d_o) (void)hipFree(d_o);
+    if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("debug_math: ") + hipGetErrorString(e));
+    return MI3PT_OK;
+}

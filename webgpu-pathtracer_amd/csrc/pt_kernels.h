@@ -1,0 +1,97 @@
+// pt_kernels.h -- parameter blocks shared by the kernel file and the context.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pt {
+
+// per-pass counters, see mi3pt_counter in include/mi3pt.h
+enum { CNT_RAYS, CNT_BOX, CNT_TRI, CNT_HIT, CNT_MISS, CNT_OVERFLOW, CNT_PIXELS, CNT_RESERVED, CNT_COUNT };
+
+// child references carried by node packets and by the packet walk's stack
+constexpr uint32_t REF_LEAF = 0x80000000u;   // | triangleIndex
+constexpr uint32_t REF_NONE = 0xffffffffu;   // absent child (left/right < 0)
+
+// "BVH node packet": one 64-byte record per INTERNAL node holding both children's
+// boxes and what is needed to continue below them, so that one aligned 64-B read
+// replaces the reference walk's three 48-B record reads per internal node
+// (raytrace.wgsl:175, 185, 193).  Values are bit copies of the uploaded records.
+struct NodePacket {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    uint32_t lref, rref;     // child reference: leaf -> 0x80000000 | triangleIndex, else packet index
+    uint32_t pad[2];
+};
+static_assert(sizeof(NodePacket) == 64, "packet is one 64-B line");
+
+// 48-byte triangle record for intersection only (positions + material index); the
+// vertex normals (only needed for the one closest hit per ray) stay in the uploaded
+// 112-B records.
+struct TriPacket {
+    float a[3]; uint32_t material;
+    float b[3]; uint32_t pad0;
+    float c[3]; uint32_t pad1;
+};
+static_assert(sizeof(TriPacket) == 48, "three 16-B vectors");
+
+struct SceneRefs {
+    const float4 *tris;     // reference layout, 7 x float4 per triangle
+    const float4 *nodes;    // reference layout, 3 x float4 per node
+    const float4 *mats;     // reference layout, 4 x float4 per material
+    const float4 *env;      // rgba32float texels
+    const float4 *packets;  // NodePacket array (internal nodes, breadth-first), or null
+    const float4 *tripk;    // TriPacket array, or null
+    uint32_t ntris, nnodes, nmats, npackets;
+    uint32_t root_ref;      // reference of node 0 in packet terms
+    int32_t env_w, env_h;
+};
+
+// raytrace.wgsl:66-75, decoded from the 96-byte block
+struct RtUniforms {
+    float res_x, res_y, aspect;
+    uint32_t frame;
+    int32_t max_bounces, samples_per_frame;
+    float cam_pos[3], cam_dir[3];
+    float fov, focal_distance, aperture;
+    float env_intensity, env_rotation;
+};
+
+// accumulate.wgsl:1-5
+struct AccUniforms {
+    uint32_t res_w, res_h, frame, enabled;
+};
+
+// fullscreen.wgsl:14-20
+struct FsUniforms {
+    float res_x, res_y, aspect, scaling;
+    uint32_t denoise, tonemapping;
+};
+
+struct Tile {
+    int32_t tex_w, tex_h;        // full texture size
+    int32_t local_rows;          // rows held by this rank
+    int32_t rank, nranks, block_rows;
+};
+
+struct RtLaunch {
+    SceneRefs scene;
+    RtUniforms un;
+    AccUniforms acc;
+    Tile tile;
+    float4 *radiance;            // per-frame output (unfused) -- may be null when fused
+    float4 *accum;               // running mean
+    uint64_t *block_counters;    // [gridDim.x][CNT_COUNT]
+    int32_t store_f16;
+};
+
+void launch_raytrace(const RtLaunch &L, bool fuse_accumulate, int variant, hipStream_t s);
+void launch_accumulate(const AccUniforms &acc, const Tile &tile, const float4 *input, float4 *accum,
+                       int store_f16, hipStream_t s);
+void launch_fullscreen(const FsUniforms &fs, const float4 *tex, int tex_w, int tex_h,
+                       int canvas_w, int canvas_h, float4 *out_f32, uint32_t *out_rgba8, hipStream_t s);
+void launch_debug_intersect(const SceneRefs &scene, const float *rays, size_t n, float *out, int variant,
+                            hipStream_t s);
+void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s);
+int raytrace_grid_blocks(const Tile &tile);
+
+}  // namespace pt

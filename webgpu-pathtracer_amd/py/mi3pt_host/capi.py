@@ -1,0 +1,289 @@
+"""ctypes binding of libmi3pt.so (include/mi3pt.h).
+
+Thin by design: one Python method per C entry point, numpy arrays in and out, status
+codes turned into `Mi3ptError` (the way the N-API shim turns them into thrown Errors).
+No compute happens here and there is no fallback: if the library or a HIP device is
+missing the calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_PATH = os.path.join(PKG_ROOT, "libmi3pt.so")
+
+PASS_RAYTRACE, PASS_ACCUMULATE, PASS_FULLSCREEN = 0, 1, 2
+SUBMIT_RAYTRACE, SUBMIT_ACCUMULATE, SUBMIT_FULLSCREEN = 1, 2, 4
+TEX_OUTPUT, TEX_ACCUMULATION, TEX_CANVAS = 0, 1, 2
+STORAGE_F32, STORAGE_F16 = 0, 1
+COUNTER_NAMES = ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels", "reserved")
+
+# every symbol include/mi3pt.h declares; tests/test_capi_symbols.py checks the header
+# against this list and against the built library.
+SYMBOLS = (
+    "mi3pt_abi_version", "mi3pt_last_error", "mi3pt_device_count", "mi3pt_device_name",
+    "mi3pt_create", "mi3pt_destroy", "mi3pt_set_stream", "mi3pt_set_storage", "mi3pt_set_tile",
+    "mi3pt_tile_local_rows", "mi3pt_upload_triangles", "mi3pt_upload_materials", "mi3pt_upload_bvh",
+    "mi3pt_upload_environment", "mi3pt_upload_environment_cdf", "mi3pt_resize", "mi3pt_reset",
+    "mi3pt_set_uniforms", "mi3pt_submit", "mi3pt_sync", "mi3pt_read_texture", "mi3pt_read_canvas_rgba8",
+    "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
+    "mi3pt_pass_time_us", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
+    "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
+    "mi3pt_host_env_cdf",
+)
+
+
+class Mi3ptError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"mi3pt error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libmi3pt.so (built by webgpu-pathtracer_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise Mi3ptError(-1, f"{path} not found: build it with `make -C webgpu-pathtracer_amd/csrc` "
+                             "(or __graft_entry__.build())")
+    lib = ctypes.CDLL(path)
+    c_void_p, c_size_t, c_int = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.mi3pt_last_error.restype = ctypes.c_char_p
+    lib.mi3pt_create.argtypes = [c_int, ctypes.POINTER(c_void_p)]
+    lib.mi3pt_destroy.argtypes = [c_void_p]
+    lib.mi3pt_set_stream.argtypes = [c_void_p, c_void_p]
+    lib.mi3pt_set_storage.argtypes = [c_void_p, c_int]
+    lib.mi3pt_set_tile.argtypes = [c_void_p, c_int, c_int, c_int]
+    lib.mi3pt_set_kernel_variant.argtypes = [c_void_p, c_int]
+    for name in ("mi3pt_upload_triangles", "mi3pt_upload_materials", "mi3pt_upload_bvh"):
+        getattr(lib, name).argtypes = [c_void_p, c_void_p, c_size_t]
+    for name in ("mi3pt_upload_environment", "mi3pt_upload_environment_cdf"):
+        getattr(lib, name).argtypes = [c_void_p, c_void_p, c_int, c_int]
+    lib.mi3pt_resize.argtypes = [c_void_p, c_int, c_int]
+    lib.mi3pt_reset.argtypes = [c_void_p]
+    lib.mi3pt_set_uniforms.argtypes = [c_void_p, c_int, c_void_p, c_size_t]
+    lib.mi3pt_submit.argtypes = [c_void_p, ctypes.c_uint]
+    lib.mi3pt_sync.argtypes = [c_void_p]
+    lib.mi3pt_read_texture.argtypes = [c_void_p, c_int, c_void_p, c_size_t]
+    lib.mi3pt_read_canvas_rgba8.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.mi3pt_accumulation_device_ptr.argtypes = [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t)]
+    lib.mi3pt_bind_accumulation.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.mi3pt_enable_timing.argtypes = [c_void_p, c_int]
+    lib.mi3pt_pass_time_us.argtypes = [c_void_p, c_int, ctypes.POINTER(ctypes.c_float)]
+    lib.mi3pt_get_counters.argtypes = [c_void_p, c_void_p]
+    lib.mi3pt_reset_counters.argtypes = [c_void_p]
+    lib.mi3pt_debug_intersect.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.mi3pt_debug_math.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t]
+    lib.mi3pt_host_build_bvh.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
+    lib.mi3pt_host_build_bvh_f64.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
+    lib.mi3pt_host_env_cdf.argtypes = [c_void_p, c_int, c_int, c_void_p]
+    lib.mi3pt_device_count.argtypes = [ctypes.POINTER(c_int)]
+    lib.mi3pt_device_name.argtypes = [c_int, ctypes.c_char_p, c_size_t]
+    lib.mi3pt_tile_local_rows.argtypes = [c_int, c_int, c_int, c_int]
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise Mi3ptError(rc, lib.mi3pt_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(arr):
+    return arr.ctypes.data_as(ctypes.c_void_p)
+
+
+def device_count():
+    lib = load_library()
+    n = ctypes.c_int(0)
+    _check(lib, lib.mi3pt_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_name(device=0):
+    lib = load_library()
+    buf = ctypes.create_string_buffer(256)
+    _check(lib, lib.mi3pt_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+def tile_local_rows(height, rank, nranks, block_rows):
+    return load_library().mi3pt_tile_local_rows(height, rank, nranks, block_rows)
+
+
+# ---- host-side scene compile (no device) ----
+
+def host_build_bvh(triangles, nthreads=0):
+    """triangles: structured array (layout.TRIANGLE) or raw bytes -> BVH_NODE array."""
+    from . import layout
+    lib = load_library()
+    tri = np.ascontiguousarray(triangles)
+    n = tri.nbytes // 112
+    nodes = np.zeros(max(2 * n - 1, 1), layout.BVH_NODE)
+    count = ctypes.c_size_t(0)
+    _check(lib, lib.mi3pt_host_build_bvh(_ptr(tri), n, _ptr(nodes), nodes.nbytes, ctypes.byref(count), nthreads))
+    return nodes[:count.value]
+
+
+def host_build_bvh_f64(positions, nthreads=0):
+    """positions: (n, 3, 3) float64 world-space triangle vertices."""
+    from . import layout
+    lib = load_library()
+    pos = np.ascontiguousarray(positions, np.float64)
+    n = pos.size // 9
+    nodes = np.zeros(max(2 * n - 1, 1), layout.BVH_NODE)
+    count = ctypes.c_size_t(0)
+    _check(lib, lib.mi3pt_host_build_bvh_f64(_ptr(pos), n, _ptr(nodes), nodes.nbytes, ctypes.byref(count), nthreads))
+    return nodes[:count.value]
+
+
+def host_env_cdf(rgba):
+    lib = load_library()
+    env = np.ascontiguousarray(rgba, np.float32)
+    h, w = env.shape[0], env.shape[1]
+    out = np.empty((h, w, 4), np.float32)
+    _check(lib, lib.mi3pt_host_env_cdf(_ptr(env), w, h, _ptr(out)))
+    return out
+
+
+class Context:
+    """One mi3pt_ctx: a HIP device + stream + the path tracer's device resources."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        handle = ctypes.c_void_p()
+        _check(self.lib, self.lib.mi3pt_create(device, ctypes.byref(handle)))
+        self.handle = handle
+        self.width = self.height = 0
+        self.local_rows = 0
+        self._tile = (0, 1, 8)
+        self._next_tile = (0, 1, 8)
+
+    def close(self):
+        if self.handle:
+            self.lib.mi3pt_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _c(self, rc):
+        _check(self.lib, rc)
+
+    def set_stream(self, stream_ptr):
+        self._c(self.lib.mi3pt_set_stream(self.handle, stream_ptr))
+
+    def set_storage(self, storage):
+        self._c(self.lib.mi3pt_set_storage(self.handle, storage))
+
+    def set_kernel_variant(self, variant):
+        self._c(self.lib.mi3pt_set_kernel_variant(self.handle, variant))
+
+    def set_tile(self, rank, nranks, block_rows=8):
+        self._c(self.lib.mi3pt_set_tile(self.handle, rank, nranks, block_rows))
+        self._next_tile = (rank, nranks, block_rows)
+
+    def upload_triangles(self, tris):
+        a = np.ascontiguousarray(tris)
+        self._c(self.lib.mi3pt_upload_triangles(self.handle, _ptr(a), a.nbytes))
+
+    def upload_materials(self, mats):
+        a = np.ascontiguousarray(mats)
+        self._c(self.lib.mi3pt_upload_materials(self.handle, _ptr(a), a.nbytes))
+
+    def upload_bvh(self, nodes):
+        a = np.ascontiguousarray(nodes)
+        self._c(self.lib.mi3pt_upload_bvh(self.handle, _ptr(a), a.nbytes))
+
+    def upload_environment(self, rgba):
+        a = np.ascontiguousarray(rgba, np.float32)
+        self._c(self.lib.mi3pt_upload_environment(self.handle, _ptr(a), a.shape[1], a.shape[0]))
+
+    def upload_environment_cdf(self, rgba):
+        a = np.ascontiguousarray(rgba, np.float32)
+        self._c(self.lib.mi3pt_upload_environment_cdf(self.handle, _ptr(a), a.shape[1], a.shape[0]))
+
+    def resize(self, width, height):
+        self._c(self.lib.mi3pt_resize(self.handle, width, height))
+        self.width, self.height = width, height
+        self._tile = self._next_tile
+        self.local_rows = tile_local_rows(height, *self._tile)
+
+    def reset(self):
+        self._c(self.lib.mi3pt_reset(self.handle))
+
+    def set_uniforms(self, which, data):
+        b = data if isinstance(data, (bytes, bytearray)) else data.tobytes()
+        self._c(self.lib.mi3pt_set_uniforms(self.handle, which, b, len(b)))
+
+    def submit(self, mask):
+        self._c(self.lib.mi3pt_submit(self.handle, mask))
+
+    def sync(self):
+        self._c(self.lib.mi3pt_sync(self.handle))
+
+    def read_texture(self, which):
+        rows = self.height if which == TEX_CANVAS else self.local_rows
+        out = np.empty((rows, self.width, 4), np.float32)
+        self._c(self.lib.mi3pt_read_texture(self.handle, which, _ptr(out), out.size))
+        return out
+
+    def read_canvas_rgba8(self):
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        self._c(self.lib.mi3pt_read_canvas_rgba8(self.handle, _ptr(out), out.nbytes))
+        return out
+
+    def accumulation_device_ptr(self):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._c(self.lib.mi3pt_accumulation_device_ptr(self.handle, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def bind_accumulation(self, dev_ptr, nbytes):
+        self._c(self.lib.mi3pt_bind_accumulation(self.handle, dev_ptr, nbytes))
+
+    def enable_timing(self, enabled=True):
+        self._c(self.lib.mi3pt_enable_timing(self.handle, int(enabled)))
+
+    def pass_time_us(self, which):
+        v = ctypes.c_float()
+        self._c(self.lib.mi3pt_pass_time_us(self.handle, which, ctypes.byref(v)))
+        return v.value
+
+    def counters(self):
+        out = np.zeros(8, np.uint64)
+        self._c(self.lib.mi3pt_get_counters(self.handle, _ptr(out)))
+        return dict(zip(COUNTER_NAMES, (int(x) for x in out)))
+
+    def reset_counters(self):
+        self._c(self.lib.mi3pt_reset_counters(self.handle))
+
+    def debug_intersect(self, rays):
+        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.empty((len(r), 12), np.float32)
+        self._c(self.lib.mi3pt_debug_intersect(self.handle, _ptr(r), len(r), _ptr(out)))
+        return out
+
+    def debug_math(self, fn, a, b=None):
+        a = np.ascontiguousarray(a, np.float32)
+        out = np.empty_like(a)
+        bb = np.ascontiguousarray(b, np.float32) if b is not None else None
+        self._c(self.lib.mi3pt_debug_math(self.handle, fn, _ptr(a), _ptr(bb) if bb is not None else None,
+                                          _ptr(out), a.size))
+        return out
