@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--image", default=None, help="WxH override (experiments only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -123,6 +124,8 @@ def main():
         dist.barrier()
 
     width, height = image_size(world, args.scaling)
+    if args.image:
+        width, height = (int(v) for v in args.image.lower().split("x"))
     sc, env = build_scene(args.workload)
     bounces = 8
 

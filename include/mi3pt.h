@@ -187,7 +187,8 @@ int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds);
 int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT]);
 int mi3pt_reset_counters(mi3pt_ctx *ctx);
 
-/* Kernel variant: 0 = auto, 1 = generic reference-layout walk, 2 = packet walk
+/* Kernel variant: 0 = auto (3), 1 = per-pixel kernel walking the uploaded records,
+ * 2 = per-pixel kernel walking node packets, 3 = persistent waves with lane refill
  * (needs child adjacency right == left + 1, which flattenBVH guarantees). */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
 
@@ -199,6 +200,11 @@ int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n, float *ou
 /* fn: 0 sin, 1 cos, 2 tan, 3 log, 4 exp, 5 atan2(a,b), 6 asin, 7 pow(a,b),
  * 8 fp16 round trip, 9 sqrt, 10 a/b.  b may be NULL for unary functions. */
 int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n);
+
+/* Diagnostic stamps of the last persistent raytrace launch: 4 x uint64 per resident wave
+ * (begin, work-queue-empty, end on the 100 MHz wall clock; shader cycles begin->end).
+ * out == NULL: enable != 0 allocates the buffer, enable == 0 frees it. */
+int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out, size_t capacity_slots, size_t *slots_out);
 
 /* ---- host-side scene compile (CPU, no device needed) ----
  * mi3pt_host_build_bvh: buildBVH + buildBVHRecursive + flattenBVH,

@@ -58,7 +58,7 @@ def _random_rays(rng, n, origin_scale=3.0):
     return np.concatenate([o, d], axis=1).astype(np.float32)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])
 def test_ray_scene_intersect_matches_oracle(gpu_ctx, orc, demo, env, variant):
     ctx = gpu_ctx
     pc.upload_scene(ctx, demo, env)
@@ -69,7 +69,13 @@ def test_ray_scene_intersect_matches_oracle(gpu_ctx, orc, demo, env, variant):
     special = np.array([[0, 5, 0.5, 0, -1, 0], [0, 0.4, 5, 0, 0, -1], [-5, 0.4, 0.5, 1, 0, 0],
                         [0.4, 5, 0.5, 0, -1, 0], [0.4, 5, 0.9, 0, -1, 0], [0, 0, 0, 0, 1, 0],
                         [2.5, 1, 2.5, 0, -1, 0], [0, 1e-7, 0, 1, 0, 0]], np.float32)
-    rays = np.concatenate([rays, special])
+    # directions whose significand is all ones / origins outside the guarded range force the
+    # exact-division fallback of the prepared-reciprocal slab test (RayPre::slow)
+    ones = np.frombuffer(np.array([0x3f7fffff, 0x3effffff, 0xbf7fffff, 0x3f7ffff3], np.uint32).tobytes(), np.float32)
+    guard = np.array([[0.3, 2.0, 0.2, ones[1], -ones[0], ones[1] * 0.5], [0, 3, 0.5, 0.1, ones[2], 0.05],
+                      [1e-30, 3, 0.5, 0.01, -1, 0.02], [0.1, 3e20, 0.5, 0, -1, 0], [0.2, 2, 0.1, ones[3] * 0.1, -0.9, 0.1]],
+                     np.float32)
+    rays = np.concatenate([rays, special, guard])
     got = ctx.debug_intersect(rays)
     osc = pc.oracle_scene(orc, demo, env)
     for i, r in enumerate(rays):
@@ -119,7 +125,7 @@ def _chain_scene(depth):
     return tris, mats, nodes
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])
 @pytest.mark.parametrize("depth", [10, 62, 63, 64, 70])
 def test_stack_overflow_abort_matches_oracle(gpu_ctx, orc, variant, depth):
     tris, mats, nodes = _chain_scene(depth)
@@ -143,6 +149,41 @@ def test_stack_overflow_abort_matches_oracle(gpu_ctx, orc, variant, depth):
     ctx.set_kernel_variant(0)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+def test_stack_overflow_inside_a_frame(gpu_ctx, orc, env, variant):
+    """The 64-entry abort must also come out right inside the full raytrace pass of every
+    kernel variant (the persistent kernels keep the stack pointer across steps)."""
+    tris, mats, nodes = _chain_scene(70)
+    ctx = gpu_ctx
+    ctx.upload_bvh(nodes)
+    ctx.upload_triangles(tris)
+    ctx.upload_materials(mats)
+    ctx.upload_environment(env)
+    ctx.set_kernel_variant(variant)
+    ctx.set_tile(0, 1, 8)
+    w = h = 24
+    ctx.resize(w, h)
+    ctx.reset_counters()
+
+    class Cam:
+        camera = dict(position=(0.0, 0.0, 5.0), fov=30.0, focalDistance=1.0, aperture=0.0)
+
+        @staticmethod
+        def camera_direction():
+            return (0.0, 0.0, -1.0)
+
+    u = pc.rt_uniforms(Cam, w, h, frame=2, bounces=3)
+    pc.gpu_frame(ctx, u)
+    got = ctx.read_texture(capi.TEX_OUTPUT)
+    cnt = ctx.counters()
+    want, ocnt = orc.raytrace(orc.OracleScene(tris, mats, nodes, env), u.tobytes(), w, h)
+    assert ocnt["stack_overflows"] > 0
+    assert pc.same_bits(got, want), pc.describe_diff(got, want)
+    for k in ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels"):
+        assert cnt[k] == ocnt[k], f"counter {k}: gpu {cnt[k]} oracle {ocnt[k]}"
+    ctx.set_kernel_variant(0)
+
+
 # ---------------------------------------------------------------- whole passes
 
 FRAME_CASES = [
@@ -159,7 +200,7 @@ FRAME_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", FRAME_CASES, ids=[f"{c[0]}x{c[1]}-b{c[2]}-s{c[3]}-a{c[4]}" for c in FRAME_CASES])
 def test_raytrace_pass_bit_identical(gpu_ctx, orc, demo, env, case, variant):
     w, h, bounces, spf, aperture, focal, frame, rotation = case
@@ -322,14 +363,14 @@ def test_full_hd_properties(gpu_ctx, orc, demo, env):
     u = pc.rt_uniforms(demo, w, h, frame=2, bounces=8)
     a = pc.acc_uniforms(w, h, 2)
     images = {}
-    for variant in (1, 2):
+    for variant in (1, 2, 3, 4, 5):
         ctx.set_kernel_variant(variant)
         ctx.reset()
         ctx.reset_counters()
         pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
         images[variant] = (ctx.read_texture(capi.TEX_ACCUMULATION), ctx.counters())
-    assert pc.same_bits(images[1][0], images[2][0])
-    assert images[1][1] == images[2][1]
+    assert all(pc.same_bits(images[v][0], images[2][0]) for v in (1, 3, 4, 5))
+    assert all(images[v][1] == images[2][1] for v in (1, 3, 4, 5))
     cnt = images[2][1]
     assert cnt["pixels"] == w * h
     assert cnt["rays"] == cnt["hits"] + cnt["misses"]

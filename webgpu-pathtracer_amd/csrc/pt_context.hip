@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,6 +41,7 @@ struct mi3pt_ctx {
     void *d_packets = nullptr, *d_tripk = nullptr;
     size_t ntris = 0, nnodes = 0, nmats = 0, npackets = 0;
     uint32_t root_ref = 0;
+    uint32_t scene_flags = 0;
     int64_t max_tri_ref = -1;       // largest triangleIndex referenced by a leaf
     int64_t max_mat_ref = -1;       // largest materialIndex referenced by a triangle
 
@@ -48,9 +50,14 @@ struct mi3pt_ctx {
     int rank = 0, nranks = 1, block_rows = 8;                 // active tile
     int next_rank = 0, next_nranks = 1, next_block_rows = 8;  // applied at resize
     float4 *d_radiance = nullptr, *d_accum_own = nullptr, *d_accum = nullptr, *d_canvas = nullptr;
+    float4 *d_radiance_alt = nullptr;    // second frame-radiance image (frame pipelining)
+    float4 *last_radiance = nullptr;     // the radiance image the most recent raytrace pass wrote
     uint32_t *d_canvas8 = nullptr;
     bool output_is_accum = false;
     uint64_t *d_block_counters = nullptr;
+    uint32_t *d_tile_counter = nullptr;
+    uint64_t *d_wave_times = nullptr;     // diagnostic stamps, allocated by mi3pt_debug_wave_times(enable)
+    int wave_times_slots = 0;
     int nblocks = 0;
 
     uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE];
@@ -59,6 +66,18 @@ struct mi3pt_ctx {
 
     int storage = MI3PT_STORAGE_F32;
     int variant = 0;
+    int walk_min = 32;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
+    int waves_per_cu = 10;
+
+    // Frame pipelining: raytrace kernels of consecutive frames run on two alternating
+    // internal streams so that frame f+1 fills the CUs while frame f's last paths drain;
+    // the ordered running mean (accumulate) stays on the main stream.
+    bool pipeline = true;                // MI3PT_PIPELINE=0 turns it off (one fused kernel per frame)
+    hipStream_t rt_stream[2] = { nullptr, nullptr };
+    hipEvent_t rt_done[2] = {}, acc_done[2] = {}, main_mark = nullptr;
+    bool acc_done_valid[2] = { false, false };
+    bool main_dirty = true;              // main-stream work the next raytrace kernel must wait for
+    uint64_t seq = 0;
 
     bool timing = false;
     hipEvent_t ev[3][2] = {};
@@ -118,9 +137,19 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
         return pt_set_error(MI3PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
+    if (const char *e = std::getenv("MI3PT_PIPELINE")) ctx->pipeline = std::atoi(e) != 0;
+    for (int k = 0; k < 2; k++) {
+        (void)hipStreamCreateWithFlags(&ctx->rt_stream[k], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&ctx->rt_done[k], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&ctx->acc_done[k], hipEventDisableTiming);
+    }
+    (void)hipEventCreateWithFlags(&ctx->main_mark, hipEventDisableTiming);
+    if (const char *e = std::getenv("MI3PT_WALK_MIN")) ctx->walk_min = std::atoi(e);
+    if (const char *e = std::getenv("MI3PT_WAVES_PER_CU")) ctx->waves_per_cu = std::atoi(e);
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
-    if (hipMalloc(&ctx->d_env, env_bytes) != hipSuccess || hipMalloc(&ctx->d_cdf, env_bytes) != hipSuccess) {
+    if (hipMalloc(&ctx->d_env, env_bytes) != hipSuccess || hipMalloc(&ctx->d_cdf, env_bytes) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_tile_counter, 256) != hipSuccess) {
         mi3pt_destroy(ctx);
         return pt_set_error(MI3PT_ERR_HIP, "hipMalloc(environment) failed");
     }
@@ -138,6 +167,8 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
 static void free_textures(mi3pt_ctx *ctx)
 {
     if (ctx->d_radiance) (void)hipFree(ctx->d_radiance);
+    if (ctx->d_radiance_alt) (void)hipFree(ctx->d_radiance_alt);
+    ctx->d_radiance_alt = ctx->last_radiance = nullptr;
     if (ctx->d_accum_own) (void)hipFree(ctx->d_accum_own);
     if (ctx->d_canvas) (void)hipFree(ctx->d_canvas);
     if (ctx->d_canvas8) (void)hipFree(ctx->d_canvas8);
@@ -153,12 +184,21 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
     if (!ctx) return MI3PT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < 2; k++)
+        if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     free_textures(ctx);
-    for (void *p : { ctx->d_tris, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk })
+    for (void *p : { ctx->d_tris, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk,
+                     (void *)ctx->d_tile_counter, (void *)ctx->d_wave_times })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
         for (int k = 0; k < 2; k++)
             if (ctx->ev[p][k]) (void)hipEventDestroy(ctx->ev[p][k]);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->rt_stream[k]) (void)hipStreamDestroy(ctx->rt_stream[k]);
+        if (ctx->rt_done[k]) (void)hipEventDestroy(ctx->rt_done[k]);
+        if (ctx->acc_done[k]) (void)hipEventDestroy(ctx->acc_done[k]);
+    }
+    if (ctx->main_mark) (void)hipEventDestroy(ctx->main_mark);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MI3PT_OK;
@@ -169,6 +209,8 @@ extern "C" int mi3pt_set_stream(mi3pt_ctx *ctx, void *hip_stream)
     if (int rc = require_ctx(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->main_dirty = true;
+    ctx->acc_done_valid[0] = ctx->acc_done_valid[1] = false;
     return MI3PT_OK;
 }
 
@@ -184,7 +226,7 @@ extern "C" int mi3pt_set_storage(mi3pt_ctx *ctx, int storage)
 extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
-    if (variant < 0 || variant > 2) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0, 1 or 2");
+    if (variant < 0 || variant > 5) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..5");
     ctx->variant = variant;
     return MI3PT_OK;
 }
@@ -268,8 +310,14 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
     std::vector<uint32_t> packet_of(n, pt::REF_NONE);
     size_t npackets = 0;
     int64_t max_tri = -1;
+    bool coords_safe = true;     // precondition of the exact fast slab test (pt_kernels.hip, RayPre)
     for (size_t i = 0; i < n; i++) {
         const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+        for (size_t off : { (size_t)0, (size_t)4, (size_t)8, (size_t)16, (size_t)20, (size_t)24 }) {
+            const float v = ldf(r, off);
+            const float a = v < 0 ? -v : v;
+            if (!(v == 0.0f || (a >= 8.470329472543003e-22f && a <= 1.152921504606847e18f))) coords_safe = false;
+        }
         if (ldi(r, 28) == 1) {
             const int32_t ti = ldi(r, 40);
             if (ti < 0) return pt_set_error(MI3PT_ERR_INVALID, "leaf node with negative triangleIndex");
@@ -316,6 +364,7 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
     ctx->nnodes = n;
     ctx->npackets = npackets;
     ctx->root_ref = ref_of(0);
+    ctx->scene_flags = coords_safe ? 1u : 0u;
     ctx->max_tri_ref = max_tri;
     return MI3PT_OK;
 }
@@ -359,6 +408,7 @@ static int zero_textures(mi3pt_ctx *ctx)
     const size_t canvas_px = (size_t)ctx->width * ctx->height;
     if (tex_bytes) {
         HIP_TRY(hipMemsetAsync(ctx->d_radiance, 0, tex_bytes, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_radiance_alt, 0, tex_bytes, ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_accum, 0, tex_bytes, ctx->stream));
     }
     if (canvas_px) {
@@ -366,6 +416,8 @@ static int zero_textures(mi3pt_ctx *ctx)
         HIP_TRY(hipMemsetAsync(ctx->d_canvas8, 0, canvas_px * 4, ctx->stream));
     }
     ctx->output_is_accum = false;
+    ctx->last_radiance = ctx->d_radiance;
+    ctx->main_dirty = true;
     return MI3PT_OK;
 }
 
@@ -382,12 +434,14 @@ extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
     const size_t tex_bytes = (size_t)ctx->local_rows * width * 16;
     const size_t canvas_px = (size_t)width * height;
     HIP_TRY(hipMalloc((void **)&ctx->d_radiance, tex_bytes ? tex_bytes : 16));
+    HIP_TRY(hipMalloc((void **)&ctx->d_radiance_alt, tex_bytes ? tex_bytes : 16));
     HIP_TRY(hipMalloc((void **)&ctx->d_accum_own, tex_bytes ? tex_bytes : 16));
     ctx->d_accum = ctx->d_accum_own;
     HIP_TRY(hipMalloc((void **)&ctx->d_canvas, canvas_px * 16));
     HIP_TRY(hipMalloc((void **)&ctx->d_canvas8, canvas_px * 4));
     ctx->nblocks = pt::raytrace_grid_blocks(tile_of(ctx));
-    const size_t cbytes = (size_t)(ctx->nblocks ? ctx->nblocks : 1) * pt::CNT_COUNT * sizeof(uint64_t);
+    // two counter sets: overlapping raytrace kernels of consecutive frames use alternate halves
+    const size_t cbytes = 2 * (size_t)(ctx->nblocks ? ctx->nblocks : 1) * pt::CNT_COUNT * sizeof(uint64_t);
     HIP_TRY(hipMalloc((void **)&ctx->d_block_counters, cbytes));
     HIP_TRY(hipMemsetAsync(ctx->d_block_counters, 0, cbytes, ctx->stream));
     return zero_textures(ctx);
@@ -433,6 +487,7 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.ntris = (uint32_t)ctx->ntris; s.nnodes = (uint32_t)ctx->nnodes; s.nmats = (uint32_t)ctx->nmats;
     s.npackets = (uint32_t)ctx->npackets;
     s.root_ref = ctx->root_ref;
+    s.flags = ctx->scene_flags;
     s.env_w = MI3PT_ENV_WIDTH; s.env_h = MI3PT_ENV_HEIGHT;
     return s;
 }
@@ -449,7 +504,10 @@ static int check_scene(const mi3pt_ctx *ctx)
     return MI3PT_OK;
 }
 
-static int pick_variant(const mi3pt_ctx *ctx) { return ctx->variant == 1 ? 1 : 2; }
+// 0 = auto -> the persistent kernel; the probes only know the two per-ray walks.
+static int pick_variant(const mi3pt_ctx *ctx) { return ctx->variant == 0 ? 4 : ctx->variant; }
+// the walk the probe runs: 1 = uploaded records, 2 = packets, 3 = packets + prepared-reciprocal slab test
+static int pick_walk(const mi3pt_ctx *ctx) { return ctx->variant == 0 ? 3 : (ctx->variant >= 4 ? 3 : (ctx->variant == 3 ? 2 : ctx->variant)); }
 
 static pt::AccUniforms acc_uniforms(const mi3pt_ctx *ctx)
 {
@@ -471,6 +529,7 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
     const pt::AccUniforms acc = acc_uniforms(ctx);
     bool fused = false;
     for (bool &r : ctx->ev_recorded) r = false;
+    const bool f16 = ctx->storage == MI3PT_STORAGE_F16;
 
     if (do_rt) {
         if (int rc = check_scene(ctx)) return rc;
@@ -488,21 +547,63 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
         L.radiance = ctx->d_radiance;
         L.accum = ctx->d_accum;
         L.block_counters = ctx->d_block_counters;
-        L.store_f16 = ctx->storage == MI3PT_STORAGE_F16;
-        // Fuse when the accumulate pass covers exactly the pixels the raytrace pass writes.
-        fused = do_acc && acc.res_w == (uint32_t)L.un.res_x && acc.res_h == (uint32_t)L.un.res_y;
-        if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0][0], ctx->stream));
-        pt::launch_raytrace(L, fused, pick_variant(ctx), ctx->stream);
-        HIP_TRY(hipGetLastError());
-        if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[0][1], ctx->stream)); ctx->ev_recorded[0] = true; }
-        ctx->output_is_accum = fused;
+        L.tile_counter = ctx->d_tile_counter;
+        L.wave_times = ctx->d_wave_times;
+        L.store_f16 = f16;
+        L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
+        L.waves_per_cu = ctx->waves_per_cu;
+        const bool same_region = acc.res_w == (uint32_t)L.un.res_x && acc.res_h == (uint32_t)L.un.res_y;
+        const int variant = pick_variant(ctx);
+        if (do_acc && same_region && ctx->pipeline && variant >= 3) {
+            // Pipelined frame: raytrace on a side stream into this parity's radiance image,
+            // ordered accumulate on the main stream.
+            const int par = (int)(ctx->seq++ & 1u);
+            hipStream_t rs = ctx->rt_stream[par];
+            if (ctx->main_dirty) {      // resets / rebinds queued on the main stream come first
+                HIP_TRY(hipEventRecord(ctx->main_mark, ctx->stream));
+                HIP_TRY(hipStreamWaitEvent(ctx->rt_stream[0], ctx->main_mark, 0));
+                HIP_TRY(hipStreamWaitEvent(ctx->rt_stream[1], ctx->main_mark, 0));
+                ctx->main_dirty = false;
+            }
+            // accumulate(f-2) must have consumed this radiance image
+            if (ctx->acc_done_valid[par]) HIP_TRY(hipStreamWaitEvent(rs, ctx->acc_done[par], 0));
+            L.radiance = par ? ctx->d_radiance_alt : ctx->d_radiance;
+            L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
+            L.tile_counter = ctx->d_tile_counter + par * 32;
+            if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0][0], rs));
+            pt::launch_raytrace(L, false, variant, rs);
+            HIP_TRY(hipGetLastError());
+            if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[0][1], rs)); ctx->ev_recorded[0] = true; }
+            HIP_TRY(hipEventRecord(ctx->rt_done[par], rs));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->rt_done[par], 0));
+            if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1][0], ctx->stream));
+            pt::launch_accumulate(acc, tile, L.radiance, ctx->d_accum, f16, ctx->stream);
+            HIP_TRY(hipGetLastError());
+            if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[1][1], ctx->stream)); ctx->ev_recorded[1] = true; }
+            HIP_TRY(hipEventRecord(ctx->acc_done[par], ctx->stream));
+            ctx->acc_done_valid[par] = true;
+            ctx->last_radiance = L.radiance;
+            ctx->output_is_accum = true;
+            fused = true;               // the accumulate pass has been taken care of
+        } else {
+            // Fuse when the accumulate pass covers exactly the pixels the raytrace pass writes.
+            fused = do_acc && same_region;
+            if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0][0], ctx->stream));
+            pt::launch_raytrace(L, fused, variant, ctx->stream);
+            HIP_TRY(hipGetLastError());
+            if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[0][1], ctx->stream)); ctx->ev_recorded[0] = true; }
+            ctx->last_radiance = ctx->d_radiance;
+            ctx->output_is_accum = fused;
+            ctx->main_dirty = true;     // a later pipelined frame must not overtake this kernel
+        }
     }
     if (do_acc && !fused) {
         if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1][0], ctx->stream));
-        pt::launch_accumulate(acc, tile, ctx->d_radiance, ctx->d_accum, ctx->storage == MI3PT_STORAGE_F16, ctx->stream);
+        pt::launch_accumulate(acc, tile, ctx->last_radiance, ctx->d_accum, f16, ctx->stream);
         HIP_TRY(hipGetLastError());
         if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[1][1], ctx->stream)); ctx->ev_recorded[1] = true; }
         ctx->output_is_accum = true;   // accumulate.ts:171-175 copies the mean into outputTexture
+        ctx->main_dirty = true;
     }
     if (do_fs) {
         if (ctx->nranks != 1)
@@ -511,7 +612,7 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
         pt::FsUniforms fs;
         fs.res_x = ldf(ctx->u_fs, 0); fs.res_y = ldf(ctx->u_fs, 4); fs.aspect = ldf(ctx->u_fs, 8);
         fs.scaling = ldf(ctx->u_fs, 12); fs.denoise = ldu(ctx->u_fs, 16); fs.tonemapping = ldu(ctx->u_fs, 20);
-        const float4 *tex = ctx->output_is_accum ? ctx->d_accum : ctx->d_radiance;
+        const float4 *tex = ctx->output_is_accum ? ctx->d_accum : ctx->last_radiance;
         if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2][0], ctx->stream));
         pt::launch_fullscreen(fs, tex, ctx->width, ctx->height, ctx->width, ctx->height, ctx->d_canvas,
                               ctx->d_canvas8, ctx->stream);
@@ -537,7 +638,7 @@ extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t 
     size_t need;
     switch (which) {
     case MI3PT_TEX_OUTPUT:
-        src = ctx->output_is_accum ? ctx->d_accum : ctx->d_radiance;
+        src = ctx->output_is_accum ? ctx->d_accum : ctx->last_radiance;
         need = (size_t)ctx->local_rows * ctx->width * 4;
         break;
     case MI3PT_TEX_ACCUMULATION:
@@ -584,6 +685,7 @@ extern "C" int mi3pt_bind_accumulation(mi3pt_ctx *ctx, void *dev_ptr, size_t nby
     if (int rc = require_ctx(ctx)) return rc;
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "bind before resize");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->main_dirty = true;
     if (!dev_ptr) {
         ctx->d_accum = ctx->d_accum_own;
         return MI3PT_OK;
@@ -621,10 +723,10 @@ extern "C" int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT])
     if (!out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     for (int k = 0; k < MI3PT_CNT_COUNT; k++) out[k] = 0;
     if (ctx->nblocks == 0) return MI3PT_OK;
-    std::vector<uint64_t> host((size_t)ctx->nblocks * pt::CNT_COUNT);
+    std::vector<uint64_t> host(2 * (size_t)ctx->nblocks * pt::CNT_COUNT);
     HIP_TRY(hipMemcpyAsync(host.data(), ctx->d_block_counters, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int b = 0; b < ctx->nblocks; b++)
+    for (int b = 0; b < 2 * ctx->nblocks; b++)
         for (int k = 0; k < MI3PT_CNT_COUNT; k++) out[k] += host[(size_t)b * pt::CNT_COUNT + k];
     return MI3PT_OK;
 }
@@ -633,7 +735,36 @@ extern "C" int mi3pt_reset_counters(mi3pt_ctx *ctx)
 {
     if (int rc = require_ctx(ctx)) return rc;
     if (ctx->nblocks == 0) return MI3PT_OK;
-    HIP_TRY(hipMemsetAsync(ctx->d_block_counters, 0, (size_t)ctx->nblocks * pt::CNT_COUNT * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_block_counters, 0, 2 * (size_t)ctx->nblocks * pt::CNT_COUNT * 8, ctx->stream));
+    ctx->main_dirty = true;
+    return MI3PT_OK;
+}
+
+// Diagnostic: per-wave begin / feed-empty / end stamps of the last persistent raytrace
+// launch.  out == NULL enables (allocates) or, with capacity 0 and enable 0, disables it.
+extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out, size_t capacity_slots,
+                                      size_t *slots_out)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    const int slots = 256 * 10;
+    if (!out) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (enable && !ctx->d_wave_times) {
+            HIP_TRY(hipMalloc((void **)&ctx->d_wave_times, (size_t)slots * 32));
+            HIP_TRY(hipMemset(ctx->d_wave_times, 0, (size_t)slots * 32));
+            ctx->wave_times_slots = slots;
+        } else if (!enable && ctx->d_wave_times) {
+            (void)hipFree(ctx->d_wave_times);
+            ctx->d_wave_times = nullptr;
+            ctx->wave_times_slots = 0;
+        }
+        return MI3PT_OK;
+    }
+    if (!ctx->d_wave_times) return pt_set_error(MI3PT_ERR_STATE, "wave times are not enabled");
+    if (capacity_slots < (size_t)ctx->wave_times_slots) return pt_set_error(MI3PT_ERR_INVALID, "buffer too small");
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_wave_times, (size_t)ctx->wave_times_slots * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (slots_out) *slots_out = (size_t)ctx->wave_times_slots;
     return MI3PT_OK;
 }
 
@@ -651,7 +782,7 @@ extern "C" int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n
     }
     hipError_t e = hipMemcpyAsync(d_rays, rays, n * 24, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        pt::launch_debug_intersect(scene_refs(ctx), d_rays, n, d_out, pick_variant(ctx), ctx->stream);
+        pt::launch_debug_intersect(scene_refs(ctx), d_rays, n, d_out, pick_walk(ctx), ctx->stream);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * 48, hipMemcpyDeviceToHost, ctx->stream);

@@ -43,6 +43,7 @@ struct SceneRefs {
     const float4 *tripk;    // TriPacket array, or null
     uint32_t ntris, nnodes, nmats, npackets;
     uint32_t root_ref;      // reference of node 0 in packet terms
+    uint32_t flags;         // bit0: every box coordinate is 0 or within [2^-70, 2^60] (fast slab test allowed)
     int32_t env_w, env_h;
 };
 
@@ -81,7 +82,11 @@ struct RtLaunch {
     float4 *radiance;            // per-frame output (unfused) -- may be null when fused
     float4 *accum;               // running mean
     uint64_t *block_counters;    // [gridDim.x][CNT_COUNT]
+    uint32_t *tile_counter;      // work queue head of the persistent kernel (zeroed per launch)
+    uint64_t *wave_times;        // diagnostic: [grid][4] begin / feed-empty / end (100 MHz) + shader cycles, or null
     int32_t store_f16;
+    int32_t walk_min;            // state-machine kernel: walk while at least this many lanes are walking
+    int32_t waves_per_cu;        // persistent kernels: resident one-wave workgroups per CU
 };
 
 void launch_raytrace(const RtLaunch &L, bool fuse_accumulate, int variant, hipStream_t s);
@@ -93,5 +98,6 @@ void launch_debug_intersect(const SceneRefs &scene, const float *rays, size_t n,
                             hipStream_t s);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s);
 int raytrace_grid_blocks(const Tile &tile);
+int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu);
 
 }  // namespace pt

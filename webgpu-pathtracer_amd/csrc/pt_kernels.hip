@@ -100,6 +100,88 @@ PT_DEV bool ray_aabb(const f3 &o, const f3 &d, float mnx, float mny, float mnz,
     return ok && (tmax >= fmaxf(0.0f, tmin));
 }
 
+// ---------------------------------------------------------------------------------
+// The same slab test with the twelve IEEE divisions of a node's two boxes replaced by
+// a per-ray reciprocal.  All six quotients of a box share the ray's three divisors, so
+// y = RN(1/d) is formed once per path segment (one true division per axis) and each
+// quotient is recovered EXACTLY as RN(n/d) by two Newton corrections with exact fma
+// residuals (Markstein's theorem: with y the correctly rounded reciprocal and q1 a
+// faithful quotient, RN(q1 + (n - d*q1)*y) is the correctly rounded n/d, provided the
+// significand of d is not all ones and nothing under/overflows):
+//     q0 = n*y;  q1 = fma(fma(-d, q0, n), y, q0);  q2 = fma(fma(-d, q1, n), y, q1)
+// 5 VALU ops instead of the 11 of the hardware division expansion.  The conditions
+// are checked per ray (RayPre::slow) and per scene (SceneRefs::flags); a ray that
+// fails them takes ray_aabb() above.  tests/test_gpu_parity.py holds this kernel
+// bit-identical to the plain-division kernels; oracle-side evidence for the identity
+// is tests/test_exact_division.py (CPU, brute force).
+// ---------------------------------------------------------------------------------
+struct RayPre {
+    float ix, iy, iz;        // RN(1/d) per axis (0 where the axis is parallel)
+    uint32_t flags;          // bit0..2: axis parallel (|d| < EPSILON); bit3: slow path
+};
+
+PT_DEV float div_pre(float n, float d, float y)
+{
+    const float q0 = n * y;
+    const float q1 = fmaf(fmaf(-d, q0, n), y, q0);
+    return fmaf(fmaf(-d, q1, n), y, q1);
+}
+
+PT_DEV bool safe_magnitude(float v)
+{
+    const float a = fabsf(v);
+    return v == 0.0f || (a >= 8.470329472543003e-22f && a <= 1.152921504606847e18f);   // [2^-70, 2^60]
+}
+
+PT_DEV RayPre ray_prepare(const f3 &o, const f3 &d, uint32_t scene_flags)
+{
+    RayPre p;
+    const bool px = fabsf(d.x) < PT_EPSILON, py = fabsf(d.y) < PT_EPSILON, pz = fabsf(d.z) < PT_EPSILON;
+    p.ix = px ? 0.0f : 1.0f / d.x;
+    p.iy = py ? 0.0f : 1.0f / d.y;
+    p.iz = pz ? 0.0f : 1.0f / d.z;
+    // Markstein's exception (significand all ones; a 4-bit margin is kept) and range guards
+    const bool bad_x = !px && ((__float_as_uint(d.x) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.x) > 1048576.0f);
+    const bool bad_y = !py && ((__float_as_uint(d.y) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.y) > 1048576.0f);
+    const bool bad_z = !pz && ((__float_as_uint(d.z) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.z) > 1048576.0f);
+    const bool slow = bad_x || bad_y || bad_z || !(scene_flags & 1u) || !safe_magnitude(o.x) ||
+                      !safe_magnitude(o.y) || !safe_magnitude(o.z) || !(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z);
+    p.flags = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u) | (slow ? 8u : 0u);
+    return p;
+}
+
+PT_DEV bool ray_aabb_pre(const f3 &o, const f3 &d, const RayPre &p, float mnx, float mny, float mnz,
+                         float mxx, float mxy, float mxz)
+{
+    if (p.flags & 8u) return ray_aabb(o, d, mnx, mny, mnz, mxx, mxy, mxz);
+    bool ok = true;
+    float tnx, tfx, tny, tfy, tnz, tfz;
+    {
+        const float t1 = div_pre(mnx - o.x, d.x, p.ix), t2 = div_pre(mxx - o.x, d.x, p.ix);
+        const bool par = (p.flags & 1u) != 0u;
+        tnx = par ? -PT_INF : fminf(t1, t2);
+        tfx = par ? PT_INF : fmaxf(t1, t2);
+        ok = ok && !(par && (o.x < mnx || o.x > mxx));
+    }
+    {
+        const float t1 = div_pre(mny - o.y, d.y, p.iy), t2 = div_pre(mxy - o.y, d.y, p.iy);
+        const bool par = (p.flags & 2u) != 0u;
+        tny = par ? -PT_INF : fminf(t1, t2);
+        tfy = par ? PT_INF : fmaxf(t1, t2);
+        ok = ok && !(par && (o.y < mny || o.y > mxy));
+    }
+    {
+        const float t1 = div_pre(mnz - o.z, d.z, p.iz), t2 = div_pre(mxz - o.z, d.z, p.iz);
+        const bool par = (p.flags & 4u) != 0u;
+        tnz = par ? -PT_INF : fminf(t1, t2);
+        tfz = par ? PT_INF : fmaxf(t1, t2);
+        ok = ok && !(par && (o.z < mnz || o.z > mxz));
+    }
+    const float tmin = fmaxf(fmaxf(fmaxf(-PT_INF, tnx), tny), tnz);
+    const float tmax = fminf(fminf(fminf(PT_INF, tfx), tfy), tfz);
+    return ok && !(tmin > tmax) && (tmax >= fmaxf(0.0f, tmin));
+}
+
 // raytrace.wgsl:78-116 -- Moller-Trumbore, two-sided.  Returns hit and (t, u, v);
 // position and normal are formed once, for the closest hit, by finish_hit().
 PT_DEV bool ray_triangle(const f3 &o, const f3 &d, const f3 &a, const f3 &b, const f3 &c,
@@ -223,11 +305,60 @@ PT_DEV void traverse_packets(const SceneRefs &sc, const f3 &o, const f3 &d,
     }
 }
 
+// The packet walk with the prepared-reciprocal slab test (what the state-machine kernel
+// executes per lane), as one call: used by the probe kernel.
+PT_DEV void traverse_packets_pre(const SceneRefs &sc, const f3 &o, const f3 &d,
+                                 uint32_t *stack, Best &best, Counters &cnt)
+{
+    best.t = PT_INF; best.u = 0.0f; best.v = 0.0f; best.tri = -1;
+    cnt.rays++;
+    if (sc.nnodes == 0) return;
+    const RayPre pre = ray_prepare(o, d, sc.flags);
+    {
+        const float4 n0 = sc.nodes[0], n1 = sc.nodes[1];
+        cnt.box++;
+        if (!ray_aabb_pre(o, d, pre, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z)) return;
+    }
+    int sp = 1;
+    stack[0] = sc.root_ref;
+    while (sp > 0) {
+        if (sp >= PT_MAX_STACK) { cnt.overflow++; return; }
+        sp--;
+        const uint32_t ref = stack[sp * 64];
+        if (ref & PT_REF_LEAF) {
+            const uint32_t ti = ref & 0x7fffffffu;
+            const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
+            const float4 pb = sc.tripk[(size_t)ti * 3 + 1];
+            const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
+            cnt.tri++;
+            float t, u, v;
+            if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
+                best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti;
+            }
+        } else {
+            const float4 p0 = sc.packets[(size_t)ref * 4 + 0];
+            const float4 p1 = sc.packets[(size_t)ref * 4 + 1];
+            const float4 p2 = sc.packets[(size_t)ref * 4 + 2];
+            const float4 p3 = sc.packets[(size_t)ref * 4 + 3];
+            const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
+            if (lref != PT_REF_NONE) {
+                cnt.box++;
+                if (ray_aabb_pre(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y)) { stack[sp * 64] = lref; sp++; }
+            }
+            if (rref != PT_REF_NONE) {
+                cnt.box++;
+                if (ray_aabb_pre(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w)) { stack[sp * 64] = rref; sp++; }
+            }
+        }
+    }
+}
+
 template <int VARIANT>
 PT_DEV void traverse(const SceneRefs &sc, const f3 &o, const f3 &d, uint32_t *stack, Best &best,
                      Counters &cnt)
 {
-    if (VARIANT == 2) traverse_packets(sc, o, d, stack, best, cnt);
+    if (VARIANT == 3) traverse_packets_pre(sc, o, d, stack, best, cnt);
+    else if (VARIANT == 2) traverse_packets(sc, o, d, stack, best, cnt);
     else traverse_generic(sc, o, d, stack, best, cnt);
 }
 
@@ -485,6 +616,462 @@ __global__ void __launch_bounds__(64) k_raytrace(const RtLaunch L)
     }
 }
 
+// ---------------------------------------------------------------------------------
+// VARIANT 3: persistent waves with lane refill.
+//
+// The per-pixel kernels above lose most of their lanes to path-length divergence: a
+// wave runs until its longest path ends (up to maxBounces segments) while the average
+// path is ~2 segments long.  Here a wave is a pool of 64 path slots.  Every iteration
+// (1) dead slots are refilled with new (pixel, frame) jobs -- __ballot gives the dead
+// mask, mbcnt ranks the dead lanes, and the ranks index consecutive pixels of the
+// wave's current 8x8 tile; tiles come from one global counter, fetched one ahead --
+// (2) all live lanes trace one path segment, (3) hits scatter, misses and exhausted
+// paths finish and write their pixel.  Legal because every job reseeds from its own
+// pixel index and frame (raytrace.wgsl:435-436): any job -> lane assignment gives the
+// same pixels, bit for bit.
+// ---------------------------------------------------------------------------------
+PT_DEV int lane_rank(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool FUSE>
+PT_DEV void write_pixel(const RtLaunch &L, uint32_t gx, uint32_t gy, uint32_t ly, f3 color)
+{
+    const size_t idx = (size_t)ly * L.tile.tex_w + gx;
+    color.x = store_round(color.x, L.store_f16);
+    color.y = store_round(color.y, L.store_f16);
+    color.z = store_round(color.z, L.store_f16);
+    if (FUSE) {
+        if (gx < L.acc.res_w && gy < L.acc.res_h) {
+            const float4 prev = L.accum[idx];
+            const f3 nc = accumulate_texel(L.acc, color, xyz(prev));
+            L.accum[idx] = make_float4(store_round(nc.x, L.store_f16), store_round(nc.y, L.store_f16),
+                                       store_round(nc.z, L.store_f16), 1.0f);
+        }
+    } else {
+        L.radiance[idx] = make_float4(color.x, color.y, color.z, 1.0f);
+    }
+}
+
+struct PathSlot {
+    f3 o, d, ray_color, light, incoming;
+    uint32_t gx, gy, ly, seed;
+    int32_t bounce, sample;
+    bool alive;
+};
+
+template <bool FUSE>
+__global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
+{
+    __shared__ uint32_t stack_lds[PT_MAX_STACK * 64];
+    const int lane = threadIdx.x;
+    uint32_t *stack = stack_lds + lane;
+    const SceneRefs &sc = L.scene;
+    const RtUniforms &un = L.un;
+    const int tiles_x = (L.tile.tex_w + 7) >> 3;
+    const int ntiles = tiles_x * ((L.tile.local_rows + 7) >> 3);
+    const uint32_t res_w = (uint32_t)un.res_x, res_h = (uint32_t)un.res_y;
+
+    const CameraFrame cf = camera_frame(un);
+    const f3 cam_pos = F3(un.cam_pos[0], un.cam_pos[1], un.cam_pos[2]);
+    float sinr, cosr;
+    ptm::sincos(un.env_rotation, sinr, cosr);
+
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0 };
+    PathSlot p;
+    p.alive = false;
+    p.gx = p.gy = p.ly = p.seed = 0u;
+    p.bounce = p.sample = 0;
+    p.o = p.d = p.ray_color = p.light = p.incoming = F3(0.0f, 0.0f, 0.0f);
+
+    // Starts the slot's next camera path, or finishes the pixel when all samples are done
+    // (raytrace.wgsl:441-455).  A zero-length path (maxBounces <= 0) contributes nothing.
+    auto next_path = [&]() {
+        for (;;) {
+            if (p.sample >= un.samples_per_frame) {
+                const float n = (float)un.samples_per_frame;
+                write_pixel<FUSE>(L, p.gx, p.gy, p.ly, F3(p.incoming.x / n, p.incoming.y / n, p.incoming.z / n));
+                p.alive = false;
+                return;
+            }
+            const float uvx = (float)p.gx / un.res_x, uvy = (float)p.gy / un.res_y;
+            const f3 dir0 = camera_direction(cf, un.aspect, uvx, uvy);
+            float jx, jy, kx, ky;
+            rand_point_in_circle(p.seed, jx, jy);
+            const f3 jitter = F3(jx * (1.0f / un.res_x), jy * (1.0f / un.res_y), 0.0f);
+            rand_point_in_circle(p.seed, kx, ky);
+            const f3 jitter2 = F3(kx * un.aperture, ky * un.aperture, 0.0f);
+            const f3 focal = (cam_pos + dir0 * un.focal_distance) + jitter;
+            p.o = cam_pos + jitter2;
+            p.d = normalize(focal - p.o);
+            p.bounce = 0;
+            p.light = F3(0.0f, 0.0f, 0.0f);
+            p.ray_color = F3(1.0f, 1.0f, 1.0f);
+            if (un.max_bounces > 0) {
+                p.alive = true;
+                return;
+            }
+            p.incoming = p.incoming + p.light;
+            p.sample++;
+        }
+    };
+
+    auto fetch_tile = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = (int)atomicAdd(L.tile_counter, 1u);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+
+    int cur_tile = 0, cur_used = 64;
+    int next_tile = fetch_tile();
+    bool feed_empty = false;
+
+    for (;;) {
+        // ---- (1) refill dead slots from the wave's tile
+        unsigned long long dead = __ballot(!p.alive);
+        while (dead != 0ull && !feed_empty) {
+            if (cur_used >= 64) {
+                cur_tile = next_tile;
+                if (cur_tile >= ntiles) { feed_empty = true; break; }
+                next_tile = fetch_tile();
+                cur_used = 0;
+            }
+            const int take = min((int)__popcll(dead), 64 - cur_used);
+            const int rank = lane_rank(dead);
+            if (!p.alive && rank < take) {
+                const int j = cur_used + rank;
+                const int px = (cur_tile % tiles_x) * 8 + (j & 7);
+                const int ply = (cur_tile / tiles_x) * 8 + (j >> 3);
+                const int pgy = local_to_global_row(ply, L.tile);
+                // raytrace.wgsl:425-427
+                const bool ok = px < L.tile.tex_w && ply < L.tile.local_rows && pgy < L.tile.tex_h &&
+                                (uint32_t)px < res_w && (uint32_t)pgy < res_h;
+                if (ok) {
+                    p.gx = (uint32_t)px; p.gy = (uint32_t)pgy; p.ly = (uint32_t)ply;
+                    cnt.pixels++;
+                    p.seed = (p.gx + p.gy * res_w) + un.frame * 719393u + PT_SEED;
+                    p.sample = 0;
+                    p.incoming = F3(0.0f, 0.0f, 0.0f);
+                    next_path();
+                }
+            }
+            cur_used += take;
+            dead = __ballot(!p.alive);
+        }
+        if (__ballot(p.alive) == 0ull) break;
+
+        // ---- (2) one path segment for every live slot, (3) shade
+        if (p.alive) {
+            Best best;
+            traverse_packets(sc, p.o, p.d, stack, best, cnt);
+            bool ended;
+            if (best.tri >= 0) {
+                cnt.hit++;
+                f3 position, normal;
+                int32_t mi;
+                finish_hit(sc, p.o, p.d, best, position, normal, mi);
+                const float4 m0 = sc.mats[(size_t)mi * 4 + 0];
+                const float4 m1 = sc.mats[(size_t)mi * 4 + 1];
+                const float4 m2 = sc.mats[(size_t)mi * 4 + 2];
+                const float4 m3 = sc.mats[(size_t)mi * 4 + 3];
+                const f3 diffuse_dir = normalize(normal + rand_direction(p.seed));
+                const f3 specular_dir = reflect(p.d, normal);
+                float is_specular = 0.0f;
+                if (m2.x >= rand1(p.seed)) is_specular = 1.0f;
+                p.o = position;
+                p.d = mix(diffuse_dir, specular_dir, is_specular * (1.0f - m1.w));
+                const f3 emitted = xyz(m3) * m3.w;
+                p.light = p.light + emitted * p.ray_color;
+                p.ray_color = p.ray_color * mix(xyz(m0), xyz(m1), is_specular);
+                p.bounce++;
+                ended = p.bounce >= un.max_bounces;
+            } else {
+                cnt.miss++;
+                float u, v;
+                env_uv_from_dir(p.d, sinr, cosr, u, v);
+                const f3 env = sample_env(sc.env, sc.env_w, sc.env_h, u, v);
+                p.light = p.light + (p.ray_color * env) * un.env_intensity;
+                ended = true;
+            }
+            if (ended) {
+                p.incoming = p.incoming + p.light;
+                p.sample++;
+                next_path();
+            }
+        }
+    }
+
+    const uint32_t s_rays = wave_sum(cnt.rays), s_box = wave_sum(cnt.box), s_tri = wave_sum(cnt.tri);
+    const uint32_t s_hit = wave_sum(cnt.hit), s_miss = wave_sum(cnt.miss);
+    const uint32_t s_ovf = wave_sum(cnt.overflow), s_pix = wave_sum(cnt.pixels);
+    if (lane == 0 && L.block_counters) {
+        uint64_t *c = L.block_counters + (size_t)blockIdx.x * CNT_COUNT;
+        c[CNT_RAYS] += s_rays; c[CNT_BOX] += s_box; c[CNT_TRI] += s_tri; c[CNT_HIT] += s_hit;
+        c[CNT_MISS] += s_miss; c[CNT_OVERFLOW] += s_ovf; c[CNT_PIXELS] += s_pix;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// VARIANT 4: persistent waves, per-lane state machine.
+//
+// Variant 3 still runs every segment's walk to the longest lane's length.  Here each
+// lane is in one of three modes and the wave alternates between two kinds of step:
+//   TRAVERSE  the lane is inside rayBVHIntersect: stack pointer, best hit and stack
+//             (LDS) persist across steps; a "walk step" pops ONE stack entry per lane.
+//   SHADE     the walk is over (stack empty, root missed or 64-entry abort): the lane
+//             waits for the next "service step", which shades hits / looks up the
+//             environment, finishes pixels, refills dead lanes with new jobs and starts
+//             the next segments (root box test included).
+//   DEAD      no job.
+// Walk steps run while at least walk_min lanes are walking (or nothing else can make
+// progress); otherwise a service step runs with every waiting lane at once.  Each lane
+// still executes exactly the reference's sequence of tests for its own ray, so results
+// and counters are unchanged.
+// ---------------------------------------------------------------------------------
+enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
+
+template <bool FUSE>
+__global__ void __launch_bounds__(64) k_raytrace_sm(const RtLaunch L)
+{
+    __shared__ uint32_t stack_lds[PT_MAX_STACK * 64];
+    const int lane = threadIdx.x;
+    uint32_t *stack = stack_lds + lane;
+    const SceneRefs &sc = L.scene;
+    const RtUniforms &un = L.un;
+    const int tiles_x = (L.tile.tex_w + 7) >> 3;
+    const int ntiles = tiles_x * ((L.tile.local_rows + 7) >> 3);
+    const uint32_t res_w = (uint32_t)un.res_x, res_h = (uint32_t)un.res_y;
+
+    const CameraFrame cf = camera_frame(un);
+    const f3 cam_pos = F3(un.cam_pos[0], un.cam_pos[1], un.cam_pos[2]);
+    float sinr, cosr;
+    ptm::sincos(un.env_rotation, sinr, cosr);
+    float4 root0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), root1 = root0;
+    if (sc.nnodes != 0) { root0 = sc.nodes[0]; root1 = sc.nodes[1]; }
+
+    // diagnostic stamps (only when a buffer is bound): wall clock (100 MHz) and shader clock
+    const uint64_t t_begin_rt = L.wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const uint64_t t_begin_clk = L.wave_times ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint64_t t_empty_rt = 0ull;
+
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0 };
+    int mode = M_DEAD;
+    f3 o = F3(0.0f, 0.0f, 0.0f), d = o, ray_color = o, light = o, incoming = o;
+    uint32_t gx = 0u, gy = 0u, ly = 0u, seed = 0u;
+    int32_t bounce = 0, sample = 0;
+    int sp = 0;
+    Best best;
+    best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
+    RayPre pre;
+    pre.ix = pre.iy = pre.iz = 0.0f;
+    pre.flags = 8u;
+
+    auto fetch_tile = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = (int)atomicAdd(L.tile_counter, 1u);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+    int cur_tile = 0, cur_used = 64;
+    int next_tile = fetch_tile();
+    bool feed_empty = false;
+
+    for (;;) {
+        const unsigned long long walking = __ballot(mode == M_TRAV);
+        const bool serviceable = __ballot(mode == M_SHADE) != 0ull ||
+                                 (!feed_empty && __ballot(mode == M_DEAD) != 0ull);
+        const int nwalk = (int)__popcll(walking);
+        if (nwalk > 0 && (nwalk >= L.walk_min || !serviceable)) {
+            // ---- walk step: one pop per walking lane (raytrace.wgsl:166-200)
+            if (mode == M_TRAV) {
+                sp--;
+                const uint32_t ref = stack[sp * 64];
+                if (ref & PT_REF_LEAF) {
+                    const uint32_t ti = ref & 0x7fffffffu;
+                    const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
+                    const float4 pb = sc.tripk[(size_t)ti * 3 + 1];
+                    const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
+                    cnt.tri++;
+                    float t, u, v;
+                    if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
+                        best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti;
+                    }
+                } else {
+                    const float4 p0 = sc.packets[(size_t)ref * 4 + 0];
+                    const float4 p1 = sc.packets[(size_t)ref * 4 + 1];
+                    const float4 p2 = sc.packets[(size_t)ref * 4 + 2];
+                    const float4 p3 = sc.packets[(size_t)ref * 4 + 3];
+                    const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
+                    if (lref != PT_REF_NONE) {
+                        cnt.box++;
+                        if (ray_aabb_pre(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y)) { stack[sp * 64] = lref; sp++; }
+                    }
+                    if (rref != PT_REF_NONE) {
+                        cnt.box++;
+                        if (ray_aabb_pre(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w)) { stack[sp * 64] = rref; sp++; }
+                    }
+                }
+                if (sp >= PT_MAX_STACK) { cnt.overflow++; mode = M_SHADE; }     // :167-171
+                else if (sp == 0) mode = M_SHADE;
+            }
+            continue;
+        }
+        if (!serviceable) break;      // nobody walking, nothing waiting, no jobs left
+
+        // ---- service step
+        bool need_path = false;       // start the slot's next camera path (or finish the pixel)
+        bool need_segment = false;    // start rayBVHIntersect for (o, d)
+        if (mode == M_SHADE) {
+            bool ended;
+            if (best.tri >= 0) {      // trace(), raytrace.wgsl:380-395
+                cnt.hit++;
+                f3 position, normal;
+                int32_t mi;
+                finish_hit(sc, o, d, best, position, normal, mi);
+                const float4 m0 = sc.mats[(size_t)mi * 4 + 0];
+                const float4 m1 = sc.mats[(size_t)mi * 4 + 1];
+                const float4 m2 = sc.mats[(size_t)mi * 4 + 2];
+                const float4 m3 = sc.mats[(size_t)mi * 4 + 3];
+                const f3 diffuse_dir = normalize(normal + rand_direction(seed));
+                const f3 specular_dir = reflect(d, normal);
+                float is_specular = 0.0f;
+                if (m2.x >= rand1(seed)) is_specular = 1.0f;
+                o = position;
+                d = mix(diffuse_dir, specular_dir, is_specular * (1.0f - m1.w));
+                const f3 emitted = xyz(m3) * m3.w;
+                light = light + emitted * ray_color;
+                ray_color = ray_color * mix(xyz(m0), xyz(m1), is_specular);
+                bounce++;
+                ended = bounce >= un.max_bounces;
+            } else {                  // :396-407
+                cnt.miss++;
+                float u, v;
+                env_uv_from_dir(d, sinr, cosr, u, v);
+                const f3 env = sample_env(sc.env, sc.env_w, sc.env_h, u, v);
+                light = light + (ray_color * env) * un.env_intensity;
+                ended = true;
+            }
+            mode = M_DEAD;            // until a path / segment is started below
+            if (ended) {
+                incoming = incoming + light;
+                sample++;
+                if (sample >= un.samples_per_frame) {
+                    // pixel finished (:455, :477): the slot is free for the refill below
+                    const float n = (float)un.samples_per_frame;
+                    write_pixel<FUSE>(L, gx, gy, ly, F3(incoming.x / n, incoming.y / n, incoming.z / n));
+                } else {
+                    need_path = true;
+                }
+            } else {
+                need_segment = true;
+            }
+        }
+        // refill: dead lanes that are not about to continue their own pixel take new jobs
+        {
+            unsigned long long dead = __ballot(mode == M_DEAD && !need_path && !need_segment);
+            while (dead != 0ull && !feed_empty) {
+                if (cur_used >= 64) {
+                    cur_tile = next_tile;
+                    if (cur_tile >= ntiles) {
+                        feed_empty = true;
+                        if (L.wave_times) t_empty_rt = __builtin_amdgcn_s_memrealtime();
+                        break;
+                    }
+                    next_tile = fetch_tile();
+                    cur_used = 0;
+                }
+                const int take = min((int)__popcll(dead), 64 - cur_used);
+                const int rank = lane_rank(dead);
+                const bool mine = ((dead >> lane) & 1ull) != 0ull && rank < take;
+                if (mine) {
+                    const int j = cur_used + rank;
+                    const int px = (cur_tile % tiles_x) * 8 + (j & 7);
+                    const int ply = (cur_tile / tiles_x) * 8 + (j >> 3);
+                    const int pgy = local_to_global_row(ply, L.tile);
+                    const bool ok = px < L.tile.tex_w && ply < L.tile.local_rows && pgy < L.tile.tex_h &&
+                                    (uint32_t)px < res_w && (uint32_t)pgy < res_h;     // :425-427
+                    if (ok) {
+                        gx = (uint32_t)px; gy = (uint32_t)pgy; ly = (uint32_t)ply;
+                        cnt.pixels++;
+                        seed = (gx + gy * res_w) + un.frame * 719393u + PT_SEED;    // :435-436
+                        sample = 0;
+                        incoming = F3(0.0f, 0.0f, 0.0f);
+                        need_path = true;
+                    }
+                }
+                cur_used += take;
+                // lanes that took a job (valid or not) leave the dead set; invalid ones rejoin next round
+                dead = __ballot(mode == M_DEAD && !need_path && !need_segment && !mine);
+            }
+        }
+        if (need_path) {
+            // raytrace.wgsl:441-455: next sample's camera path, or the pixel is finished
+            for (;;) {
+                if (sample >= un.samples_per_frame) {
+                    const float n = (float)un.samples_per_frame;
+                    write_pixel<FUSE>(L, gx, gy, ly, F3(incoming.x / n, incoming.y / n, incoming.z / n));
+                    break;
+                }
+                const float uvx = (float)gx / un.res_x, uvy = (float)gy / un.res_y;
+                const f3 dir0 = camera_direction(cf, un.aspect, uvx, uvy);
+                float jx, jy, kx, ky;
+                rand_point_in_circle(seed, jx, jy);
+                const f3 jitter = F3(jx * (1.0f / un.res_x), jy * (1.0f / un.res_y), 0.0f);
+                rand_point_in_circle(seed, kx, ky);
+                const f3 jitter2 = F3(kx * un.aperture, ky * un.aperture, 0.0f);
+                const f3 focal = (cam_pos + dir0 * un.focal_distance) + jitter;
+                o = cam_pos + jitter2;
+                d = normalize(focal - o);
+                bounce = 0;
+                light = F3(0.0f, 0.0f, 0.0f);
+                ray_color = F3(1.0f, 1.0f, 1.0f);
+                if (un.max_bounces > 0) { need_segment = true; break; }
+                incoming = incoming + light;
+                sample++;
+            }
+        }
+        if (need_segment) {
+            // raySceneIntersect + the root test of rayBVHIntersect, raytrace.wgsl:155-164, 205-211
+            best.t = PT_INF; best.u = 0.0f; best.v = 0.0f; best.tri = -1;
+            cnt.rays++;
+            mode = M_SHADE;
+            if (sc.nnodes != 0) {
+                pre = ray_prepare(o, d, sc.flags);
+                cnt.box++;
+                if (ray_aabb_pre(o, d, pre, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
+                    stack[0] = sc.root_ref;
+                    sp = 1;
+                    mode = M_TRAV;
+                }
+            }
+        }
+    }
+
+    if (L.wave_times && lane == 0) {
+        uint64_t *w = L.wave_times + (size_t)blockIdx.x * 4;
+        w[0] = t_begin_rt;
+        w[1] = t_empty_rt;
+        w[2] = __builtin_amdgcn_s_memrealtime();
+        w[3] = __builtin_amdgcn_s_memtime() - t_begin_clk;
+    }
+    const uint32_t s_rays = wave_sum(cnt.rays), s_box = wave_sum(cnt.box), s_tri = wave_sum(cnt.tri);
+    const uint32_t s_hit = wave_sum(cnt.hit), s_miss = wave_sum(cnt.miss);
+    const uint32_t s_ovf = wave_sum(cnt.overflow), s_pix = wave_sum(cnt.pixels);
+    if (lane == 0 && L.block_counters) {
+        uint64_t *c = L.block_counters + (size_t)blockIdx.x * CNT_COUNT;
+        c[CNT_RAYS] += s_rays; c[CNT_BOX] += s_box; c[CNT_TRI] += s_tri; c[CNT_HIT] += s_hit;
+        c[CNT_MISS] += s_miss; c[CNT_OVERFLOW] += s_ovf; c[CNT_PIXELS] += s_pix;
+    }
+}
+
+int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu)
+{
+    const int ntiles = raytrace_grid_blocks(tile);
+    if (waves_per_cu <= 0 || waves_per_cu > 10) waves_per_cu = 10;   // 16 KB of LDS per one-wave workgroup
+    const int resident = 256 * waves_per_cu;
+    return ntiles < resident ? ntiles : resident;
+}
+
 int raytrace_grid_blocks(const Tile &tile)
 {
     const int tiles_x = (tile.tex_w + 7) / 8;
@@ -496,7 +1083,20 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
 {
     const int blocks = raytrace_grid_blocks(L.tile);
     if (blocks <= 0) return;
-    const dim3 grid(blocks), block(64);
+    const dim3 block(64);
+    if (variant >= 3) {
+        const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu));
+        (void)hipMemsetAsync(L.tile_counter, 0, sizeof(uint32_t), s);
+        if (variant == 3) {
+            if (fuse) hipLaunchKernelGGL((k_raytrace_persistent<true>), grid, block, 0, s, L);
+            else hipLaunchKernelGGL((k_raytrace_persistent<false>), grid, block, 0, s, L);
+        } else {
+            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true>), grid, block, 0, s, L);
+            else hipLaunchKernelGGL((k_raytrace_sm<false>), grid, block, 0, s, L);
+        }
+        return;
+    }
+    const dim3 grid(blocks);
     if (variant == 2) {
         if (fuse) hipLaunchKernelGGL((k_raytrace<true, 2>), grid, block, 0, s, L);
         else hipLaunchKernelGGL((k_raytrace<false, 2>), grid, block, 0, s, L);
@@ -700,7 +1300,8 @@ void launch_debug_intersect(const SceneRefs &scene, const float *rays, size_t n,
 {
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    if (variant == 2) hipLaunchKernelGGL(k_debug_intersect<2>, grid, block, 0, s, scene, rays, n, out);
+    if (variant >= 3) hipLaunchKernelGGL(k_debug_intersect<3>, grid, block, 0, s, scene, rays, n, out);
+    else if (variant == 2) hipLaunchKernelGGL(k_debug_intersect<2>, grid, block, 0, s, scene, rays, n, out);
     else hipLaunchKernelGGL(k_debug_intersect<1>, grid, block, 0, s, scene, rays, n, out);
 }
 

@@ -29,7 +29,7 @@ SYMBOLS = (
     "mi3pt_set_uniforms", "mi3pt_submit", "mi3pt_sync", "mi3pt_read_texture", "mi3pt_read_canvas_rgba8",
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
-    "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
+    "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
 )
 
@@ -81,6 +81,7 @@ def load_library(path=None):
     lib.mi3pt_reset_counters.argtypes = [c_void_p]
     lib.mi3pt_debug_intersect.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.mi3pt_debug_math.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t]
+    lib.mi3pt_debug_wave_times.argtypes = [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]
     lib.mi3pt_host_build_bvh.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
     lib.mi3pt_host_build_bvh_f64.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
     lib.mi3pt_host_env_cdf.argtypes = [c_void_p, c_int, c_int, c_void_p]
@@ -279,6 +280,15 @@ class Context:
         out = np.empty((len(r), 12), np.float32)
         self._c(self.lib.mi3pt_debug_intersect(self.handle, _ptr(r), len(r), _ptr(out)))
         return out
+
+    def enable_wave_times(self, enabled=True):
+        self._c(self.lib.mi3pt_debug_wave_times(self.handle, int(enabled), None, 0, None))
+
+    def wave_times(self):
+        out = np.zeros((2560, 4), np.uint64)
+        n = ctypes.c_size_t()
+        self._c(self.lib.mi3pt_debug_wave_times(self.handle, 1, _ptr(out), len(out), ctypes.byref(n)))
+        return out[:n.value]
 
     def debug_math(self, fn, a, b=None):
         a = np.ascontiguousarray(a, np.float32)
