@@ -1,0 +1,90 @@
+"""Multi-GPU path on CPU: world_size 2 over gloo.  Each rank renders its round-robin 8-row
+blocks (with the oracle standing in for the device), the HDR accumulation buffers are
+gathered to rank 0 exactly as bench.py does over RCCL, and the de-interleaved image
+must equal the single-rank image bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import ptcommon as pc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, block, outq):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (os.path.join(root, "webgpu-pathtracer_amd", "py"), os.path.join(root, "oracle"), here):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import pt_oracle as orc
+    from mi3pt_host import capi, scenes
+    from mi3pt_host.tiles import deinterleave_rows
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = scenes.demo_scene()
+    sc.build_bvh(nthreads=2)
+    env = scenes.synthetic_env()
+    osc = orc.OracleScene(sc.triangles, sc.material_bytes, sc.nodes, env)
+    rows = capi.tile_local_rows(h, rank, world, block)
+    acc = np.zeros((rows, w, 4), np.float32)
+    for frame in (2, 3):
+        img, _ = orc.raytrace(osc, pc.rt_uniforms(sc, w, h, frame=frame, bounces=3).tobytes(), w, h, rank, world, block)
+        acc = orc.accumulate(pc.acc_uniforms(w, h, frame).tobytes(), w, h, img, acc, rank, world, block)
+    max_rows = capi.tile_local_rows(h, 0, world, block)
+    send = torch.zeros((max_rows, w, 4))
+    send[:rows] = torch.from_numpy(acc)
+    gathered = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, gathered, dst=0)
+    if rank == 0:
+        whole = deinterleave_rows([g.numpy() for g in gathered], h, world, block)
+        outq.put(whole)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w,h,block", [(48, 40, 8), (40, 37, 5)])
+def test_two_rank_tile_split_gathers_to_the_whole_image(orc, demo, env, w, h, block):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, w, h, block, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    whole = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    osc = pc.oracle_scene(orc, demo, env)
+    acc = np.zeros((h, w, 4), np.float32)
+    for frame in (2, 3):
+        img, _ = orc.raytrace(osc, pc.rt_uniforms(demo, w, h, frame=frame, bounces=3).tobytes(), w, h)
+        acc = orc.accumulate(pc.acc_uniforms(w, h, frame).tobytes(), w, h, img, acc)
+    assert pc.same_bits(whole, acc), pc.describe_diff(whole, acc)
+
+
+def test_deinterleave_is_the_inverse_of_the_row_deal():
+    from mi3pt_host import capi
+    from mi3pt_host.tiles import deinterleave_rows, local_rows_of
+    h, w = 70, 3
+    img = np.arange(h * w * 4, dtype=np.float32).reshape(h, w, 4)
+    for world, block in ((1, 8), (2, 8), (3, 5), (8, 8), (4, 16)):
+        parts = []
+        for r in range(world):
+            rows = local_rows_of(h, r, world, block)
+            assert len(rows) == capi.tile_local_rows(h, r, world, block)
+            pad = np.zeros((capi.tile_local_rows(h, 0, world, block), w, 4), np.float32)
+            pad[:len(rows)] = img[rows]
+            parts.append(pad)
+        assert np.array_equal(deinterleave_rows(parts, h, world, block), img)
