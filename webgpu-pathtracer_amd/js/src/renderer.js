@@ -1,0 +1,185 @@
+'use strict';
+// src/renderer.ts without the DOM: same public API (create / diagnostic / render / update /
+// setUniforms / reset / start / pause / resize / destroy / on / emit; frames,
+// samplesPerFrame, scalingFactor, status, frame, progress, hasFramesToSample, timings,
+// width / height / scaledWidth / scaledHeight / aspect), the GPUDevice replaced by a
+// libmi3pt.so context reached through the N-API addon.  canvas / context / format have no
+// headless meaning; readOutput / readAccumulation / readCanvas are the read-back a headless
+// drop-in needs instead of canvas.toDataURL (src/main.ts:351-356).
+const path = require('path');
+const { RaytracePass } = require('./passes/raytrace');
+const { AccumulatePass } = require('./passes/accumulate');
+const { FullscreenPass } = require('./passes/fullscreen');
+const { FloatType } = require('./scene');
+
+const TEX_OUTPUT = 0, TEX_ACCUMULATION = 1, TEX_CANVAS = 2;
+
+let nativeModule = null;
+function loadNative() {
+  if (nativeModule === null) {
+    try {
+      nativeModule = require(path.join(__dirname, '..', 'mi3pt.node'));
+    } catch (err) {
+      throw new Error('mi3pt.node / libmi3pt.so not loadable (build with __graft_entry__.build()): ' + err.message);
+    }
+  }
+  return nativeModule;
+}
+
+class Renderer {
+  constructor(args) {                                   // renderer.ts:47-92
+    this.native = args.native;
+    this.handle = args.handle;
+    this.options = Object.assign({ enableTimestampQuery: false, verbose: false, presentEveryFrame: true },
+      args.options || {});
+    this._width = 0;
+    this._height = 0;
+    this._frame = 1;
+    this._scalingFactor = 0.25;
+    this.frames = 64;
+    this.samplesPerFrame = 1;
+    this.status = 'idle';
+    this.listeners = new Map();
+    this.tile = args.tile || { rank: 0, nranks: 1, blockRows: 8 };
+    if (this.options.enableTimestampQuery) this.native.enableTiming(this.handle, 1);
+    this.passes = {
+      raytrace: new RaytracePass(this),
+      accumulate: new AccumulatePass(this),
+      fullscreen: new FullscreenPass(this),
+    };
+  }
+
+  // ---- renderer.ts:470-533
+  static async diagnostic() {
+    let native;
+    try { native = loadNative(); } catch (err) { return { supported: false }; }
+    if (native.deviceCount() <= 0) return { supported: false };
+    return { supported: true, info: { description: native.deviceName(0), vendor: 'amd', architecture: 'gfx950' } };
+  }
+
+  static async create(options) {
+    const native = loadNative();
+    const opts = options || {};
+    const handle = native.create(opts.device || 0);      // throws "HIP device not found." (renderer.ts:514-516)
+    const tile = opts.tile || { rank: 0, nranks: 1, blockRows: 8 };
+    native.setTile(handle, tile.rank, tile.nranks, tile.blockRows);
+    return new Renderer({ native, handle, options: opts, tile });
+  }
+
+  // ---- renderer.ts:132-281
+  updateEnvironmentTexture(texture) {
+    if (texture.image.width !== 1024 || texture.image.height !== 512) {
+      throw new Error('Environment texture must be 1024x512 pixels. Please resize the texture and try again.');
+    }
+    if (texture.type !== FloatType) {
+      throw new Error('Environment texture must be a floating point texture. Please convert the texture and try again.');
+    }
+    const data = texture.image.data;
+    this.native.uploadEnvironment(this.handle, data, 1024, 512);
+    this.native.uploadEnvironmentCdf(this.handle, this.native.hostEnvCdf(data, 1024, 512), 1024, 512);
+  }
+
+  // ---- renderer.ts:283-324
+  resize(width, height) {
+    if (this._width === width && this._height === height) return;
+    this._width = width;
+    this._height = height;
+    this.native.resize(this.handle, width, height);
+    this.reset();
+    this.emit('resize');
+  }
+  get scalingFactor() { return this._scalingFactor; }
+  set scalingFactor(value) {
+    this._scalingFactor = value;
+    this.setUniforms('fullscreen', { scalingFactor: value });
+  }
+  get width() { return this._width; }
+  get scaledWidth() { return this._width * this._scalingFactor; }
+  get height() { return this._height; }
+  get scaledHeight() { return this._height * this._scalingFactor; }
+  get aspect() { return this._width / this._height; }
+
+  // ---- renderer.ts:330-356
+  get hasFramesToSample() { return this._frame <= this.frames; }
+  get progress() { return this._frame / (this.frames + 1); }
+  get frame() { return this._frame; }
+  set frame(value) {
+    this._frame = value;
+    if (this._frame > this.frames) {
+      this.status = 'idle';
+      this.emit('complete');
+    }
+  }
+  get timings() {
+    return {
+      raytrace: this.passes.raytrace.timingAverage,
+      accumulate: this.passes.accumulate.timingAverage,
+      fullscreen: this.passes.fullscreen.timingAverage,
+    };
+  }
+
+  setUniforms(pass, value) { this.passes[pass].setUniforms(value); }        // renderer.ts:358-360
+  update(scene, camera) { this.passes.raytrace.updateScene(scene, camera); } // renderer.ts:362-364
+
+  render(scene, camera) {                                                    // renderer.ts:366-395
+    this.update(scene, camera);
+    const shouldSample = this.status === 'sampling' && this.hasFramesToSample;
+    if (shouldSample) this.frame++;
+    this.passes.raytrace.update();
+    this.passes.accumulate.update();
+    this.passes.fullscreen.update();
+    const commandEncoder = { passes: 0 };
+    if (shouldSample) {
+      this.passes.raytrace.render(commandEncoder);
+      this.emit('progress', this.progress);
+    }
+    if (shouldSample) this.passes.accumulate.render(commandEncoder);
+    if (this.options.presentEveryFrame) this.passes.fullscreen.render(commandEncoder);
+    if (commandEncoder.passes) this.native.submit(this.handle, commandEncoder.passes);   // queue.submit
+    if (shouldSample) this.passes.raytrace.updateTimings();
+    if (shouldSample) this.passes.accumulate.updateTimings();
+    if (this.options.presentEveryFrame) this.passes.fullscreen.updateTimings();
+  }
+
+  reset() {                                                                  // renderer.ts:397-416
+    const prevStatus = this.status;
+    this.status = 'paused';
+    if (this._width > 0) this.native.reset(this.handle);
+    this.emit('reset');
+    this._frame = 1;
+    this.status = prevStatus === 'idle' ? 'sampling' : prevStatus;
+    if (this.status === 'sampling') this.emit('start');
+  }
+
+  async destroy() {                                                          // renderer.ts:418-429
+    this.native.sync(this.handle);
+    this.native.destroy(this.handle);
+  }
+
+  start() { this.status = this._frame > this.frames ? 'idle' : 'sampling'; } // renderer.ts:431-437
+  pause() {                                                                  // renderer.ts:439-444
+    if (this.status !== 'paused') {
+      this.status = 'paused';
+      this.emit('pause');
+    }
+  }
+  on(event, callback) {                                                      // renderer.ts:446-458
+    if (!this.listeners.has(event)) this.listeners.set(event, []);
+    this.listeners.get(event).push(callback);
+  }
+  emit(event) {                                                              // renderer.ts:460-468
+    const args = Array.prototype.slice.call(arguments, 1);
+    const list = this.listeners.get(event);
+    if (list) list.forEach((callback) => callback.apply(null, args));
+  }
+
+  // ---- headless read-back
+  get localRows() { return this.native.tileLocalRows(this._height, this.tile.rank, this.tile.nranks, this.tile.blockRows); }
+  readOutput() { return this.native.readTexture(this.handle, TEX_OUTPUT, this.localRows * this._width * 4); }
+  readAccumulation() { return this.native.readTexture(this.handle, TEX_ACCUMULATION, this.localRows * this._width * 4); }
+  readCanvasFloat() { return this.native.readTexture(this.handle, TEX_CANVAS, this._height * this._width * 4); }
+  readCanvas() { return this.native.readCanvasRgba8(this.handle, this._height * this._width * 4); }
+  counters() { return this.native.getCounters(this.handle); }
+}
+
+module.exports = { Renderer, loadNative };
