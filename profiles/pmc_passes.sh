@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 while read -r counters; do
   i=$((i+1))
+  if [ -n "${PASSES:-}" ] && ! echo " $PASSES " | grep -q " $i "; then continue; fi
   rocprofv3 --kernel-trace --pmc $counters --output-format csv -d $ROOT/$OUT/pass$i -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > $ROOT/$OUT.pass$i.log 2>&1
 done <<'LIST'
 SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY

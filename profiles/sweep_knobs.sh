@@ -1,3 +1,6 @@
-for wm in 8 16 24 32 40; do echo "walk_min $wm: $(MI3PT_WALK_MIN=$wm python bench.py --no-cpu-baseline --steps 24 --variant 4 2>/dev/null | python -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], j["ms_per_step"])')"; done
-for w in 4 6 8 10; do echo "waves/cu $w: $(MI3PT_WAVES_PER_CU=$w python bench.py --no-cpu-baseline --steps 24 --variant 4 2>/dev/null | python -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], j["ms_per_step"])')"; done
-for im in 960x540 1920x1080 3840x2160 3840x4320; do echo "image $im: $(python bench.py --no-cpu-baseline --steps 12 --variant 4 --image $im 2>/dev/null | python -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], j["ms_per_step"])')"; done
+#!/bin/bash
+# Knob sweeps for the state-machine kernel (demo workload, 1080p).  usage: sweep_knobs.sh
+run() { python bench.py --no-cpu-baseline --steps 32 "$@" 2>/dev/null | python -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], j["ms_per_step"])'; }
+for w in 8 10 12 16; do echo "waves/cu $w pipelined: $(MI3PT_WAVES_PER_CU=$w run)"; done
+for w in 10 16; do echo "waves/cu $w unpipelined: $(MI3PT_PIPELINE=0 MI3PT_WAVES_PER_CU=$w run)"; done
+for wm in 24 32 40 48; do echo "walk_min $wm (16 waves/cu): $(MI3PT_WALK_MIN=$wm run)"; done

@@ -56,6 +56,7 @@ struct mi3pt_ctx {
     bool output_is_accum = false;
     uint64_t *d_block_counters = nullptr;
     uint32_t *d_tile_counter = nullptr;
+    uint32_t *d_stack_overflow = nullptr; // [2 parities][4096 waves][32][64] overflow stack entries
     uint64_t *d_wave_times = nullptr;     // diagnostic stamps, allocated by mi3pt_debug_wave_times(enable)
     int wave_times_slots = 0;
     int nblocks = 0;
@@ -67,7 +68,7 @@ struct mi3pt_ctx {
     int storage = MI3PT_STORAGE_F32;
     int variant = 0;
     int walk_min = 32;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
-    int waves_per_cu = 10;
+    int waves_per_cu = 16;
 
     // Frame pipelining: raytrace kernels of consecutive frames run on two alternating
     // internal streams so that frame f+1 fills the CUs while frame f's last paths drain;
@@ -149,7 +150,8 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
     if (hipMalloc(&ctx->d_env, env_bytes) != hipSuccess || hipMalloc(&ctx->d_cdf, env_bytes) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_tile_counter, 256) != hipSuccess) {
+        hipMalloc((void **)&ctx->d_tile_counter, 256) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * 4096 * 32 * 64 * 4) != hipSuccess) {
         mi3pt_destroy(ctx);
         return pt_set_error(MI3PT_ERR_HIP, "hipMalloc(environment) failed");
     }
@@ -188,7 +190,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     free_textures(ctx);
     for (void *p : { ctx->d_tris, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk,
-                     (void *)ctx->d_tile_counter, (void *)ctx->d_wave_times })
+                     (void *)ctx->d_tile_counter, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
         for (int k = 0; k < 2; k++)
@@ -310,14 +312,19 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
     std::vector<uint32_t> packet_of(n, pt::REF_NONE);
     size_t npackets = 0;
     int64_t max_tri = -1;
-    bool coords_safe = true;     // precondition of the exact fast slab test (pt_kernels.hip, RayPre)
-    for (size_t i = 0; i < n; i++) {
-        const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+    // precondition of the exact fast slab test (pt_kernels.hip, RayPre): per box, every
+    // coordinate is 0 or within [2^-70, 2^60]
+    auto box_safe = [&](size_t node) {
+        const uint8_t *r = src + node * MI3PT_BVHNODE_STRIDE;
         for (size_t off : { (size_t)0, (size_t)4, (size_t)8, (size_t)16, (size_t)20, (size_t)24 }) {
             const float v = ldf(r, off);
             const float a = v < 0 ? -v : v;
-            if (!(v == 0.0f || (a >= 8.470329472543003e-22f && a <= 1.152921504606847e18f))) coords_safe = false;
+            if (!(v == 0.0f || (a >= 8.470329472543003e-22f && a <= 1.152921504606847e18f))) return false;
         }
+        return true;
+    };
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
         if (ldi(r, 28) == 1) {
             const int32_t ti = ldi(r, 40);
             if (ti < 0) return pt_set_error(MI3PT_ERR_INVALID, "leaf node with negative triangleIndex");
@@ -358,13 +365,14 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
         }
         p.lref = ref_of(left);
         p.rref = ref_of(right);
+        p.flags = ((left >= 0 && !box_safe((size_t)left)) ? 1u : 0u) | ((right >= 0 && !box_safe((size_t)right)) ? 2u : 0u);
     }
     if (int rc = replace_buffer(ctx, &ctx->d_nodes, bytes, nbytes)) return rc;
     if (int rc = replace_buffer(ctx, &ctx->d_packets, pk.data(), pk.size() * sizeof(pt::NodePacket))) return rc;
     ctx->nnodes = n;
     ctx->npackets = npackets;
     ctx->root_ref = ref_of(0);
-    ctx->scene_flags = coords_safe ? 1u : 0u;
+    ctx->scene_flags = box_safe(0) ? 1u : 0u;
     ctx->max_tri_ref = max_tri;
     return MI3PT_OK;
 }
@@ -488,6 +496,7 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.npackets = (uint32_t)ctx->npackets;
     s.root_ref = ctx->root_ref;
     s.flags = ctx->scene_flags;
+    if (std::getenv("MI3PT_FORCE_SLOW_SLAB")) s.flags = 0;     // experiment knob: plain IEEE divisions
     s.env_w = MI3PT_ENV_WIDTH; s.env_h = MI3PT_ENV_HEIGHT;
     return s;
 }
@@ -549,6 +558,7 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
         L.block_counters = ctx->d_block_counters;
         L.tile_counter = ctx->d_tile_counter;
         L.wave_times = ctx->d_wave_times;
+        L.stack_overflow = ctx->d_stack_overflow;
         L.store_f16 = f16;
         L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
         L.waves_per_cu = ctx->waves_per_cu;
@@ -570,6 +580,7 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
             L.radiance = par ? ctx->d_radiance_alt : ctx->d_radiance;
             L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
             L.tile_counter = ctx->d_tile_counter + par * 32;
+            L.stack_overflow = ctx->d_stack_overflow + (size_t)par * 4096 * 32 * 64;
             if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0][0], rs));
             pt::launch_raytrace(L, false, variant, rs);
             HIP_TRY(hipGetLastError());

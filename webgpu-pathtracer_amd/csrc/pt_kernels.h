@@ -20,7 +20,8 @@ struct NodePacket {
     float lmin[3], lmax[3];
     float rmin[3], rmax[3];
     uint32_t lref, rref;     // child reference: leaf -> 0x80000000 | triangleIndex, else packet index
-    uint32_t pad[2];
+    uint32_t flags;          // bit0 / bit1: left / right box has a non-zero coordinate outside [2^-70, 2^60]
+    uint32_t pad;
 };
 static_assert(sizeof(NodePacket) == 64, "packet is one 64-B line");
 
@@ -43,7 +44,7 @@ struct SceneRefs {
     const float4 *tripk;    // TriPacket array, or null
     uint32_t ntris, nnodes, nmats, npackets;
     uint32_t root_ref;      // reference of node 0 in packet terms
-    uint32_t flags;         // bit0: every box coordinate is 0 or within [2^-70, 2^60] (fast slab test allowed)
+    uint32_t flags;         // bit0: every ROOT box coordinate is 0 or within [2^-70, 2^60]
     int32_t env_w, env_h;
 };
 
@@ -83,6 +84,7 @@ struct RtLaunch {
     float4 *accum;               // running mean
     uint64_t *block_counters;    // [gridDim.x][CNT_COUNT]
     uint32_t *tile_counter;      // work queue head of the persistent kernel (zeroed per launch)
+    uint32_t *stack_overflow;    // state-machine kernel: [grid][32][64] stack entries beyond the LDS part
     uint64_t *wave_times;        // diagnostic: [grid][4] begin / feed-empty / end (100 MHz) + shader cycles, or null
     int32_t store_f16;
     int32_t walk_min;            // state-machine kernel: walk while at least this many lanes are walking

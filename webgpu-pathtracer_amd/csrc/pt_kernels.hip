@@ -66,6 +66,7 @@ PT_DEV float clamp1(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi
 
 struct Counters {
     uint32_t rays, box, tri, hit, miss, overflow, pixels;
+    uint32_t slow;      // path segments that took the plain-division fallback of the fast slab test
 };
 
 struct Best {
@@ -110,8 +111,10 @@ PT_DEV bool ray_aabb(const f3 &o, const f3 &d, float mnx, float mny, float mnz,
 // significand of d is not all ones and nothing under/overflows):
 //     q0 = n*y;  q1 = fma(fma(-d, q0, n), y, q0);  q2 = fma(fma(-d, q1, n), y, q1)
 // 5 VALU ops instead of the 11 of the hardware division expansion.  The conditions
-// are checked per ray (RayPre::slow) and per scene (SceneRefs::flags); a ray that
-// fails them takes ray_aabb() above.  tests/test_gpu_parity.py holds this kernel
+// are checked per ray (RayPre::slow: direction significand / range, origin components 0
+// or within [2^-70, 2^60]) and per box (a packet flag set at upload for the rare boxes
+// with a non-zero coordinate outside [2^-70, 2^60], e.g. the 1e-33 residues three.js's
+// SphereGeometry leaves at the poles); a test that fails them takes ray_aabb() above.  tests/test_gpu_parity.py holds this kernel
 // bit-identical to the plain-division kernels; oracle-side evidence for the identity
 // is tests/test_exact_division.py (CPU, brute force).
 // ---------------------------------------------------------------------------------
@@ -144,16 +147,17 @@ PT_DEV RayPre ray_prepare(const f3 &o, const f3 &d, uint32_t scene_flags)
     const bool bad_x = !px && ((__float_as_uint(d.x) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.x) > 1048576.0f);
     const bool bad_y = !py && ((__float_as_uint(d.y) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.y) > 1048576.0f);
     const bool bad_z = !pz && ((__float_as_uint(d.z) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.z) > 1048576.0f);
-    const bool slow = bad_x || bad_y || bad_z || !(scene_flags & 1u) || !safe_magnitude(o.x) ||
+    (void)scene_flags;
+    const bool slow = bad_x || bad_y || bad_z || !safe_magnitude(o.x) ||
                       !safe_magnitude(o.y) || !safe_magnitude(o.z) || !(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z);
     p.flags = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u) | (slow ? 8u : 0u);
     return p;
 }
 
-PT_DEV bool ray_aabb_pre(const f3 &o, const f3 &d, const RayPre &p, float mnx, float mny, float mnz,
+PT_DEV bool ray_aabb_pre(const f3 &o, const f3 &d, const RayPre &p, bool box_unsafe, float mnx, float mny, float mnz,
                          float mxx, float mxy, float mxz)
 {
-    if (p.flags & 8u) return ray_aabb(o, d, mnx, mny, mnz, mxx, mxy, mxz);
+    if ((p.flags & 8u) || box_unsafe) return ray_aabb(o, d, mnx, mny, mnz, mxx, mxy, mxz);
     bool ok = true;
     float tnx, tfx, tny, tfy, tnz, tfz;
     {
@@ -317,7 +321,7 @@ PT_DEV void traverse_packets_pre(const SceneRefs &sc, const f3 &o, const f3 &d,
     {
         const float4 n0 = sc.nodes[0], n1 = sc.nodes[1];
         cnt.box++;
-        if (!ray_aabb_pre(o, d, pre, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z)) return;
+        if (!ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z)) return;
     }
     int sp = 1;
     stack[0] = sc.root_ref;
@@ -343,11 +347,11 @@ PT_DEV void traverse_packets_pre(const SceneRefs &sc, const f3 &o, const f3 &d,
             const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
             if (lref != PT_REF_NONE) {
                 cnt.box++;
-                if (ray_aabb_pre(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y)) { stack[sp * 64] = lref; sp++; }
+                if (ray_aabb_pre(o, d, pre, (__float_as_uint(p3.z) & 1u) != 0u, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y)) { stack[sp * 64] = lref; sp++; }
             }
             if (rref != PT_REF_NONE) {
                 cnt.box++;
-                if (ray_aabb_pre(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w)) { stack[sp * 64] = rref; sp++; }
+                if (ray_aabb_pre(o, d, pre, (__float_as_uint(p3.z) & 2u) != 0u, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w)) { stack[sp * 64] = rref; sp++; }
             }
         }
     }
@@ -582,7 +586,7 @@ __global__ void __launch_bounds__(64) k_raytrace(const RtLaunch L)
     const int ly = tile_y * 8 + (lane >> 3);
     const int gy = local_to_global_row(ly, L.tile);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
     // raytrace.wgsl:425-427
     const bool in_tex = gx < L.tile.tex_w && ly < L.tile.local_rows && gy < L.tile.tex_h;
     const bool active = in_tex && (uint32_t)gx < (uint32_t)L.un.res_x && (uint32_t)gy < (uint32_t)L.un.res_y;
@@ -678,7 +682,7 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
     float sinr, cosr;
     ptm::sincos(un.env_rotation, sinr, cosr);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
     PathSlot p;
     p.alive = false;
     p.gx = p.gy = p.ly = p.seed = 0u;
@@ -831,12 +835,29 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
 // ---------------------------------------------------------------------------------
 enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
 
+#define PT_SM_LDS_DEPTH 32
+#ifndef PT_SM_MIN_WAVES
+#define PT_SM_MIN_WAVES 4
+#endif
+
 template <bool FUSE>
-__global__ void __launch_bounds__(64) k_raytrace_sm(const RtLaunch L)
+__global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
 {
-    __shared__ uint32_t stack_lds[PT_MAX_STACK * 64];
+    // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
+    // deeper entries (rare: the stack holds about one entry per tree level) go to this
+    // wave's slice of a global overflow area, so the 64-entry abort semantics are kept
+    // while a wave only needs 8 KB of LDS.
+    __shared__ uint32_t stack_lds[PT_SM_LDS_DEPTH * 64];
     const int lane = threadIdx.x;
     uint32_t *stack = stack_lds + lane;
+    uint32_t *ovf = L.stack_overflow + (size_t)blockIdx.x * ((PT_MAX_STACK - PT_SM_LDS_DEPTH) * 64) + lane;
+    auto st_load = [&](int i) -> uint32_t {
+        return i < PT_SM_LDS_DEPTH ? stack[i * 64] : ovf[(i - PT_SM_LDS_DEPTH) * 64];
+    };
+    auto st_store = [&](int i, uint32_t v) {
+        if (i < PT_SM_LDS_DEPTH) stack[i * 64] = v;
+        else ovf[(i - PT_SM_LDS_DEPTH) * 64] = v;
+    };
     const SceneRefs &sc = L.scene;
     const RtUniforms &un = L.un;
     const int tiles_x = (L.tile.tex_w + 7) >> 3;
@@ -855,7 +876,7 @@ __global__ void __launch_bounds__(64) k_raytrace_sm(const RtLaunch L)
     const uint64_t t_begin_clk = L.wave_times ? __builtin_amdgcn_s_memtime() : 0ull;
     uint64_t t_empty_rt = 0ull;
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
     int mode = M_DEAD;
     f3 o = F3(0.0f, 0.0f, 0.0f), d = o, ray_color = o, light = o, incoming = o;
     uint32_t gx = 0u, gy = 0u, ly = 0u, seed = 0u;
@@ -885,7 +906,7 @@ __global__ void __launch_bounds__(64) k_raytrace_sm(const RtLaunch L)
             // ---- walk step: one pop per walking lane (raytrace.wgsl:166-200)
             if (mode == M_TRAV) {
                 sp--;
-                const uint32_t ref = stack[sp * 64];
+                const uint32_t ref = st_load(sp);
                 if (ref & PT_REF_LEAF) {
                     const uint32_t ti = ref & 0x7fffffffu;
                     const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
@@ -904,11 +925,11 @@ __global__ void __launch_bounds__(64) k_raytrace_sm(const RtLaunch L)
                     const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
                     if (lref != PT_REF_NONE) {
                         cnt.box++;
-                        if (ray_aabb_pre(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y)) { stack[sp * 64] = lref; sp++; }
+                        if (ray_aabb_pre(o, d, pre, (__float_as_uint(p3.z) & 1u) != 0u, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y)) { st_store(sp, lref); sp++; }
                     }
                     if (rref != PT_REF_NONE) {
                         cnt.box++;
-                        if (ray_aabb_pre(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w)) { stack[sp * 64] = rref; sp++; }
+                        if (ray_aabb_pre(o, d, pre, (__float_as_uint(p3.z) & 2u) != 0u, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w)) { st_store(sp, rref); sp++; }
                     }
                 }
                 if (sp >= PT_MAX_STACK) { cnt.overflow++; mode = M_SHADE; }     // :167-171
@@ -1037,9 +1058,10 @@ __global__ void __launch_bounds__(64) k_raytrace_sm(const RtLaunch L)
             mode = M_SHADE;
             if (sc.nnodes != 0) {
                 pre = ray_prepare(o, d, sc.flags);
+                if (pre.flags & 8u) cnt.slow++;
                 cnt.box++;
-                if (ray_aabb_pre(o, d, pre, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
-                    stack[0] = sc.root_ref;
+                if (ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
+                    st_store(0, sc.root_ref);
                     sp = 1;
                     mode = M_TRAV;
                 }
@@ -1056,18 +1078,19 @@ __global__ void __launch_bounds__(64) k_raytrace_sm(const RtLaunch L)
     }
     const uint32_t s_rays = wave_sum(cnt.rays), s_box = wave_sum(cnt.box), s_tri = wave_sum(cnt.tri);
     const uint32_t s_hit = wave_sum(cnt.hit), s_miss = wave_sum(cnt.miss);
-    const uint32_t s_ovf = wave_sum(cnt.overflow), s_pix = wave_sum(cnt.pixels);
+    const uint32_t s_ovf = wave_sum(cnt.overflow), s_pix = wave_sum(cnt.pixels), s_slow = wave_sum(cnt.slow);
     if (lane == 0 && L.block_counters) {
         uint64_t *c = L.block_counters + (size_t)blockIdx.x * CNT_COUNT;
         c[CNT_RAYS] += s_rays; c[CNT_BOX] += s_box; c[CNT_TRI] += s_tri; c[CNT_HIT] += s_hit;
         c[CNT_MISS] += s_miss; c[CNT_OVERFLOW] += s_ovf; c[CNT_PIXELS] += s_pix;
+        c[CNT_RESERVED] += s_slow;
     }
 }
 
 int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu)
 {
     const int ntiles = raytrace_grid_blocks(tile);
-    if (waves_per_cu <= 0 || waves_per_cu > 10) waves_per_cu = 10;   // 16 KB of LDS per one-wave workgroup
+    if (waves_per_cu <= 0 || waves_per_cu > 16) waves_per_cu = 16;   // VGPR-limited: 4 waves per SIMD
     const int resident = 256 * waves_per_cu;
     return ntiles < resident ? ntiles : resident;
 }
@@ -1280,7 +1303,7 @@ __global__ void __launch_bounds__(64) k_debug_intersect(const SceneRefs sc, cons
     if (i >= n) return;
     const f3 o = F3(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
     const f3 d = F3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
     Best best;
     traverse<VARIANT>(sc, o, d, stack_lds + threadIdx.x, best, cnt);
     float *r = out + i * 12;
