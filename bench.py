@@ -62,13 +62,27 @@ def algorithmic_bytes(c):
     return 48 * c["box_tests"] + 112 * c["tri_tests"] + 64 * c["hits"] + 64 * c["misses"] + 32 * c["pixels"]
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (separate runs,
+    see profiles/pmc_passes.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    16-B-per-lane reads, WRITE_SIZE as is).  Collected offline and committed as
+    profiles/traffic.json; null when no measurement exists for the workload."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            entry = json.load(f).get(workload)
+        return int(entry["hbm_bytes_per_launch"]) if entry else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(sc, env, un_bytes_for_frame, width, height, budget_s=12.0):
     """Time the CPU oracle on interleaved 1/32 shards of the same frames until the
     budget is used.  kind = "port": the oracle is a restatement, not the reference."""
     import pt_oracle as orc
     osc = orc.OracleScene(sc.triangles, sc.material_bytes, sc.nodes, env)
     cores = os.cpu_count() or 1
-    shards = 32
+    shards = 8
     rays = 0
     pixels = 0
     n = 0
@@ -80,7 +94,7 @@ def cpu_baseline(sc, env, un_bytes_for_frame, width, height, budget_s=12.0):
         pixels += cnt["pixels"]
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= shards * 4:
+        if dt >= budget_s or n >= shards * 512:
             break
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"{n} interleaved 1/{shards}-image shards of the same {width}x{height} 8-bounce frames "
@@ -144,7 +158,7 @@ def main():
         u.set({"resolution": [width, height], "frame": frame, "enabled": 1})
         return u.tobytes()
 
-    stream = torch.cuda.Stream()
+    stream = torch.cuda.Stream()       # the context's main stream (events below are recorded on it)
     ctx = capi.Context(local_rank)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_kernel_variant(args.variant)
@@ -181,14 +195,13 @@ def main():
     ctx.sync()
     ctx.reset_counters()
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ---- the timed job: K frames (raytrace kernels of consecutive frames overlap on two
+    # internal streams; the ordered accumulate runs on `stream`), then the one gather.
     sync_all()
     t0 = time.perf_counter()
-    ev0.record(stream)
     for _ in range(args.steps):
         one_frame(frame)
         frame += 1
-    ev1.record(stream)
     if world > 1:
         # the one exchange of the job: HDR accumulation buffers -> rank 0 over xGMI
         with torch.cuda.stream(stream):
@@ -196,9 +209,28 @@ def main():
             dist.gather(send, gathered, dst=0)
     sync_all()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)
-
     counters = ctx.counters()
+
+    # ---- the dominant kernel on its own: the same frames, one fused raytrace+accumulate
+    # launch at a time on `stream`, bracketed by HIP events on that stream.  This is the
+    # per-launch duration rocprofv3 --kernel-trace reports for k_raytrace_sm<true>.
+    iso_steps = max(4, min(16, args.steps))
+    ctx.set_pipelining(False)
+    one_frame(frame)
+    frame += 1
+    ctx.sync()
+    ctx.reset_counters()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    for _ in range(iso_steps):
+        one_frame(frame)
+        frame += 1
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / iso_steps
+    iso_counters = ctx.counters()
+    ctx.set_pipelining(True)
+
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     c = torch.tensor([counters[k] for k in capi.COUNTER_NAMES], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -210,8 +242,9 @@ def main():
     if rank == 0:
         rays = total["rays"]
         steps = max(args.steps, 1)
-        per_launch_bytes = algorithmic_bytes(counters) / steps       # this rank's kernel
+        per_launch_bytes = algorithmic_bytes(iso_counters) / iso_steps       # this rank's kernel
         achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        effective = algorithmic_bytes(counters) / steps / (elapsed / steps) / 1e9
         out = {
             "metric": "Mrays/s", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -222,14 +255,19 @@ def main():
                        + f", {width}x{height}, 8 bounces, 1 spp per step, {args.steps} steps",
                        "triangles": int(len(sc.triangles)), "bvh_nodes": int(len(sc.nodes)),
                        "image": [width, height], "max_bounces": bounces,
-                       "parallelism": f"tile-split x{world} (8-row blocks, round robin), scene replicated, "
-                                      "one RCCL gather at the end" if world > 1 else "single GPU",
-                       "rays_per_step": rays // steps, "kernel": "k_raytrace<fused accumulate, packet walk>"},
+                       "parallelism": (f"tile-split x{world} (8-row blocks, round robin), scene replicated, "
+                                       "one RCCL gather at the end") if world > 1 else "single GPU",
+                       "rays_per_step": rays // steps,
+                       "frame_pipelining": "raytrace kernels of consecutive frames overlap on two streams; "
+                                           "accumulate stays ordered on the main stream"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel_ms": round(kernel_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
+                         "kernel": "k_raytrace_sm<true> (fused raytrace+accumulate), one launch at a time",
+                         "kernel_ms": round(kernel_ms, 4), "launches_timed": iso_steps,
                          "algorithmic_bytes_per_launch": int(per_launch_bytes),
-                         "bytes_per_ray": round(algorithmic_bytes(total) / max(rays, 1), 1)},
+                         "bytes_per_ray": round(algorithmic_bytes(total) / max(rays, 1), 1),
+                         "pipelined_job_GBps": round(effective, 1),
+                         "pipelined_job_frac": round(effective / HBM_PEAK_GBS, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, env, rt_uniforms, width, height)

@@ -191,6 +191,11 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
  * 2 = per-pixel kernel walking node packets, 3 = persistent waves with lane refill
  * (needs child adjacency right == left + 1, which flattenBVH guarantees). */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
+/* Frame pipelining (default on): with RAYTRACE|ACCUMULATE submits the raytrace kernels of
+ * consecutive frames run on two alternating internal streams, so frame f+1 fills the CUs
+ * while the last paths of frame f drain; the running mean stays ordered on the context's
+ * stream and results are bit-identical.  Off: one fused kernel per frame on the stream. */
+int mi3pt_set_pipelining(mi3pt_ctx *ctx, int enabled);
 
 /* ---- component probes on the device (parity tests of the pieces) ----
  * rays: n x 6 floats (origin, direction); out: n x 12 floats

@@ -435,11 +435,15 @@ void orc_raytrace(const orc_scene *sc, const uint8_t *uniforms96, int tex_w, int
     {
         uint64_t cnt[C_COUNT];
         memset(cnt, 0, sizeof cnt);
-#pragma omp for schedule(dynamic, 1)
-        for (int ly = 0; ly < local_rows; ly++) {
+        /* work unit = 64 consecutive pixels of one row, so small shards still feed many threads */
+        const int chunks_x = (tex_w + 63) / 64;
+#pragma omp for schedule(dynamic, 4)
+        for (long long job = 0; job < (long long)local_rows * chunks_x; job++) {
+            int ly = (int)(job / chunks_x);
+            int x0 = (int)(job % chunks_x) * 64;
             int gy = local_to_global_row(ly, rank, nranks, block_rows);
             if ((uint32_t)gy >= rh || gy >= tex_h) continue;
-            for (int gx = 0; gx < tex_w && (uint32_t)gx < rw; gx++) {
+            for (int gx = x0; gx < x0 + 64 && gx < tex_w && (uint32_t)gx < rw; gx++) {
                 float px[4];
                 raytrace_pixel(sc, &un, (uint32_t)gx, (uint32_t)gy, px, cnt);
                 float *o = out + 4 * ((size_t)ly * tex_w + gx);

@@ -233,6 +233,15 @@ extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
     return MI3PT_OK;
 }
 
+extern "C" int mi3pt_set_pipelining(mi3pt_ctx *ctx, int enabled)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->pipeline = enabled != 0;
+    ctx->main_dirty = true;
+    return MI3PT_OK;
+}
+
 extern "C" int mi3pt_set_tile(mi3pt_ctx *ctx, int rank, int nranks, int block_rows)
 {
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");

@@ -29,6 +29,7 @@ SYMBOLS = (
     "mi3pt_set_uniforms", "mi3pt_submit", "mi3pt_sync", "mi3pt_read_texture", "mi3pt_read_canvas_rgba8",
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
+    "mi3pt_set_pipelining",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
 )
@@ -62,6 +63,7 @@ def load_library(path=None):
     lib.mi3pt_set_storage.argtypes = [c_void_p, c_int]
     lib.mi3pt_set_tile.argtypes = [c_void_p, c_int, c_int, c_int]
     lib.mi3pt_set_kernel_variant.argtypes = [c_void_p, c_int]
+    lib.mi3pt_set_pipelining.argtypes = [c_void_p, c_int]
     for name in ("mi3pt_upload_triangles", "mi3pt_upload_materials", "mi3pt_upload_bvh"):
         getattr(lib, name).argtypes = [c_void_p, c_void_p, c_size_t]
     for name in ("mi3pt_upload_environment", "mi3pt_upload_environment_cdf"):
@@ -196,6 +198,9 @@ class Context:
 
     def set_kernel_variant(self, variant):
         self._c(self.lib.mi3pt_set_kernel_variant(self.handle, variant))
+
+    def set_pipelining(self, enabled):
+        self._c(self.lib.mi3pt_set_pipelining(self.handle, int(enabled)))
 
     def set_tile(self, rank, nranks, block_rows=8):
         self._c(self.lib.mi3pt_set_tile(self.handle, rank, nranks, block_rows))
