@@ -202,6 +202,7 @@ def main():
     for _ in range(args.steps):
         one_frame(frame)
         frame += 1
+    ctx.flush()      # launch the frames still queued for batching (no host wait)
     if world > 1:
         # the one exchange of the job: HDR accumulation buffers -> rank 0 over xGMI
         with torch.cuda.stream(stream):

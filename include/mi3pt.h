@@ -162,6 +162,12 @@ int mi3pt_set_uniforms(mi3pt_ctx *ctx, int pass /* mi3pt_pass */, const void *by
  * the two-pass result). ---- */
 int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask);
 int mi3pt_sync(mi3pt_ctx *ctx);   /* queue.onSubmittedWorkDone(), renderer.ts:420 */
+/* RAYTRACE|ACCUMULATE submits may be queued inside the library and launched together (up to
+ * 8 consecutive frames whose uniforms differ only in `frame` run as one kernel + one ordered
+ * accumulate).  Every call that observes or changes device state launches the queue first;
+ * mi3pt_flush does only that, without waiting -- use it before synchronising the stream
+ * yourself (e.g. torch.cuda.synchronize()). */
+int mi3pt_flush(mi3pt_ctx *ctx);
 
 /* ---- read-back (the capability a headless drop-in needs; the reference only has
  * canvas.toDataURL, main.ts:351-356).  Blocking.  dst holds rows x width x 4 floats

@@ -255,6 +255,43 @@ def test_accumulation_over_frames(gpu_ctx, orc, demo, env, storage, fused):
     ctx.set_storage(capi.STORAGE_F32)
 
 
+def test_deferred_batching_matches_frame_by_frame(gpu_ctx, orc, demo, env):
+    """RAYTRACE|ACCUMULATE submits are queued and run as batches of up to 8 consecutive frames
+    (one kernel over (frame, tile) jobs + one ordered multi-frame accumulate).  11 frames with
+    a camera change in the middle (which splits a batch) must equal the same frames submitted
+    with pipelining off (one fused kernel per frame), bit for bit, and the oracle for the
+    first frames."""
+    w, h = 80, 48
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.set_storage(capi.STORAGE_F32)
+
+    def run(pipelined):
+        ctx.set_pipelining(pipelined)
+        ctx.resize(w, h)
+        ctx.reset_counters()
+        for i, frame in enumerate(range(2, 13)):
+            u = pc.rt_uniforms(demo, w, h, frame=frame, bounces=4, aperture=0.0 if i < 6 else 0.03, focal=4.1)
+            pc.gpu_frame(ctx, u, pc.acc_uniforms(w, h, frame), capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+        return ctx.read_texture(capi.TEX_ACCUMULATION), ctx.counters()
+
+    batched, cb = run(True)
+    single, cs = run(False)
+    ctx.set_pipelining(True)
+    assert pc.same_bits(batched, single), pc.describe_diff(batched, single)
+    for k in ("rays", "box_tests", "tri_tests", "hits", "misses", "pixels"):
+        assert cb[k] == cs[k]
+    assert cb["pixels"] == 11 * w * h
+    osc = pc.oracle_scene(orc, demo, env)
+    acc = np.zeros((h, w, 4), np.float32)
+    for i, frame in enumerate(range(2, 13)):
+        u = pc.rt_uniforms(demo, w, h, frame=frame, bounces=4, aperture=0.0 if i < 6 else 0.03, focal=4.1)
+        img, _ = orc.raytrace(osc, u.tobytes(), w, h)
+        acc = orc.accumulate(pc.acc_uniforms(w, h, frame).tobytes(), w, h, img, acc)
+    assert pc.same_bits(batched, acc), pc.describe_diff(batched, acc)
+
+
 def test_accumulate_disabled_passes_frame_through(gpu_ctx, orc, demo, env):
     w = h = 32
     ctx = gpu_ctx

@@ -80,6 +80,14 @@ struct mi3pt_ctx {
     bool main_dirty = true;              // main-stream work the next raytrace kernel must wait for
     uint64_t seq = 0;
 
+    // Deferred batching: RAYTRACE|ACCUMULATE frames are queued and up to batch_max consecutive
+    // frames (identical uniforms except `frame`) run as ONE raytrace launch + one ordered
+    // multi-frame accumulate, so the persistent kernel's drain tail is paid once per batch.
+    // Anything that observes or changes device state flushes the queue first.
+    struct PendingFrame { uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE]; uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE]; };
+    std::vector<PendingFrame> pending;
+    int batch_max = 8;                   // MI3PT_BATCH (1 = no batching)
+
     bool timing = false;
     hipEvent_t ev[3][2] = {};
     bool ev_recorded[3] = { false, false, false };
@@ -96,6 +104,8 @@ static int require_ctx(mi3pt_ctx *ctx)
     if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     return MI3PT_OK;
 }
+
+static int require_idle(mi3pt_ctx *ctx);      // require_ctx + flush of the deferred frame queue (below)
 
 extern "C" int mi3pt_abi_version(void) { return MI3PT_ABI_VERSION; }
 extern "C" const char *mi3pt_last_error(void) { return g_last_error.c_str(); }
@@ -146,6 +156,9 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     }
     (void)hipEventCreateWithFlags(&ctx->main_mark, hipEventDisableTiming);
     if (const char *e = std::getenv("MI3PT_WALK_MIN")) ctx->walk_min = std::atoi(e);
+    if (const char *e = std::getenv("MI3PT_BATCH")) ctx->batch_max = std::atoi(e);
+    if (ctx->batch_max < 1) ctx->batch_max = 1;
+    if (ctx->batch_max > 16) ctx->batch_max = 16;
     if (const char *e = std::getenv("MI3PT_WAVES_PER_CU")) ctx->waves_per_cu = std::atoi(e);
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
@@ -208,7 +221,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
 
 extern "C" int mi3pt_set_stream(mi3pt_ctx *ctx, void *hip_stream)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     ctx->main_dirty = true;
@@ -221,6 +234,7 @@ extern "C" int mi3pt_set_storage(mi3pt_ctx *ctx, int storage)
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     if (storage != MI3PT_STORAGE_F32 && storage != MI3PT_STORAGE_F16)
         return pt_set_error(MI3PT_ERR_INVALID, "storage must be MI3PT_STORAGE_F32 or MI3PT_STORAGE_F16");
+    if (int rc = require_idle(ctx)) return rc;
     ctx->storage = storage;
     return MI3PT_OK;
 }
@@ -229,13 +243,14 @@ extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     if (variant < 0 || variant > 5) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..5");
+    if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
     return MI3PT_OK;
 }
 
 extern "C" int mi3pt_set_pipelining(mi3pt_ctx *ctx, int enabled)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->pipeline = enabled != 0;
     ctx->main_dirty = true;
@@ -271,7 +286,7 @@ static int replace_buffer(mi3pt_ctx *ctx, void **dst, const void *bytes, size_t 
 
 extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (!bytes || nbytes == 0 || nbytes % MI3PT_TRIANGLE_STRIDE)
         return pt_set_error(MI3PT_ERR_INVALID, "triangle bytes must be a non-zero multiple of 112");
     const size_t n = nbytes / MI3PT_TRIANGLE_STRIDE;
@@ -299,7 +314,7 @@ extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t 
 
 extern "C" int mi3pt_upload_materials(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (!bytes || nbytes == 0 || nbytes % MI3PT_MATERIAL_STRIDE)
         return pt_set_error(MI3PT_ERR_INVALID, "material bytes must be a non-zero multiple of 64");
     if (int rc = replace_buffer(ctx, &ctx->d_mats, bytes, nbytes)) return rc;
@@ -309,7 +324,7 @@ extern "C" int mi3pt_upload_materials(mi3pt_ctx *ctx, const void *bytes, size_t 
 
 extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (!bytes || nbytes == 0 || nbytes % MI3PT_BVHNODE_STRIDE)
         return pt_set_error(MI3PT_ERR_INVALID, "BVH bytes must be a non-zero multiple of 48");
     const size_t n = nbytes / MI3PT_BVHNODE_STRIDE;
@@ -388,7 +403,7 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
 
 static int upload_env_like(mi3pt_ctx *ctx, void *dst, const float *rgba, int width, int height)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (!rgba) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (width != MI3PT_ENV_WIDTH || height != MI3PT_ENV_HEIGHT)   // renderer.ts:133-137
         return pt_set_error(MI3PT_ERR_INVALID,
@@ -424,8 +439,8 @@ static int zero_textures(mi3pt_ctx *ctx)
     const size_t tex_bytes = (size_t)ctx->local_rows * ctx->width * 16;
     const size_t canvas_px = (size_t)ctx->width * ctx->height;
     if (tex_bytes) {
-        HIP_TRY(hipMemsetAsync(ctx->d_radiance, 0, tex_bytes, ctx->stream));
-        HIP_TRY(hipMemsetAsync(ctx->d_radiance_alt, 0, tex_bytes, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_radiance, 0, tex_bytes * ctx->batch_max, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_radiance_alt, 0, tex_bytes * ctx->batch_max, ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_accum, 0, tex_bytes, ctx->stream));
     }
     if (canvas_px) {
@@ -440,7 +455,7 @@ static int zero_textures(mi3pt_ctx *ctx)
 
 extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
         return pt_set_error(MI3PT_ERR_INVALID, "width/height must be in [1, 32768]");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -450,8 +465,8 @@ extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
     ctx->local_rows = mi3pt_tile_local_rows(height, ctx->rank, ctx->nranks, ctx->block_rows);
     const size_t tex_bytes = (size_t)ctx->local_rows * width * 16;
     const size_t canvas_px = (size_t)width * height;
-    HIP_TRY(hipMalloc((void **)&ctx->d_radiance, tex_bytes ? tex_bytes : 16));
-    HIP_TRY(hipMalloc((void **)&ctx->d_radiance_alt, tex_bytes ? tex_bytes : 16));
+    HIP_TRY(hipMalloc((void **)&ctx->d_radiance, tex_bytes ? tex_bytes * ctx->batch_max : 16));
+    HIP_TRY(hipMalloc((void **)&ctx->d_radiance_alt, tex_bytes ? tex_bytes * ctx->batch_max : 16));
     HIP_TRY(hipMalloc((void **)&ctx->d_accum_own, tex_bytes ? tex_bytes : 16));
     ctx->d_accum = ctx->d_accum_own;
     HIP_TRY(hipMalloc((void **)&ctx->d_canvas, canvas_px * 16));
@@ -466,7 +481,7 @@ extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
 
 extern "C" int mi3pt_reset(mi3pt_ctx *ctx)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "reset before resize");
     return zero_textures(ctx);
 }
@@ -535,6 +550,97 @@ static pt::AccUniforms acc_uniforms(const mi3pt_ctx *ctx)
     return a;
 }
 
+static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const pt::AccUniforms &acc)
+{
+    pt::RtLaunch L;
+    L.scene = scene_refs(ctx);
+    L.un.res_x = ldf(u, 0); L.un.res_y = ldf(u, 4); L.un.aspect = ldf(u, 8);
+    L.un.frame = ldu(u, 12);
+    L.un.max_bounces = ldi(u, 16); L.un.samples_per_frame = ldi(u, 20);
+    for (int k = 0; k < 3; k++) { L.un.cam_pos[k] = ldf(u, 32 + 4 * k); L.un.cam_dir[k] = ldf(u, 48 + 4 * k); }
+    L.un.fov = ldf(u, 60); L.un.focal_distance = ldf(u, 64); L.un.aperture = ldf(u, 68);
+    L.un.env_intensity = ldf(u, 80); L.un.env_rotation = ldf(u, 84);
+    L.acc = acc;
+    L.tile = tile_of(ctx);
+    L.radiance = ctx->d_radiance;
+    L.slot_pixels = (size_t)ctx->local_rows * ctx->width;
+    L.nframes = 1;
+    L.accum = ctx->d_accum;
+    L.block_counters = ctx->d_block_counters;
+    L.tile_counter = ctx->d_tile_counter;
+    L.wave_times = ctx->d_wave_times;
+    L.stack_overflow = ctx->d_stack_overflow;
+    L.store_f16 = ctx->storage == MI3PT_STORAGE_F16;
+    L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
+    L.waves_per_cu = ctx->waves_per_cu;
+    return L;
+}
+
+static pt::AccUniforms acc_from(const uint8_t *u)
+{
+    pt::AccUniforms a;
+    a.res_w = ldu(u, 0); a.res_h = ldu(u, 4); a.frame = ldu(u, 8); a.enabled = ldu(u, 12);
+    return a;
+}
+
+// Launches the queued frames: one raytrace kernel over (frame slot, tile) jobs on this
+// parity's side stream, then the ordered multi-frame running mean on the main stream.
+static int flush_pending(mi3pt_ctx *ctx)
+{
+    if (ctx->pending.empty()) return MI3PT_OK;
+    const int n = (int)ctx->pending.size();
+    const mi3pt_ctx::PendingFrame first = ctx->pending.front();
+    ctx->pending.clear();
+    const pt::AccUniforms acc = acc_from(first.u_acc);
+    pt::RtLaunch L = build_launch(ctx, first.u_rt, acc);
+    const bool f16 = ctx->storage == MI3PT_STORAGE_F16;
+    const int par = (int)(ctx->seq++ & 1u);
+    hipStream_t rs = ctx->rt_stream[par];
+    if (ctx->main_dirty) {      // resets / rebinds queued on the main stream come first
+        HIP_TRY(hipEventRecord(ctx->main_mark, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->rt_stream[0], ctx->main_mark, 0));
+        HIP_TRY(hipStreamWaitEvent(ctx->rt_stream[1], ctx->main_mark, 0));
+        ctx->main_dirty = false;
+    }
+    // the accumulate of two batches ago must have consumed this parity's radiance slots
+    if (ctx->acc_done_valid[par]) HIP_TRY(hipStreamWaitEvent(rs, ctx->acc_done[par], 0));
+    L.radiance = par ? ctx->d_radiance_alt : ctx->d_radiance;
+    L.nframes = n;
+    L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
+    L.tile_counter = ctx->d_tile_counter + par * 32;
+    L.stack_overflow = ctx->d_stack_overflow + (size_t)par * 4096 * 32 * 64;
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0][0], rs));
+    pt::launch_raytrace(L, false, pick_variant(ctx), rs);
+    HIP_TRY(hipGetLastError());
+    if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[0][1], rs)); ctx->ev_recorded[0] = true; }
+    HIP_TRY(hipEventRecord(ctx->rt_done[par], rs));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->rt_done[par], 0));
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1][0], ctx->stream));
+    pt::launch_accumulate_batch(acc, L.tile, L.radiance, L.slot_pixels, n, ctx->d_accum, f16, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[1][1], ctx->stream)); ctx->ev_recorded[1] = true; }
+    HIP_TRY(hipEventRecord(ctx->acc_done[par], ctx->stream));
+    ctx->acc_done_valid[par] = true;
+    ctx->last_radiance = L.radiance + (size_t)(n - 1) * L.slot_pixels;
+    ctx->output_is_accum = true;
+    return MI3PT_OK;
+}
+
+// Every entry point that observes or changes device state goes through this.
+static int require_idle(mi3pt_ctx *ctx)
+{
+    if (int rc = require_ctx(ctx)) return rc;
+    return flush_pending(ctx);
+}
+
+// Can `next` join the queued frames?  Same uniforms, consecutive frame numbers.
+static bool batch_compatible(const mi3pt_ctx::PendingFrame &last, const mi3pt_ctx::PendingFrame &next)
+{
+    if (std::memcmp(last.u_rt, next.u_rt, 12) || std::memcmp(last.u_rt + 16, next.u_rt + 16, 80)) return false;
+    if (std::memcmp(last.u_acc, next.u_acc, 8) || std::memcmp(last.u_acc + 12, next.u_acc + 12, 4)) return false;
+    return ldu(next.u_rt, 12) == ldu(last.u_rt, 12) + 1u && ldu(next.u_acc, 8) == ldu(last.u_acc, 8) + 1u;
+}
+
 extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
 {
     if (int rc = require_ctx(ctx)) return rc;
@@ -545,79 +651,43 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
     const bool do_fs = pass_mask & MI3PT_SUBMIT_FULLSCREEN;
     const pt::Tile tile = tile_of(ctx);
     const pt::AccUniforms acc = acc_uniforms(ctx);
-    bool fused = false;
-    for (bool &r : ctx->ev_recorded) r = false;
     const bool f16 = ctx->storage == MI3PT_STORAGE_F16;
+    const int variant = pick_variant(ctx);
+    const bool same_region = acc.res_w == (uint32_t)ldf(ctx->u_rt, 0) && acc.res_h == (uint32_t)ldf(ctx->u_rt, 4);
+    bool acc_done = false;
 
-    if (do_rt) {
+    if (do_rt && do_acc && same_region && ctx->pipeline && variant >= 4) {
+        // queued: runs with its neighbours as one batch (see flush_pending)
         if (int rc = check_scene(ctx)) return rc;
-        pt::RtLaunch L;
-        L.scene = scene_refs(ctx);
-        const uint8_t *u = ctx->u_rt;
-        L.un.res_x = ldf(u, 0); L.un.res_y = ldf(u, 4); L.un.aspect = ldf(u, 8);
-        L.un.frame = ldu(u, 12);
-        L.un.max_bounces = ldi(u, 16); L.un.samples_per_frame = ldi(u, 20);
-        for (int k = 0; k < 3; k++) { L.un.cam_pos[k] = ldf(u, 32 + 4 * k); L.un.cam_dir[k] = ldf(u, 48 + 4 * k); }
-        L.un.fov = ldf(u, 60); L.un.focal_distance = ldf(u, 64); L.un.aperture = ldf(u, 68);
-        L.un.env_intensity = ldf(u, 80); L.un.env_rotation = ldf(u, 84);
-        L.acc = acc;
-        L.tile = tile;
-        L.radiance = ctx->d_radiance;
-        L.accum = ctx->d_accum;
-        L.block_counters = ctx->d_block_counters;
-        L.tile_counter = ctx->d_tile_counter;
-        L.wave_times = ctx->d_wave_times;
-        L.stack_overflow = ctx->d_stack_overflow;
-        L.store_f16 = f16;
-        L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
-        L.waves_per_cu = ctx->waves_per_cu;
-        const bool same_region = acc.res_w == (uint32_t)L.un.res_x && acc.res_h == (uint32_t)L.un.res_y;
-        const int variant = pick_variant(ctx);
-        if (do_acc && same_region && ctx->pipeline && variant >= 3) {
-            // Pipelined frame: raytrace on a side stream into this parity's radiance image,
-            // ordered accumulate on the main stream.
-            const int par = (int)(ctx->seq++ & 1u);
-            hipStream_t rs = ctx->rt_stream[par];
-            if (ctx->main_dirty) {      // resets / rebinds queued on the main stream come first
-                HIP_TRY(hipEventRecord(ctx->main_mark, ctx->stream));
-                HIP_TRY(hipStreamWaitEvent(ctx->rt_stream[0], ctx->main_mark, 0));
-                HIP_TRY(hipStreamWaitEvent(ctx->rt_stream[1], ctx->main_mark, 0));
-                ctx->main_dirty = false;
-            }
-            // accumulate(f-2) must have consumed this radiance image
-            if (ctx->acc_done_valid[par]) HIP_TRY(hipStreamWaitEvent(rs, ctx->acc_done[par], 0));
-            L.radiance = par ? ctx->d_radiance_alt : ctx->d_radiance;
-            L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
-            L.tile_counter = ctx->d_tile_counter + par * 32;
-            L.stack_overflow = ctx->d_stack_overflow + (size_t)par * 4096 * 32 * 64;
-            if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0][0], rs));
-            pt::launch_raytrace(L, false, variant, rs);
-            HIP_TRY(hipGetLastError());
-            if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[0][1], rs)); ctx->ev_recorded[0] = true; }
-            HIP_TRY(hipEventRecord(ctx->rt_done[par], rs));
-            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->rt_done[par], 0));
-            if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1][0], ctx->stream));
-            pt::launch_accumulate(acc, tile, L.radiance, ctx->d_accum, f16, ctx->stream);
-            HIP_TRY(hipGetLastError());
-            if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[1][1], ctx->stream)); ctx->ev_recorded[1] = true; }
-            HIP_TRY(hipEventRecord(ctx->acc_done[par], ctx->stream));
-            ctx->acc_done_valid[par] = true;
-            ctx->last_radiance = L.radiance;
-            ctx->output_is_accum = true;
-            fused = true;               // the accumulate pass has been taken care of
-        } else {
+        mi3pt_ctx::PendingFrame f;
+        std::memcpy(f.u_rt, ctx->u_rt, sizeof f.u_rt);
+        std::memcpy(f.u_acc, ctx->u_acc, sizeof f.u_acc);
+        if (!ctx->pending.empty() && !batch_compatible(ctx->pending.back(), f))
+            if (int rc = flush_pending(ctx)) return rc;
+        if (ctx->pending.empty()) for (bool &r : ctx->ev_recorded) r = false;
+        ctx->pending.push_back(f);
+        if ((int)ctx->pending.size() >= ctx->batch_max || do_fs || ctx->timing)
+            if (int rc = flush_pending(ctx)) return rc;
+        acc_done = true;
+    } else {
+        if (int rc = flush_pending(ctx)) return rc;
+        for (bool &r : ctx->ev_recorded) r = false;
+        if (do_rt) {
+            if (int rc = check_scene(ctx)) return rc;
+            const pt::RtLaunch L = build_launch(ctx, ctx->u_rt, acc);
             // Fuse when the accumulate pass covers exactly the pixels the raytrace pass writes.
-            fused = do_acc && same_region;
+            const bool fused = do_acc && same_region;
             if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0][0], ctx->stream));
             pt::launch_raytrace(L, fused, variant, ctx->stream);
             HIP_TRY(hipGetLastError());
             if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[0][1], ctx->stream)); ctx->ev_recorded[0] = true; }
             ctx->last_radiance = ctx->d_radiance;
             ctx->output_is_accum = fused;
-            ctx->main_dirty = true;     // a later pipelined frame must not overtake this kernel
+            ctx->main_dirty = true;     // a later batch must not overtake this kernel
+            acc_done = fused;
         }
     }
-    if (do_acc && !fused) {
+    if (do_acc && !acc_done) {
         if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1][0], ctx->stream));
         pt::launch_accumulate(acc, tile, ctx->last_radiance, ctx->d_accum, f16, ctx->stream);
         HIP_TRY(hipGetLastError());
@@ -642,16 +712,18 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
     return MI3PT_OK;
 }
 
+extern "C" int mi3pt_flush(mi3pt_ctx *ctx) { return require_idle(ctx); }
+
 extern "C" int mi3pt_sync(mi3pt_ctx *ctx)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MI3PT_OK;
 }
 
 extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t nfloats)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (!dst) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "read before resize");
     const float4 *src;
@@ -681,7 +753,7 @@ extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t 
 
 extern "C" int mi3pt_read_canvas_rgba8(mi3pt_ctx *ctx, uint8_t *dst, size_t nbytes)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (!dst) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "read before resize");
     const size_t need = (size_t)ctx->width * ctx->height * 4;
@@ -695,6 +767,7 @@ extern "C" int mi3pt_accumulation_device_ptr(mi3pt_ctx *ctx, void **dev_ptr, siz
 {
     if (!ctx || !dev_ptr) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "no textures before resize");
+    if (int rc = require_idle(ctx)) return rc;
     *dev_ptr = ctx->d_accum;
     if (nbytes) *nbytes = (size_t)ctx->local_rows * ctx->width * 16;
     return MI3PT_OK;
@@ -702,7 +775,7 @@ extern "C" int mi3pt_accumulation_device_ptr(mi3pt_ctx *ctx, void **dev_ptr, siz
 
 extern "C" int mi3pt_bind_accumulation(mi3pt_ctx *ctx, void *dev_ptr, size_t nbytes)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "bind before resize");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->main_dirty = true;
@@ -720,14 +793,14 @@ extern "C" int mi3pt_bind_accumulation(mi3pt_ctx *ctx, void *dev_ptr, size_t nby
 
 extern "C" int mi3pt_enable_timing(mi3pt_ctx *ctx, int enabled)
 {
-    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    if (int rc = require_idle(ctx)) return rc;
     ctx->timing = enabled != 0;
     return MI3PT_OK;
 }
 
 extern "C" int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (!microseconds || pass < 0 || pass > 2) return pt_set_error(MI3PT_ERR_INVALID, "bad argument");
     if (!ctx->ev_recorded[pass]) return pt_set_error(MI3PT_ERR_STATE, "pass was not timed in the last submit");
     HIP_TRY(hipEventSynchronize(ctx->ev[pass][1]));
@@ -739,7 +812,7 @@ extern "C" int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds)
 
 extern "C" int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT])
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (!out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     for (int k = 0; k < MI3PT_CNT_COUNT; k++) out[k] = 0;
     if (ctx->nblocks == 0) return MI3PT_OK;
@@ -753,7 +826,7 @@ extern "C" int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT])
 
 extern "C" int mi3pt_reset_counters(mi3pt_ctx *ctx)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (ctx->nblocks == 0) return MI3PT_OK;
     HIP_TRY(hipMemsetAsync(ctx->d_block_counters, 0, 2 * (size_t)ctx->nblocks * pt::CNT_COUNT * 8, ctx->stream));
     ctx->main_dirty = true;
@@ -765,7 +838,7 @@ extern "C" int mi3pt_reset_counters(mi3pt_ctx *ctx)
 extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out, size_t capacity_slots,
                                       size_t *slots_out)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     const int slots = 256 * 10;
     if (!out) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -790,7 +863,7 @@ extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out,
 
 extern "C" int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n, float *out)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (!rays || !out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (int rc = check_scene(ctx)) return rc;
     if (n == 0) return MI3PT_OK;
@@ -815,7 +888,7 @@ extern "C" int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n
 
 extern "C" int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n)
 {
-    if (int rc = require_ctx(ctx)) return rc;
+    if (int rc = require_idle(ctx)) return rc;
     if (!a || !out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (n == 0) return MI3PT_OK;
     float *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;

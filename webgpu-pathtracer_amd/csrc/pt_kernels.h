@@ -80,7 +80,9 @@ struct RtLaunch {
     RtUniforms un;
     AccUniforms acc;
     Tile tile;
-    float4 *radiance;            // per-frame output (unfused) -- may be null when fused
+    float4 *radiance;            // per-frame output (unfused): nframes slots of slot_pixels texels
+    size_t slot_pixels;          // texels per radiance slot
+    int32_t nframes;             // frames covered by this launch (frame, frame+1, ...); fused launches: 1
     float4 *accum;               // running mean
     uint64_t *block_counters;    // [gridDim.x][CNT_COUNT]
     uint32_t *tile_counter;      // work queue head of the persistent kernel (zeroed per launch)
@@ -92,6 +94,8 @@ struct RtLaunch {
 };
 
 void launch_raytrace(const RtLaunch &L, bool fuse_accumulate, int variant, hipStream_t s);
+void launch_accumulate_batch(const AccUniforms &acc0, const Tile &tile, const float4 *slots, size_t slot_pixels,
+                             int nframes, float4 *accum, int store_f16, hipStream_t s);
 void launch_accumulate(const AccUniforms &acc, const Tile &tile, const float4 *input, float4 *accum,
                        int store_f16, hipStream_t s);
 void launch_fullscreen(const FsUniforms &fs, const float4 *tex, int tex_w, int tex_h,

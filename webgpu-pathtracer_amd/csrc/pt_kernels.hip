@@ -640,7 +640,7 @@ PT_DEV int lane_rank(unsigned long long mask)
 }
 
 template <bool FUSE>
-PT_DEV void write_pixel(const RtLaunch &L, uint32_t gx, uint32_t gy, uint32_t ly, f3 color)
+PT_DEV void write_pixel(const RtLaunch &L, uint32_t gx, uint32_t gy, uint32_t ly, f3 color, uint32_t slot = 0u)
 {
     const size_t idx = (size_t)ly * L.tile.tex_w + gx;
     color.x = store_round(color.x, L.store_f16);
@@ -654,7 +654,7 @@ PT_DEV void write_pixel(const RtLaunch &L, uint32_t gx, uint32_t gy, uint32_t ly
                                        store_round(nc.z, L.store_f16), 1.0f);
         }
     } else {
-        L.radiance[idx] = make_float4(color.x, color.y, color.z, 1.0f);
+        L.radiance[(size_t)slot * L.slot_pixels + idx] = make_float4(color.x, color.y, color.z, 1.0f);
     }
 }
 
@@ -861,7 +861,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     const SceneRefs &sc = L.scene;
     const RtUniforms &un = L.un;
     const int tiles_x = (L.tile.tex_w + 7) >> 3;
-    const int ntiles = tiles_x * ((L.tile.local_rows + 7) >> 3);
+    // A launch covers L.nframes consecutive frames: job = (frame slot, 8x8 tile), frame-major.
+    const int ntiles_frame = tiles_x * ((L.tile.local_rows + 7) >> 3);
+    const int ntiles = ntiles_frame * L.nframes;
     const uint32_t res_w = (uint32_t)un.res_x, res_h = (uint32_t)un.res_y;
 
     const CameraFrame cf = camera_frame(un);
@@ -879,7 +881,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
     int mode = M_DEAD;
     f3 o = F3(0.0f, 0.0f, 0.0f), d = o, ray_color = o, light = o, incoming = o;
-    uint32_t gx = 0u, gy = 0u, ly = 0u, seed = 0u;
+    uint32_t gx = 0u, gy = 0u, ly = 0u, seed = 0u, slot = 0u;
     int32_t bounce = 0, sample = 0;
     int sp = 0;
     Best best;
@@ -979,7 +981,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (sample >= un.samples_per_frame) {
                     // pixel finished (:455, :477): the slot is free for the refill below
                     const float n = (float)un.samples_per_frame;
-                    write_pixel<FUSE>(L, gx, gy, ly, F3(incoming.x / n, incoming.y / n, incoming.z / n));
+                    write_pixel<FUSE>(L, gx, gy, ly, F3(incoming.x / n, incoming.y / n, incoming.z / n), slot);
                 } else {
                     need_path = true;
                 }
@@ -1006,15 +1008,17 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 const bool mine = ((dead >> lane) & 1ull) != 0ull && rank < take;
                 if (mine) {
                     const int j = cur_used + rank;
-                    const int px = (cur_tile % tiles_x) * 8 + (j & 7);
-                    const int ply = (cur_tile / tiles_x) * 8 + (j >> 3);
+                    const int fslot = cur_tile / ntiles_frame, ftile = cur_tile - fslot * ntiles_frame;
+                    const int px = (ftile % tiles_x) * 8 + (j & 7);
+                    const int ply = (ftile / tiles_x) * 8 + (j >> 3);
                     const int pgy = local_to_global_row(ply, L.tile);
                     const bool ok = px < L.tile.tex_w && ply < L.tile.local_rows && pgy < L.tile.tex_h &&
                                     (uint32_t)px < res_w && (uint32_t)pgy < res_h;     // :425-427
                     if (ok) {
                         gx = (uint32_t)px; gy = (uint32_t)pgy; ly = (uint32_t)ply;
                         cnt.pixels++;
-                        seed = (gx + gy * res_w) + un.frame * 719393u + PT_SEED;    // :435-436
+                        slot = (uint32_t)fslot;
+                        seed = (gx + gy * res_w) + (un.frame + slot) * 719393u + PT_SEED;    // :435-436
                         sample = 0;
                         incoming = F3(0.0f, 0.0f, 0.0f);
                         need_path = true;
@@ -1030,7 +1034,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             for (;;) {
                 if (sample >= un.samples_per_frame) {
                     const float n = (float)un.samples_per_frame;
-                    write_pixel<FUSE>(L, gx, gy, ly, F3(incoming.x / n, incoming.y / n, incoming.z / n));
+                    write_pixel<FUSE>(L, gx, gy, ly, F3(incoming.x / n, incoming.y / n, incoming.z / n), slot);
                     break;
                 }
                 const float uvx = (float)gx / un.res_x, uvy = (float)gy / un.res_y;
@@ -1148,6 +1152,41 @@ __global__ void __launch_bounds__(256) k_accumulate(const AccUniforms acc, const
         accum[i] = make_float4(store_round(nc.x, store_f16), store_round(nc.y, store_f16),
                                store_round(nc.z, store_f16), 1.0f);
     }
+}
+
+// The running mean over `nframes` consecutive frames' radiance slots, applied per pixel in
+// frame order (frame, frame+1, ...) -- the same sequence of accumulate.wgsl passes, with the
+// accumulator read and written once.
+__global__ void __launch_bounds__(256) k_accumulate_batch(const AccUniforms acc0, const Tile tile,
+                                                          const float4 *__restrict__ slots, size_t slot_pixels,
+                                                          int nframes, float4 *__restrict__ accum, int store_f16)
+{
+    const size_t n = (size_t)tile.local_rows * tile.tex_w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ly = (int)(i / tile.tex_w);
+        const int gx = (int)(i - (size_t)ly * tile.tex_w);
+        const int gy = local_to_global_row(ly, tile);
+        if ((uint32_t)gx >= acc0.res_w || (uint32_t)gy >= acc0.res_h) continue;
+        f3 p = xyz(accum[i]);
+        for (int k = 0; k < nframes; k++) {
+            AccUniforms a = acc0;
+            a.frame = acc0.frame + (uint32_t)k;
+            const f3 nc = accumulate_texel(a, xyz(slots[(size_t)k * slot_pixels + i]), p);
+            p = F3(store_round(nc.x, store_f16), store_round(nc.y, store_f16), store_round(nc.z, store_f16));
+        }
+        accum[i] = make_float4(p.x, p.y, p.z, 1.0f);
+    }
+}
+
+void launch_accumulate_batch(const AccUniforms &acc0, const Tile &tile, const float4 *slots, size_t slot_pixels,
+                             int nframes, float4 *accum, int store_f16, hipStream_t s)
+{
+    const size_t n = (size_t)tile.local_rows * tile.tex_w;
+    if (n == 0 || nframes <= 0) return;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_accumulate_batch, dim3(blocks), dim3(256), 0, s, acc0, tile, slots, slot_pixels, nframes,
+                       accum, store_f16);
 }
 
 void launch_accumulate(const AccUniforms &acc, const Tile &tile, const float4 *input, float4 *accum,

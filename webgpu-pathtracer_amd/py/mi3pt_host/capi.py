@@ -29,7 +29,7 @@ SYMBOLS = (
     "mi3pt_set_uniforms", "mi3pt_submit", "mi3pt_sync", "mi3pt_read_texture", "mi3pt_read_canvas_rgba8",
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
-    "mi3pt_set_pipelining",
+    "mi3pt_set_pipelining", "mi3pt_flush",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
 )
@@ -73,6 +73,7 @@ def load_library(path=None):
     lib.mi3pt_set_uniforms.argtypes = [c_void_p, c_int, c_void_p, c_size_t]
     lib.mi3pt_submit.argtypes = [c_void_p, ctypes.c_uint]
     lib.mi3pt_sync.argtypes = [c_void_p]
+    lib.mi3pt_flush.argtypes = [c_void_p]
     lib.mi3pt_read_texture.argtypes = [c_void_p, c_int, c_void_p, c_size_t]
     lib.mi3pt_read_canvas_rgba8.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.mi3pt_accumulation_device_ptr.argtypes = [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t)]
@@ -241,6 +242,9 @@ class Context:
 
     def submit(self, mask):
         self._c(self.lib.mi3pt_submit(self.handle, mask))
+
+    def flush(self):
+        self._c(self.lib.mi3pt_flush(self.handle))
 
     def sync(self):
         self._c(self.lib.mi3pt_sync(self.handle))
