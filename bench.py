@@ -3,8 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload demo|dragon]
 
-One STEP = one Renderer.render() frame of the hot path: the fused raytrace+accumulate
-kernel, 1 sample per pixel, over the whole image.  Default workload = BASELINE.json
+One STEP = one Renderer.render() frame of the hot path (raytrace + accumulate passes, 1
+sample per pixel, whole image).  The library queues consecutive frames and launches them in
+batches (bit-identical results); the timed region ends with a flush + device sync.  Default workload = BASELINE.json
 configs[1]: default demo mesh + environment map, 1920x1080, 8 bounces, 64 frames
 (= 64 spp); `--workload dragon` is configs[2] (~870k triangles).
 
@@ -17,8 +18,9 @@ renders 1920x1080 pixels per frame (N=2: 1920x2160, N=4: 3840x2160, N=8: 3840x43
 
 Prints ONE JSON line on rank 0: metric Mrays/s (rays = raySceneIntersect calls, counted
 exactly by the kernel), plus
-  roofline     : algorithmic bytes per launch / average kernel time (HIP events on the
-                 kernel's own stream) against the 8 TB/s HBM peak,
+  roofline     : algorithmic bytes per launch / average launch duration of the dominant
+                 kernel (HIP event pairs on the stream each launch ran on, all launches of
+                 the timed region) against the 8 TB/s HBM peak,
   cpu_baseline : the CPU oracle timed on a bounded sample of the same workload
                  (rank 0, N = 1 only).
 The oracle is only ever the baseline / checker here, never the thing measured as `value`.
@@ -162,6 +164,7 @@ def main():
     ctx = capi.Context(local_rank)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_kernel_variant(args.variant)
+    ctx.enable_timing(True)            # one HIP event pair per batched raytrace launch
     ctx.upload_bvh(sc.nodes)
     ctx.upload_triangles(sc.triangles)
     ctx.upload_materials(sc.material_bytes)
@@ -194,6 +197,7 @@ def main():
         frame += 1
     ctx.sync()
     ctx.reset_counters()
+    ctx.raytrace_launch_stats(reset=True)
 
     # ---- the timed job: K frames (raytrace kernels of consecutive frames overlap on two
     # internal streams; the ordered accumulate runs on `stream`), then the one gather.
@@ -212,25 +216,11 @@ def main():
     elapsed = time.perf_counter() - t0
     counters = ctx.counters()
 
-    # ---- the dominant kernel on its own: the same frames, one fused raytrace+accumulate
-    # launch at a time on `stream`, bracketed by HIP events on that stream.  This is the
-    # per-launch duration rocprofv3 --kernel-trace reports for k_raytrace_sm<true>.
-    iso_steps = max(4, min(16, args.steps))
-    ctx.set_pipelining(False)
-    one_frame(frame)
-    frame += 1
-    ctx.sync()
-    ctx.reset_counters()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(stream)
-    for _ in range(iso_steps):
-        one_frame(frame)
-        frame += 1
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    kernel_ms = ev0.elapsed_time(ev1) / iso_steps
-    iso_counters = ctx.counters()
-    ctx.set_pipelining(True)
+    # ---- the dominant kernel's launches inside the timed region: the library brackets every
+    # batched raytrace launch with a HIP event pair on the stream it runs on; this is the
+    # per-launch duration rocprofv3 --kernel-trace reports for k_raytrace_sm<false>.
+    launch_ms_total, launches, launch_frames = ctx.raytrace_launch_stats()
+    kernel_ms = launch_ms_total / max(launches, 1)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     c = torch.tensor([counters[k] for k in capi.COUNTER_NAMES], dtype=torch.float64, device="cuda")
@@ -243,7 +233,7 @@ def main():
     if rank == 0:
         rays = total["rays"]
         steps = max(args.steps, 1)
-        per_launch_bytes = algorithmic_bytes(iso_counters) / iso_steps       # this rank's kernel
+        per_launch_bytes = algorithmic_bytes(counters) / max(launches, 1)    # this rank's kernel
         achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         effective = algorithmic_bytes(counters) / steps / (elapsed / steps) / 1e9
         out = {
@@ -259,12 +249,15 @@ def main():
                        "parallelism": (f"tile-split x{world} (8-row blocks, round robin), scene replicated, "
                                        "one RCCL gather at the end") if world > 1 else "single GPU",
                        "rays_per_step": rays // steps,
-                       "frame_pipelining": "raytrace kernels of consecutive frames overlap on two streams; "
-                                           "accumulate stays ordered on the main stream"},
+                       "frames_per_launch": round(launch_frames / max(launches, 1), 2),
+                       "scheduling": "consecutive frames are batched into one persistent launch over (frame, tile) "
+                                     "jobs; batches alternate between two streams; one ordered multi-frame "
+                                     "accumulate per batch on the main stream"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_raytrace_sm<true> (fused raytrace+accumulate), one launch at a time",
-                         "kernel_ms": round(kernel_ms, 4), "launches_timed": iso_steps,
+                         "kernel": "k_raytrace_sm<false> (persistent raytrace, batched frames)",
+                         "kernel_ms": round(kernel_ms, 4), "launches_timed": int(launches),
+                         "frames_in_timed_launches": int(launch_frames),
                          "algorithmic_bytes_per_launch": int(per_launch_bytes),
                          "bytes_per_ray": round(algorithmic_bytes(total) / max(rays, 1), 1),
                          "pipelined_job_GBps": round(effective, 1),

@@ -188,6 +188,10 @@ int mi3pt_bind_accumulation(mi3pt_ctx *ctx, void *dev_ptr, size_t nbytes);
  * event pair per pass per submit. ---- */
 int mi3pt_enable_timing(mi3pt_ctx *ctx, int enabled);
 int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds);
+/* With timing enabled: GPU time summed over the batched raytrace launches since the last
+ * reset (HIP event pairs on the stream each kernel ran on), their number, and the frames
+ * they covered.  Waits for the launches in flight. */
+int mi3pt_raytrace_launch_stats(mi3pt_ctx *ctx, int reset, double *total_ms, uint64_t *launches, uint64_t *frames);
 
 /* ---- counters (roofline inputs) ---- */
 int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT]);

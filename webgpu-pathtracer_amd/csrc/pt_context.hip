@@ -86,7 +86,13 @@ struct mi3pt_ctx {
     // Anything that observes or changes device state flushes the queue first.
     struct PendingFrame { uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE]; uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE]; };
     std::vector<PendingFrame> pending;
-    int batch_max = 8;                   // MI3PT_BATCH (1 = no batching)
+    int batch_max = 16;                  // MI3PT_BATCH (1 = no batching)
+    // per-launch GPU time of the batched raytrace kernel (HIP events on its own stream)
+    hipEvent_t ev_rt[2][2] = {};
+    bool ev_rt_pending[2] = { false, false };
+    double rt_total_ms = 0.0, rt_last_ms = 0.0;
+    uint64_t rt_launches = 0, rt_frames = 0;
+    int ev_rt_frames[2] = { 0, 0 };
 
     bool timing = false;
     hipEvent_t ev[3][2] = {};
@@ -142,7 +148,10 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     HIP_TRY(hipSetDevice(device));
     mi3pt_ctx *ctx = new mi3pt_ctx();
     ctx->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    hipError_t e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio_greatest);
+    if (e != hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
         return pt_set_error(MI3PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -150,11 +159,18 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     ctx->stream = ctx->own_stream;
     if (const char *e = std::getenv("MI3PT_PIPELINE")) ctx->pipeline = std::atoi(e) != 0;
     for (int k = 0; k < 2; k++) {
-        (void)hipStreamCreateWithFlags(&ctx->rt_stream[k], hipStreamNonBlocking);
+        // lowest priority: the persistent raytrace waves must never starve the (tiny, ordered)
+        // accumulate kernels on the main stream, which gate the batch after next
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&ctx->rt_stream[k], hipStreamNonBlocking, least) != hipSuccess)
+            (void)hipStreamCreateWithFlags(&ctx->rt_stream[k], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&ctx->rt_done[k], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&ctx->acc_done[k], hipEventDisableTiming);
     }
     (void)hipEventCreateWithFlags(&ctx->main_mark, hipEventDisableTiming);
+    for (int k = 0; k < 2; k++)
+        for (int j = 0; j < 2; j++) (void)hipEventCreate(&ctx->ev_rt[k][j]);
     if (const char *e = std::getenv("MI3PT_WALK_MIN")) ctx->walk_min = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_BATCH")) ctx->batch_max = std::atoi(e);
     if (ctx->batch_max < 1) ctx->batch_max = 1;
@@ -214,6 +230,9 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
         if (ctx->acc_done[k]) (void)hipEventDestroy(ctx->acc_done[k]);
     }
     if (ctx->main_mark) (void)hipEventDestroy(ctx->main_mark);
+    for (int k = 0; k < 2; k++)
+        for (int j = 0; j < 2; j++)
+            if (ctx->ev_rt[k][j]) (void)hipEventDestroy(ctx->ev_rt[k][j]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MI3PT_OK;
@@ -583,6 +602,21 @@ static pt::AccUniforms acc_from(const uint8_t *u)
     return a;
 }
 
+// Folds a finished batch launch's event pair into the launch statistics.
+static int collect_rt_time(mi3pt_ctx *ctx, int par)
+{
+    if (!ctx->ev_rt_pending[par]) return MI3PT_OK;
+    HIP_TRY(hipEventSynchronize(ctx->ev_rt[par][1]));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_rt[par][0], ctx->ev_rt[par][1]));
+    ctx->rt_total_ms += ms;
+    ctx->rt_last_ms = ms;
+    ctx->rt_launches++;
+    ctx->rt_frames += (uint64_t)ctx->ev_rt_frames[par];
+    ctx->ev_rt_pending[par] = false;
+    return MI3PT_OK;
+}
+
 // Launches the queued frames: one raytrace kernel over (frame slot, tile) jobs on this
 // parity's side stream, then the ordered multi-frame running mean on the main stream.
 static int flush_pending(mi3pt_ctx *ctx)
@@ -609,10 +643,17 @@ static int flush_pending(mi3pt_ctx *ctx)
     L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
     L.tile_counter = ctx->d_tile_counter + par * 32;
     L.stack_overflow = ctx->d_stack_overflow + (size_t)par * 4096 * 32 * 64;
-    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0][0], rs));
+    if (ctx->timing) {
+        if (int rc = collect_rt_time(ctx, par)) return rc;      // the launch of two batches ago
+        HIP_TRY(hipEventRecord(ctx->ev_rt[par][0], rs));
+    }
     pt::launch_raytrace(L, false, pick_variant(ctx), rs);
     HIP_TRY(hipGetLastError());
-    if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[0][1], rs)); ctx->ev_recorded[0] = true; }
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev_rt[par][1], rs));
+        ctx->ev_rt_pending[par] = true;
+        ctx->ev_rt_frames[par] = n;
+    }
     HIP_TRY(hipEventRecord(ctx->rt_done[par], rs));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->rt_done[par], 0));
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1][0], ctx->stream));
@@ -666,7 +707,7 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
             if (int rc = flush_pending(ctx)) return rc;
         if (ctx->pending.empty()) for (bool &r : ctx->ev_recorded) r = false;
         ctx->pending.push_back(f);
-        if ((int)ctx->pending.size() >= ctx->batch_max || do_fs || ctx->timing)
+        if ((int)ctx->pending.size() >= ctx->batch_max || do_fs)
             if (int rc = flush_pending(ctx)) return rc;
         acc_done = true;
     } else {
@@ -802,11 +843,32 @@ extern "C" int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds)
 {
     if (int rc = require_idle(ctx)) return rc;
     if (!microseconds || pass < 0 || pass > 2) return pt_set_error(MI3PT_ERR_INVALID, "bad argument");
+    if (pass == MI3PT_PASS_RAYTRACE && !ctx->ev_recorded[0] && (ctx->ev_rt_pending[0] || ctx->ev_rt_pending[1] || ctx->rt_launches)) {
+        // batched launch: the most recent batch's kernel time divided by its frames
+        const uint64_t before = ctx->rt_launches;
+        for (int par = 0; par < 2; par++) if (int rc = collect_rt_time(ctx, par)) return rc;
+        (void)before;
+        const int frames = ctx->ev_rt_frames[(int)((ctx->seq + 1u) & 1u)];
+        *microseconds = (float)(ctx->rt_last_ms * 1000.0 / (frames > 0 ? frames : 1));
+        return MI3PT_OK;
+    }
     if (!ctx->ev_recorded[pass]) return pt_set_error(MI3PT_ERR_STATE, "pass was not timed in the last submit");
     HIP_TRY(hipEventSynchronize(ctx->ev[pass][1]));
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[pass][0], ctx->ev[pass][1]));
     *microseconds = ms * 1000.0f;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_raytrace_launch_stats(mi3pt_ctx *ctx, int reset, double *total_ms, uint64_t *launches,
+                                           uint64_t *frames)
+{
+    if (int rc = require_idle(ctx)) return rc;
+    for (int par = 0; par < 2; par++) if (int rc = collect_rt_time(ctx, par)) return rc;
+    if (total_ms) *total_ms = ctx->rt_total_ms;
+    if (launches) *launches = ctx->rt_launches;
+    if (frames) *frames = ctx->rt_frames;
+    if (reset) { ctx->rt_total_ms = 0.0; ctx->rt_launches = 0; ctx->rt_frames = 0; }
     return MI3PT_OK;
 }
 

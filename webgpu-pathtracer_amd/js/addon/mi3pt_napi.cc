@@ -230,6 +230,7 @@ CTX_INT_FN(SetKernelVariant, mi3pt_set_kernel_variant)
 CTX_INT_FN(EnableTiming, mi3pt_enable_timing)
 CTX_VOID_FN(Reset, mi3pt_reset)
 CTX_VOID_FN(Sync, mi3pt_sync)
+CTX_VOID_FN(Flush, mi3pt_flush)
 CTX_VOID_FN(ResetCounters, mi3pt_reset_counters)
 CTX_BYTES_FN(UploadTriangles, mi3pt_upload_triangles)
 CTX_BYTES_FN(UploadMaterials, mi3pt_upload_materials)
@@ -457,7 +458,7 @@ napi_value Init(napi_env env, napi_value exports)
         { "uploadTriangles", UploadTriangles }, { "uploadMaterials", UploadMaterials }, { "uploadBvh", UploadBvh },
         { "uploadEnvironment", UploadEnvironment }, { "uploadEnvironmentCdf", UploadEnvironmentCdf },
         { "resize", Resize }, { "reset", Reset }, { "setUniforms", SetUniforms }, { "submit", Submit },
-        { "sync", Sync }, { "readTexture", ReadTexture }, { "readCanvasRgba8", ReadCanvasRgba8 },
+        { "sync", Sync }, { "flush", Flush }, { "readTexture", ReadTexture }, { "readCanvasRgba8", ReadCanvasRgba8 },
         { "enableTiming", EnableTiming }, { "passTimeUs", PassTimeUs }, { "getCounters", GetCounters },
         { "resetCounters", ResetCounters }, { "hostBuildBvhF64", HostBuildBvhF64 }, { "hostBuildBvh", HostBuildBvh },
         { "hostEnvCdf", HostEnvCdf },

@@ -28,7 +28,7 @@ SYMBOLS = (
     "mi3pt_upload_environment", "mi3pt_upload_environment_cdf", "mi3pt_resize", "mi3pt_reset",
     "mi3pt_set_uniforms", "mi3pt_submit", "mi3pt_sync", "mi3pt_read_texture", "mi3pt_read_canvas_rgba8",
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
-    "mi3pt_pass_time_us", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
+    "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
     "mi3pt_set_pipelining", "mi3pt_flush",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
@@ -80,6 +80,8 @@ def load_library(path=None):
     lib.mi3pt_bind_accumulation.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.mi3pt_enable_timing.argtypes = [c_void_p, c_int]
     lib.mi3pt_pass_time_us.argtypes = [c_void_p, c_int, ctypes.POINTER(ctypes.c_float)]
+    lib.mi3pt_raytrace_launch_stats.argtypes = [c_void_p, c_int, ctypes.POINTER(ctypes.c_double),
+                                                ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.mi3pt_get_counters.argtypes = [c_void_p, c_void_p]
     lib.mi3pt_reset_counters.argtypes = [c_void_p]
     lib.mi3pt_debug_intersect.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
@@ -275,6 +277,13 @@ class Context:
         v = ctypes.c_float()
         self._c(self.lib.mi3pt_pass_time_us(self.handle, which, ctypes.byref(v)))
         return v.value
+
+    def raytrace_launch_stats(self, reset=False):
+        """(total GPU ms, launches, frames) of the batched raytrace kernel since the last reset."""
+        ms, n, f = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._c(self.lib.mi3pt_raytrace_launch_stats(self.handle, int(reset), ctypes.byref(ms), ctypes.byref(n),
+                                                     ctypes.byref(f)))
+        return ms.value, n.value, f.value
 
     def counters(self):
         out = np.zeros(8, np.uint64)
