@@ -130,10 +130,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # Rehearsal mode (one GPU box): MI3PT_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # uses gloo (host-staged gather) instead of RCCL, to exercise the N > 1 code path.
+    rehearsal = os.environ.get("MI3PT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if rank == 0:
         ge.build()
     if world > 1:
@@ -211,7 +219,12 @@ def main():
         # the one exchange of the job: HDR accumulation buffers -> rank 0 over xGMI
         with torch.cuda.stream(stream):
             send[: ctx.local_rows].copy_(accum)
-            dist.gather(send, gathered, dst=0)
+            if rehearsal:
+                stream.synchronize()
+                host = send.cpu()
+                dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
+            else:
+                dist.gather(send, gathered, dst=0)
     sync_all()
     elapsed = time.perf_counter() - t0
     counters = ctx.counters()
@@ -222,8 +235,9 @@ def main():
     launch_ms_total, launches, launch_frames = ctx.raytrace_launch_stats()
     kernel_ms = launch_ms_total / max(launches, 1)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    c = torch.tensor([counters[k] for k in capi.COUNTER_NAMES], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if rehearsal else "cuda"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    c = torch.tensor([counters[k] for k in capi.COUNTER_NAMES], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)

@@ -184,6 +184,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
         mi3pt_destroy(ctx);
         return pt_set_error(MI3PT_ERR_HIP, "hipMalloc(environment) failed");
     }
+    (void)hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream);     // self-cleaning afterwards
     (void)hipMemsetAsync(ctx->d_env, 0, env_bytes, ctx->stream);
     (void)hipMemsetAsync(ctx->d_cdf, 0, env_bytes, ctx->stream);
     std::memset(ctx->u_rt, 0, sizeof ctx->u_rt);

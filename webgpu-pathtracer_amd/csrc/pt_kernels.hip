@@ -806,6 +806,16 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
         }
     }
 
+    // Self-cleaning work queue: the last wave to leave resets the head and the exit counter, so
+    // launches need no memset in front of them (a memset kernel would have to wait for a free
+    // slot among the previous batch's persistent waves).
+    if (lane == 0) {
+        const uint32_t left = atomicAdd(L.tile_counter + 1, 1u);
+        if (left == gridDim.x - 1u) {
+            __hip_atomic_store(L.tile_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(L.tile_counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     const uint32_t s_rays = wave_sum(cnt.rays), s_box = wave_sum(cnt.box), s_tri = wave_sum(cnt.tri);
     const uint32_t s_hit = wave_sum(cnt.hit), s_miss = wave_sum(cnt.miss);
     const uint32_t s_ovf = wave_sum(cnt.overflow), s_pix = wave_sum(cnt.pixels);
@@ -1080,6 +1090,16 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         w[2] = __builtin_amdgcn_s_memrealtime();
         w[3] = __builtin_amdgcn_s_memtime() - t_begin_clk;
     }
+    // Self-cleaning work queue: the last wave to leave resets the head and the exit counter, so
+    // launches need no memset in front of them (a memset kernel would have to wait for a free
+    // slot among the previous batch's persistent waves).
+    if (lane == 0) {
+        const uint32_t left = atomicAdd(L.tile_counter + 1, 1u);
+        if (left == gridDim.x - 1u) {
+            __hip_atomic_store(L.tile_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(L.tile_counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     const uint32_t s_rays = wave_sum(cnt.rays), s_box = wave_sum(cnt.box), s_tri = wave_sum(cnt.tri);
     const uint32_t s_hit = wave_sum(cnt.hit), s_miss = wave_sum(cnt.miss);
     const uint32_t s_ovf = wave_sum(cnt.overflow), s_pix = wave_sum(cnt.pixels), s_slow = wave_sum(cnt.slow);
@@ -1113,7 +1133,6 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
     const dim3 block(64);
     if (variant >= 3) {
         const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu));
-        (void)hipMemsetAsync(L.tile_counter, 0, sizeof(uint32_t), s);
         if (variant == 3) {
             if (fuse) hipLaunchKernelGGL((k_raytrace_persistent<true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_persistent<false>), grid, block, 0, s, L);
