@@ -174,6 +174,10 @@ int mi3pt_flush(mi3pt_ctx *ctx);
  * (rows = local rows for OUTPUT / ACCUMULATION, canvas height for CANVAS). ---- */
 int mi3pt_read_texture(mi3pt_ctx *ctx, int which /* mi3pt_texture */, float *dst, size_t nfloats);
 int mi3pt_read_canvas_rgba8(mi3pt_ctx *ctx, uint8_t *dst, size_t nbytes);
+/* Host -> device: load a running mean into the accumulation image (which = ACCUMULATION or
+ * OUTPUT; both name the same image after an accumulate pass, accumulate.ts:171-175).  For
+ * checkpoint / resume and for presenting a gathered multi-GPU image from a 1-rank context. */
+int mi3pt_write_texture(mi3pt_ctx *ctx, int which /* mi3pt_texture */, const float *src, size_t nfloats);
 
 /* Device pointer of the accumulation image (local_rows x width x 4 fp32), for
  * zero-copy hand-off to a collective (RCCL gather of the HDR buffer). */

@@ -1,0 +1,145 @@
+"""BASELINE.json configs 3-5 as parity-test cases (configs 1-2 are in test_gpu_parity.py /
+test_golden.py / bench.py).  The oracle is too slow for whole frames of these scenes, so each
+case combines: bit-identity between the per-pixel reference kernel (variant 2) and the shipped
+persistent kernel, oracle-rendered bands of rows, counter identities, and tile-split
+reassembly (the multi-GPU decomposition run rank by rank on the one GPU)."""
+import numpy as np
+import pytest
+
+import ptcommon as pc
+from mi3pt_host import capi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dragon(built):
+    sc = scenes.dragon_class_scene()          # 869,882 triangles
+    sc.build_bvh()
+    return sc
+
+
+@pytest.fixture(scope="module")
+def forest(built):
+    sc = scenes.forest_scene(instances=1500)  # ~1.7 M triangles: config 5's generator, scaled to test time
+    sc.build_bvh()
+    return sc
+
+
+def _render(ctx, sc, w, h, frames, variant=0, **kw):
+    ctx.set_kernel_variant(variant)
+    ctx.reset()
+    ctx.reset_counters()
+    for f in frames:
+        pc.gpu_frame(ctx, pc.rt_uniforms(sc, w, h, frame=f, bounces=8, **kw), pc.acc_uniforms(w, h, f),
+                     capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+    img = ctx.read_texture(capi.TEX_ACCUMULATION)
+    cnt = ctx.counters()
+    ctx.set_kernel_variant(0)
+    return img, cnt
+
+
+def _oracle_band(orc, sc, env, w, h, frames, first_row, rows=8, **kw):
+    """Accumulated oracle image of `rows` rows starting at first_row (a multiple of rows)."""
+    nblocks = (h + rows - 1) // rows
+    rank = first_row // rows
+    osc = pc.oracle_scene(orc, sc, env)
+    acc = np.zeros((rows, w, 4), np.float32)
+    for f in frames:
+        part, _ = orc.raytrace(osc, pc.rt_uniforms(sc, w, h, frame=f, bounces=8, **kw).tobytes(), w, h, rank, nblocks, rows)
+        acc = orc.accumulate(pc.acc_uniforms(w, h, f).tobytes(), w, h, part, acc, rank, nblocks, rows)
+    return acc
+
+
+def test_config3_dragon_class_1080p(gpu_ctx, orc, dragon, env):
+    w, h = 1920, 1080
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, dragon, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    frames = (2, 3, 4)
+    ref, cref = _render(ctx, dragon, w, h, frames, variant=2)
+    got, cgot = _render(ctx, dragon, w, h, frames, variant=0)
+    assert pc.same_bits(got, ref), pc.describe_diff(got, ref)
+    for k in ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels"):
+        assert cgot[k] == cref[k]
+    assert cgot["pixels"] == 3 * w * h and cgot["rays"] == cgot["hits"] + cgot["misses"]
+    assert cgot["stack_overflows"] == 0 and cgot["reserved"] < 0.02 * cgot["rays"]
+    assert np.isfinite(got).all()
+    band = _oracle_band(orc, dragon, env, w, h, frames, first_row=480)
+    assert pc.same_bits(got[480:488], band), pc.describe_diff(got[480:488], band)
+    assert pc.max_rel_err(got[480:488], band) <= 1e-4
+
+
+def test_config4_dragon_dof_denoise_4k_tile_split(gpu_ctx, orc, dragon, env):
+    """Thin-lens DoF (aperture 0.03, focus at the model) at 3840x2160; 4-rank tile split
+    reassembles to the whole image; the de-noise + ACES pass runs on the gathered image."""
+    w, h = 3840, 2160
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, dragon, env)
+    focal = float(np.linalg.norm(np.array(dragon.camera["position"]) - np.array([0.0, 0.5, 0.0])))
+    kw = dict(aperture=0.03, focal=focal)
+    frames = (2, 3)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    whole, cwhole = _render(ctx, dragon, w, h, frames, **kw)
+    f = pc.fs_uniforms(w, h, 1.0, 1, 1)
+    ctx.set_uniforms(capi.PASS_FULLSCREEN, f.tobytes())
+    ctx.submit(capi.SUBMIT_FULLSCREEN)
+    canvas = ctx.read_canvas_rgba8()
+    assert canvas.shape == (h, w, 4) and (canvas[..., 3] == 255).all() and canvas[..., :3].std() > 5
+    out = np.zeros_like(whole)
+    rays = 0
+    for rank in range(4):
+        ctx.set_tile(rank, 4, 8)
+        ctx.resize(w, h)
+        part, c = _render(ctx, dragon, w, h, frames, **kw)
+        rows = [y for y in range(h) if (y // 8) % 4 == rank]
+        out[rows] = part
+        rays += c["rays"]
+    assert pc.same_bits(out, whole), pc.describe_diff(out, whole)
+    assert rays == cwhole["rays"]
+    band = _oracle_band(orc, dragon, env, w, h, frames, first_row=1000, **kw)
+    assert pc.same_bits(whole[1000:1008], band), pc.describe_diff(whole[1000:1008], band)
+    # the de-noise pass against the oracle on a crop (the filter only looks 6 texels around)
+    crop = whole[960:1060, 1800:2000].copy()
+    fc = pc.fs_uniforms(200, 100, 1.0, 1, 1)
+    want, _ = orc.fullscreen(fc.tobytes(), crop)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(200, 100)
+    ctx.write_texture(capi.TEX_ACCUMULATION, crop)      # hand the image to this (1-rank) context
+    ctx.set_uniforms(capi.PASS_FULLSCREEN, fc.tobytes())
+    ctx.submit(capi.SUBMIT_FULLSCREEN)
+    got = ctx.read_texture(capi.TEX_CANVAS)
+    inner = (slice(8, -8), slice(8, -8))         # away from the crop's wrap-around border
+    assert pc.same_bits(got[inner], want[inner]), pc.describe_diff(got[inner], want[inner])
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(64, 64)
+
+
+def test_config5_forest_tile_split_8(gpu_ctx, orc, forest, env):
+    """The instanced-forest generator (scaled down to ~1.7 M triangles for test time; the
+    10 M-triangle run is profiles/configs_probe.py): 8-rank tile split == whole image,
+    reference kernel == shipped kernel, oracle band."""
+    w, h = 1280, 720
+    ctx = gpu_ctx
+    assert len(forest.triangles) > 1_500_000
+    pc.upload_scene(ctx, forest, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    frames = (2,)
+    ref, cref = _render(ctx, forest, w, h, frames, variant=2)
+    whole, cwhole = _render(ctx, forest, w, h, frames)
+    assert pc.same_bits(whole, ref), pc.describe_diff(whole, ref)
+    assert cwhole["box_tests"] == cref["box_tests"] and cwhole["tri_tests"] == cref["tri_tests"]
+    out = np.zeros_like(whole)
+    for rank in range(8):
+        ctx.set_tile(rank, 8, 8)
+        ctx.resize(w, h)
+        part, _ = _render(ctx, forest, w, h, frames)
+        out[[y for y in range(h) if (y // 8) % 8 == rank]] = part
+    assert pc.same_bits(out, whole), pc.describe_diff(out, whole)
+    band = _oracle_band(orc, forest, env, w, h, frames, first_row=360)
+    assert pc.same_bits(whole[360:368], band), pc.describe_diff(whole[360:368], band)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(64, 64)

@@ -793,6 +793,27 @@ extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t 
     return MI3PT_OK;
 }
 
+// Host -> device counterpart of mi3pt_read_texture for the accumulation image: restores a
+// saved running mean (checkpoint / resume) or hands a gathered multi-GPU image to a 1-rank
+// context for the fullscreen pass.
+extern "C" int mi3pt_write_texture(mi3pt_ctx *ctx, int which, const float *src, size_t nfloats)
+{
+    if (int rc = require_idle(ctx)) return rc;
+    if (!src) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "write before resize");
+    if (which != MI3PT_TEX_ACCUMULATION && which != MI3PT_TEX_OUTPUT)
+        return pt_set_error(MI3PT_ERR_INVALID, "only the accumulation / output image can be written");
+    const size_t need = (size_t)ctx->local_rows * ctx->width * 4;
+    if (nfloats != need) return pt_set_error(MI3PT_ERR_INVALID, "source size does not match the texture");
+    if (need) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_accum, src, need * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));      // copy-on-call
+    }
+    ctx->output_is_accum = true;      // like the copy-back of accumulate.ts:171-175
+    ctx->main_dirty = true;
+    return MI3PT_OK;
+}
+
 extern "C" int mi3pt_read_canvas_rgba8(mi3pt_ctx *ctx, uint8_t *dst, size_t nbytes)
 {
     if (int rc = require_idle(ctx)) return rc;

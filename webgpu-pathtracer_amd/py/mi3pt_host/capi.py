@@ -27,6 +27,7 @@ SYMBOLS = (
     "mi3pt_tile_local_rows", "mi3pt_upload_triangles", "mi3pt_upload_materials", "mi3pt_upload_bvh",
     "mi3pt_upload_environment", "mi3pt_upload_environment_cdf", "mi3pt_resize", "mi3pt_reset",
     "mi3pt_set_uniforms", "mi3pt_submit", "mi3pt_sync", "mi3pt_read_texture", "mi3pt_read_canvas_rgba8",
+    "mi3pt_write_texture",
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
     "mi3pt_set_pipelining", "mi3pt_flush",
@@ -76,6 +77,7 @@ def load_library(path=None):
     lib.mi3pt_flush.argtypes = [c_void_p]
     lib.mi3pt_read_texture.argtypes = [c_void_p, c_int, c_void_p, c_size_t]
     lib.mi3pt_read_canvas_rgba8.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.mi3pt_write_texture.argtypes = [c_void_p, c_int, c_void_p, c_size_t]
     lib.mi3pt_accumulation_device_ptr.argtypes = [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t)]
     lib.mi3pt_bind_accumulation.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.mi3pt_enable_timing.argtypes = [c_void_p, c_int]
@@ -256,6 +258,10 @@ class Context:
         out = np.empty((rows, self.width, 4), np.float32)
         self._c(self.lib.mi3pt_read_texture(self.handle, which, _ptr(out), out.size))
         return out
+
+    def write_texture(self, which, image):
+        a = np.ascontiguousarray(image, np.float32)
+        self._c(self.lib.mi3pt_write_texture(self.handle, which, _ptr(a), a.size))
 
     def read_canvas_rgba8(self):
         out = np.empty((self.height, self.width, 4), np.uint8)
