@@ -220,8 +220,10 @@ int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n, float *ou
  * 8 fp16 round trip, 9 sqrt, 10 a/b.  b may be NULL for unary functions. */
 int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n);
 
-/* Diagnostic stamps of the last persistent raytrace launch: 4 x uint64 per resident wave
- * (begin, work-queue-empty, end on the 100 MHz wall clock; shader cycles begin->end).
+/* Diagnostic record of the last persistent raytrace launch: 8 x uint64 per resident wave
+ * (begin, work-queue-empty, end on the 100 MHz wall clock; shader cycles begin->end; then
+ * packed step statistics: walk steps | walking lanes, service steps | leaf lanes,
+ * shaded lanes | hit lanes, path starts | segment starts).
  * out == NULL: enable != 0 allocates the buffer, enable == 0 frees it. */
 int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out, size_t capacity_slots, size_t *slots_out);
 

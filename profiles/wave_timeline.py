@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-wave lifetime of the persistent raytrace kernel (demo scene, 8 bounces).
+"""Diagnostic: per-wave lifetime and step statistics of the persistent raytrace kernel.
 
-usage: python profiles/wave_timeline.py [WxH]
-Prints when the resident waves begin, see the work queue run empty, and end (100 MHz wall
-clock), plus the shader clock they averaged.  Needs a GPU.
+usage: [WORKLOAD=dragon] python profiles/wave_timeline.py [WxH] [frames_per_launch]
+Renders one launch of `frames_per_launch` batched frames (default 16; 1 = a single frame) of
+the demo (or dragon-class) scene at 8 bounces and prints when the resident waves begin, see the
+work queue run empty, and end (100 MHz wall clock), the shader clock they averaged, and how
+well filled the walk / service steps were.  Needs a GPU.
 """
 import os
 import sys
@@ -16,19 +18,23 @@ import ptcommon as pc  # noqa: E402
 from mi3pt_host import capi, scenes  # noqa: E402
 
 w, h = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1920x1080").split("x"))
-sc = scenes.demo_scene()
+nframes = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+sc = scenes.dragon_class_scene() if os.environ.get("WORKLOAD") == "dragon" else scenes.demo_scene()
 sc.build_bvh()
 env = scenes.synthetic_env()
 ctx = capi.Context(0)
 pc.upload_scene(ctx, sc, env)
 ctx.resize(w, h)
-ctx.set_kernel_variant(4)
 ctx.enable_wave_times(True)
-for frame in (2, 3, 4):
-    pc.gpu_frame(ctx, pc.rt_uniforms(sc, w, h, frame=frame, bounces=8), pc.acc_uniforms(w, h, frame), 3)
-ctx.sync()
-t = ctx.wave_times().astype(np.int64)
-t = t[t[:, 2] > 0]
+frame = 2
+for _ in range(2):                       # warm-up batch, then the measured one
+    for _ in range(nframes):
+        pc.gpu_frame(ctx, pc.rt_uniforms(sc, w, h, frame=frame, bounces=8), pc.acc_uniforms(w, h, frame), 3)
+        frame += 1
+    ctx.sync()
+raw = ctx.wave_times()
+raw = raw[raw[:, 2] > 0]
+t = raw[:, :4].astype(np.int64)
 b, e, end, clk = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
 t0 = b.min()
 
@@ -37,7 +43,8 @@ def us(x):
     return (x - t0) / 100.0
 
 
-print(f"{w}x{h}: waves {len(t)}  kernel span {us(end.max()):.1f} us")
+print(f"{w}x{h} x {nframes} frames per launch: waves {len(t)}  kernel span {us(end.max()):.1f} us "
+      f"({us(end.max()) / nframes:.1f} us per frame)")
 print(f"begin    min/median/max us: {us(b).min():.1f} {np.median(us(b)):.1f} {us(b).max():.1f}")
 ee = e[e > 0]
 if len(ee):
@@ -46,7 +53,23 @@ print(f"end      min/median/max us: {us(end).min():.1f} {np.median(us(end)):.1f}
 life = (end - b) / 100.0
 print(f"lifetime min/median/max us: {life.min():.1f} {np.median(life):.1f} {life.max():.1f}")
 print(f"shader clock over lifetime (GHz): median {np.median(clk / (life * 1e3)):.3f}")
-hist, edges = np.histogram(us(end), bins=10)
-print("end-time histogram:", [(float(a.round(0)), int(n)) for a, n in zip(edges[:-1], hist)])
-hist, edges = np.histogram(us(b), bins=10)
-print("begin-time histogram:", [(float(a.round(0)), int(n)) for a, n in zip(edges[:-1], hist)])
+
+
+def hi(x):
+    return (x >> np.uint64(32)).astype(np.int64)
+
+
+def lo(x):
+    return (x & np.uint64(0xFFFFFFFF)).astype(np.int64)
+
+
+walk_steps, walk_lanes = hi(raw[:, 4]).sum(), lo(raw[:, 4]).sum()
+service_steps, leaf_lanes = hi(raw[:, 5]).sum(), lo(raw[:, 5]).sum()
+shade_lanes, hit_lanes = hi(raw[:, 6]).sum(), lo(raw[:, 6]).sum()
+path_lanes, segment_lanes = hi(raw[:, 7]).sum(), lo(raw[:, 7]).sum()
+print(f"walk steps {walk_steps} ({walk_steps / nframes / 1e6:.3f} M per frame), mean walking lanes/step "
+      f"{walk_lanes / max(walk_steps, 1):.1f}, of which on a leaf {leaf_lanes / max(walk_steps, 1):.1f}")
+print(f"service steps {service_steps} ({service_steps / nframes / 1e3:.1f} k per frame), lanes shaded/step "
+      f"{shade_lanes / max(service_steps, 1):.1f} (hits {hit_lanes / max(service_steps, 1):.1f}), path starts/step "
+      f"{path_lanes / max(service_steps, 1):.1f}, segment starts/step {segment_lanes / max(service_steps, 1):.1f}")
+print(f"steps per wave: walk {walk_steps / len(raw):.0f}  service {service_steps / len(raw):.0f}")

@@ -923,12 +923,12 @@ extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out,
                                       size_t *slots_out)
 {
     if (int rc = require_idle(ctx)) return rc;
-    const int slots = 256 * 10;
+    const int slots = 256 * 16;
     if (!out) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (enable && !ctx->d_wave_times) {
-            HIP_TRY(hipMalloc((void **)&ctx->d_wave_times, (size_t)slots * 32));
-            HIP_TRY(hipMemset(ctx->d_wave_times, 0, (size_t)slots * 32));
+            HIP_TRY(hipMalloc((void **)&ctx->d_wave_times, (size_t)slots * 64));
+            HIP_TRY(hipMemset(ctx->d_wave_times, 0, (size_t)slots * 64));
             ctx->wave_times_slots = slots;
         } else if (!enable && ctx->d_wave_times) {
             (void)hipFree(ctx->d_wave_times);
@@ -939,7 +939,7 @@ extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out,
     }
     if (!ctx->d_wave_times) return pt_set_error(MI3PT_ERR_STATE, "wave times are not enabled");
     if (capacity_slots < (size_t)ctx->wave_times_slots) return pt_set_error(MI3PT_ERR_INVALID, "buffer too small");
-    HIP_TRY(hipMemcpyAsync(out, ctx->d_wave_times, (size_t)ctx->wave_times_slots * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_wave_times, (size_t)ctx->wave_times_slots * 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (slots_out) *slots_out = (size_t)ctx->wave_times_slots;
     return MI3PT_OK;

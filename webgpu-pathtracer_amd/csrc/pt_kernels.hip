@@ -119,8 +119,8 @@ PT_DEV bool ray_aabb(const f3 &o, const f3 &d, float mnx, float mny, float mnz,
 // is tests/test_exact_division.py (CPU, brute force).
 // ---------------------------------------------------------------------------------
 struct RayPre {
-    float ix, iy, iz;        // RN(1/d) per axis (0 where the axis is parallel)
-    uint32_t flags;          // bit0..2: axis parallel (|d| < EPSILON); bit3: slow path
+    float ix, iy, iz;        // RN(1/d) per axis
+    uint32_t flags;          // bit3: this ray takes the plain-division test
 };
 
 PT_DEV float div_pre(float n, float d, float y)
@@ -139,18 +139,20 @@ PT_DEV bool safe_magnitude(float v)
 PT_DEV RayPre ray_prepare(const f3 &o, const f3 &d, uint32_t scene_flags)
 {
     RayPre p;
-    const bool px = fabsf(d.x) < PT_EPSILON, py = fabsf(d.y) < PT_EPSILON, pz = fabsf(d.z) < PT_EPSILON;
-    p.ix = px ? 0.0f : 1.0f / d.x;
-    p.iy = py ? 0.0f : 1.0f / d.y;
-    p.iz = pz ? 0.0f : 1.0f / d.z;
-    // Markstein's exception (significand all ones; a 4-bit margin is kept) and range guards
-    const bool bad_x = !px && ((__float_as_uint(d.x) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.x) > 1048576.0f);
-    const bool bad_y = !py && ((__float_as_uint(d.y) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.y) > 1048576.0f);
-    const bool bad_z = !pz && ((__float_as_uint(d.z) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.z) > 1048576.0f);
     (void)scene_flags;
-    const bool slow = bad_x || bad_y || bad_z || !safe_magnitude(o.x) ||
+    // A parallel axis (|d| < EPSILON, raytrace.wgsl:129-133) is rare; such rays take the
+    // plain test, which keeps selects out of the fast path below.
+    const bool px = fabsf(d.x) < PT_EPSILON, py = fabsf(d.y) < PT_EPSILON, pz = fabsf(d.z) < PT_EPSILON;
+    p.ix = 1.0f / d.x;
+    p.iy = 1.0f / d.y;
+    p.iz = 1.0f / d.z;
+    // Markstein's exception (significand all ones; a 4-bit margin is kept) and range guards
+    const bool bad_x = (__float_as_uint(d.x) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.x) > 1048576.0f;
+    const bool bad_y = (__float_as_uint(d.y) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.y) > 1048576.0f;
+    const bool bad_z = (__float_as_uint(d.z) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.z) > 1048576.0f;
+    const bool slow = px || py || pz || bad_x || bad_y || bad_z || !safe_magnitude(o.x) ||
                       !safe_magnitude(o.y) || !safe_magnitude(o.z) || !(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z);
-    p.flags = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u) | (slow ? 8u : 0u);
+    p.flags = slow ? 8u : 0u;
     return p;
 }
 
@@ -158,32 +160,12 @@ PT_DEV bool ray_aabb_pre(const f3 &o, const f3 &d, const RayPre &p, bool box_uns
                          float mxx, float mxy, float mxz)
 {
     if ((p.flags & 8u) || box_unsafe) return ray_aabb(o, d, mnx, mny, mnz, mxx, mxy, mxz);
-    bool ok = true;
-    float tnx, tfx, tny, tfy, tnz, tfz;
-    {
-        const float t1 = div_pre(mnx - o.x, d.x, p.ix), t2 = div_pre(mxx - o.x, d.x, p.ix);
-        const bool par = (p.flags & 1u) != 0u;
-        tnx = par ? -PT_INF : fminf(t1, t2);
-        tfx = par ? PT_INF : fmaxf(t1, t2);
-        ok = ok && !(par && (o.x < mnx || o.x > mxx));
-    }
-    {
-        const float t1 = div_pre(mny - o.y, d.y, p.iy), t2 = div_pre(mxy - o.y, d.y, p.iy);
-        const bool par = (p.flags & 2u) != 0u;
-        tny = par ? -PT_INF : fminf(t1, t2);
-        tfy = par ? PT_INF : fmaxf(t1, t2);
-        ok = ok && !(par && (o.y < mny || o.y > mxy));
-    }
-    {
-        const float t1 = div_pre(mnz - o.z, d.z, p.iz), t2 = div_pre(mxz - o.z, d.z, p.iz);
-        const bool par = (p.flags & 4u) != 0u;
-        tnz = par ? -PT_INF : fminf(t1, t2);
-        tfz = par ? PT_INF : fmaxf(t1, t2);
-        ok = ok && !(par && (o.z < mnz || o.z > mxz));
-    }
-    const float tmin = fmaxf(fmaxf(fmaxf(-PT_INF, tnx), tny), tnz);
-    const float tmax = fminf(fminf(fminf(PT_INF, tfx), tfy), tfz);
-    return ok && !(tmin > tmax) && (tmax >= fmaxf(0.0f, tmin));
+    const float ax = div_pre(mnx - o.x, d.x, p.ix), bx = div_pre(mxx - o.x, d.x, p.ix);
+    const float ay = div_pre(mny - o.y, d.y, p.iy), by = div_pre(mxy - o.y, d.y, p.iy);
+    const float az = div_pre(mnz - o.z, d.z, p.iz), bz = div_pre(mxz - o.z, d.z, p.iz);
+    const float tmin = fmaxf(fmaxf(fmaxf(-PT_INF, fminf(ax, bx)), fminf(ay, by)), fminf(az, bz));
+    const float tmax = fminf(fminf(fminf(PT_INF, fmaxf(ax, bx)), fmaxf(ay, by)), fmaxf(az, bz));
+    return !(tmin > tmax) && (tmax >= fmaxf(0.0f, tmin));
 }
 
 // raytrace.wgsl:78-116 -- Moller-Trumbore, two-sided.  Returns hit and (t, u, v);
@@ -887,6 +869,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     const uint64_t t_begin_rt = L.wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const uint64_t t_begin_clk = L.wave_times ? __builtin_amdgcn_s_memtime() : 0ull;
     uint64_t t_empty_rt = 0ull;
+    // diagnostic step statistics (wave-uniform; stored with the stamps)
+    uint32_t st_walk_steps = 0, st_walk_lanes = 0, st_leaf_lanes = 0, st_service_steps = 0;
+    uint32_t st_shade_lanes = 0, st_hit_lanes = 0, st_path_lanes = 0, st_segment_lanes = 0;
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
     int mode = M_DEAD;
@@ -916,9 +901,11 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         const int nwalk = (int)__popcll(walking);
         if (nwalk > 0 && (nwalk >= L.walk_min || !serviceable)) {
             // ---- walk step: one pop per walking lane (raytrace.wgsl:166-200)
+            if (L.wave_times) { st_walk_steps++; st_walk_lanes += (uint32_t)nwalk; }
             if (mode == M_TRAV) {
                 sp--;
                 const uint32_t ref = st_load(sp);
+                if (L.wave_times) st_leaf_lanes += (uint32_t)__popcll(__ballot((ref & PT_REF_LEAF) != 0u));
                 if (ref & PT_REF_LEAF) {
                     const uint32_t ti = ref & 0x7fffffffu;
                     const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
@@ -952,6 +939,11 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         if (!serviceable) break;      // nobody walking, nothing waiting, no jobs left
 
         // ---- service step
+        if (L.wave_times) {
+            st_service_steps++;
+            st_shade_lanes += (uint32_t)__popcll(__ballot(mode == M_SHADE));
+            st_hit_lanes += (uint32_t)__popcll(__ballot(mode == M_SHADE && best.tri >= 0));
+        }
         bool need_path = false;       // start the slot's next camera path (or finish the pixel)
         bool need_segment = false;    // start rayBVHIntersect for (o, d)
         if (mode == M_SHADE) {
@@ -1039,6 +1031,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 dead = __ballot(mode == M_DEAD && !need_path && !need_segment && !mine);
             }
         }
+        if (L.wave_times) st_path_lanes += (uint32_t)__popcll(__ballot(need_path));
         if (need_path) {
             // raytrace.wgsl:441-455: next sample's camera path, or the pixel is finished
             for (;;) {
@@ -1065,6 +1058,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 sample++;
             }
         }
+        if (L.wave_times) st_segment_lanes += (uint32_t)__popcll(__ballot(need_segment));
         if (need_segment) {
             // raySceneIntersect + the root test of rayBVHIntersect, raytrace.wgsl:155-164, 205-211
             best.t = PT_INF; best.u = 0.0f; best.v = 0.0f; best.tri = -1;
@@ -1084,11 +1078,15 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     }
 
     if (L.wave_times && lane == 0) {
-        uint64_t *w = L.wave_times + (size_t)blockIdx.x * 4;
+        uint64_t *w = L.wave_times + (size_t)blockIdx.x * 8;
         w[0] = t_begin_rt;
         w[1] = t_empty_rt;
         w[2] = __builtin_amdgcn_s_memrealtime();
         w[3] = __builtin_amdgcn_s_memtime() - t_begin_clk;
+        w[4] = ((uint64_t)st_walk_steps << 32) | st_walk_lanes;
+        w[5] = ((uint64_t)st_service_steps << 32) | st_leaf_lanes;
+        w[6] = ((uint64_t)st_shade_lanes << 32) | st_hit_lanes;
+        w[7] = ((uint64_t)st_path_lanes << 32) | st_segment_lanes;
     }
     // Self-cleaning work queue: the last wave to leave resets the head and the exit counter, so
     // launches need no memset in front of them (a memset kernel would have to wait for a free
