@@ -843,12 +843,19 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     const int lane = threadIdx.x;
     uint32_t *stack = stack_lds + lane;
     uint32_t *ovf = L.stack_overflow + (size_t)blockIdx.x * ((PT_MAX_STACK - PT_SM_LDS_DEPTH) * 64) + lane;
+    // LDS and the overflow slice are accessed by separate instructions (a pointer select
+    // between the two address spaces would compile to flat_* accesses, which wait for every
+    // outstanding memory operation): the LDS access is unconditional, the overflow access a
+    // rare branch kept apart by the opaque asm.
     auto st_load = [&](int i) -> uint32_t {
-        return i < PT_SM_LDS_DEPTH ? stack[i * 64] : ovf[(i - PT_SM_LDS_DEPTH) * 64];
+        uint32_t v = stack[(i & (PT_SM_LDS_DEPTH - 1)) * 64];
+        asm volatile("" : "+v"(v));          // keep this a ds_read of its own
+        if (i >= PT_SM_LDS_DEPTH) v = ovf[(i - PT_SM_LDS_DEPTH) * 64];
+        return v;
     };
     auto st_store = [&](int i, uint32_t v) {
-        if (i < PT_SM_LDS_DEPTH) stack[i * 64] = v;
-        else ovf[(i - PT_SM_LDS_DEPTH) * 64] = v;
+        if (i >= PT_SM_LDS_DEPTH) ovf[(i - PT_SM_LDS_DEPTH) * 64] = v;
+        else stack[i * 64] = v;
     };
     const SceneRefs &sc = L.scene;
     const RtUniforms &un = L.un;
