@@ -1226,7 +1226,14 @@ void launch_accumulate(const AccUniforms &acc, const Tile &tile, const float4 *i
 // ---------------------------------------------------------------------------------
 // fullscreen.wgsl
 // ---------------------------------------------------------------------------------
-PT_DEV int wrapi(int v, int n) { int m = v % n; return m < 0 ? m + n : m; }
+// repeat addressing: v mod n.  Sample positions stay within one period of the texture, so the
+// common case is a conditional add / subtract; the integer modulo is the general fallback.
+PT_DEV int wrapi(int v, int n)
+{
+    if (v >= -n && v < 2 * n) return v < 0 ? v + n : (v >= n ? v - n : v);
+    const int m = v % n;
+    return m < 0 ? m + n : m;
+}
 
 // textureSample(inputTexture, sampler{linear, repeat}) -- fullscreen.ts:49-57
 PT_DEV float4 sample_repeat(const float4 *tex, int W, int H, float u, float v)
@@ -1253,30 +1260,95 @@ PT_DEV float4 sample_repeat(const float4 *tex, int W, int H, float u, float v)
     return r;
 }
 
-// fullscreen.wgsl:53-86 with sigma 5, kSigma 1, threshold 0.08 (:117-119)
-PT_DEV float4 denoise(const float4 *tex, int W, int H, float res_x, float res_y, float u, float v,
-                      float sigma, float k_sigma, float threshold)
+// fullscreen.wgsl:53-86 with sigma 5, kSigma 1, threshold 0.08 (:117-119).
+//
+// The loop bounds, the tap offsets d / size and the spatial weight
+// exp(-dot(d,d) * invSigmaQx2) * invSigmaQx2PI depend only on the tap, not on the pixel, so a
+// workgroup evaluates them once into LDS (one column of taps per thread, with the same
+// float loop `y = y + 1.0` and the same exp1) and every pixel reuses them: one exp and no
+// division per tap instead of two exps and two divisions, identical bits.
+#define PT_DN_COLS 11          // x = -radius .. radius for radius = round(kSigma * sigma) = 5
+#define PT_DN_ROWS 12
+
+struct DenoiseTaps {
+    float ox[PT_DN_COLS];                    // x / size.x
+    int count[PT_DN_COLS];                   // taps in this column
+    float oy[PT_DN_COLS][PT_DN_ROWS];        // y / size.y
+    float blur[PT_DN_COLS][PT_DN_ROWS];      // spatial weight
+};
+
+PT_DEV void denoise_build_taps(DenoiseTaps &taps, int column, float res_x, float res_y, float sigma, float k_sigma)
 {
     const float INV_PI = 0.31830988618379067153776752674503f;
-    const float INV_SQRT_OF_2PI = 0.39894228040143267793994605993439f;
     const float radius = rintf(k_sigma * sigma);
     const float rad_q = radius * radius;
     const float inv_sigma_qx2 = 0.5f / (sigma * sigma);
     const float inv_sigma_qx2pi = INV_PI * inv_sigma_qx2;
+    float x = -radius;
+    for (int c = 0; c < column; c++) x = x + 1.0f;      // the reference's float loop variable
+    int n = 0;
+    if (x <= radius) {
+        const float pt = sqrtf(rad_q - x * x);
+        for (float y = -pt; y <= pt && n < PT_DN_ROWS; y = y + 1.0f) {
+            const float dd = x * x + y * y;
+            taps.oy[column][n] = y / res_y;
+            taps.blur[column][n] = ptm::exp1(-dd * inv_sigma_qx2) * inv_sigma_qx2pi;
+            n++;
+        }
+    }
+    taps.ox[column] = x / res_x;
+    taps.count[column] = n;
+}
+
+// sample_repeat split into its horizontal and vertical halves: all taps of a column share
+// the horizontal texel pair and weight (same arithmetic as sample_repeat, evaluated once).
+struct RepeatAxis { int a, b; float f, w0; };
+
+PT_DEV RepeatAxis repeat_axis(float coord, int n)
+{
+    const float x = coord * (float)n - 0.5f;
+    float x0f = floorf(x);
+    RepeatAxis r;
+    r.f = x - x0f;
+    r.w0 = 1.0f - r.f;
+    if (!(x0f > -1.0e9f && x0f < 1.0e9f)) x0f = 0.0f;
+    const int x0 = (int)x0f;
+    r.a = wrapi(x0, n);
+    r.b = wrapi(x0 + 1, n);
+    return r;
+}
+
+PT_DEV float4 sample_repeat_axes(const float4 *tex, int W, const RepeatAxis &ax, const RepeatAxis &ay)
+{
+    const float4 p00 = tex[(size_t)ay.a * W + ax.a];
+    const float4 p10 = tex[(size_t)ay.a * W + ax.b];
+    const float4 p01 = tex[(size_t)ay.b * W + ax.a];
+    const float4 p11 = tex[(size_t)ay.b * W + ax.b];
+    float4 r;
+    r.x = (p00.x * ax.w0 + p10.x * ax.f) * ay.w0 + (p01.x * ax.w0 + p11.x * ax.f) * ay.f;
+    r.y = (p00.y * ax.w0 + p10.y * ax.f) * ay.w0 + (p01.y * ax.w0 + p11.y * ax.f) * ay.f;
+    r.z = (p00.z * ax.w0 + p10.z * ax.f) * ay.w0 + (p01.z * ax.w0 + p11.z * ax.f) * ay.f;
+    r.w = (p00.w * ax.w0 + p10.w * ax.f) * ay.w0 + (p01.w * ax.w0 + p11.w * ax.f) * ay.f;
+    return r;
+}
+
+PT_DEV float4 denoise(const DenoiseTaps &taps, const float4 *tex, int W, int H, float u, float v, float threshold)
+{
+    const float INV_SQRT_OF_2PI = 0.39894228040143267793994605993439f;
     const float inv_threshold_sqx2 = 0.5f / (threshold * threshold);
     const float inv_threshold_sqrt2pi = INV_SQRT_OF_2PI / threshold;
     const float4 centr = sample_repeat(tex, W, H, u, v);
     float zbuff = 0.0f;
     float4 abuff = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (float x = -radius; x <= radius; x = x + 1.0f) {
-        const float pt = sqrtf(rad_q - x * x);
-        for (float y = -pt; y <= pt; y = y + 1.0f) {
-            const float dd = x * x + y * y;
-            const float blur = ptm::exp1(-dd * inv_sigma_qx2) * inv_sigma_qx2pi;
-            const float4 walk = sample_repeat(tex, W, H, u + x / res_x, v + y / res_y);
+    for (int c = 0; c < PT_DN_COLS; c++) {
+        const RepeatAxis ax = repeat_axis(u + taps.ox[c], W);
+        const int n = taps.count[c];
+        for (int j = 0; j < n; j++) {
+            const RepeatAxis ay = repeat_axis(v + taps.oy[c][j], H);
+            const float4 walk = sample_repeat_axes(tex, W, ax, ay);
             const float dx = walk.x - centr.x, dy = walk.y - centr.y, dz = walk.z - centr.z, dw = walk.w - centr.w;
             const float dcdc = ((dx * dx + dy * dy) + dz * dz) + dw * dw;
-            const float delta = ptm::exp1(-dcdc * inv_threshold_sqx2) * inv_threshold_sqrt2pi * blur;
+            const float delta = ptm::exp1(-dcdc * inv_threshold_sqx2) * inv_threshold_sqrt2pi * taps.blur[c][j];
             zbuff = zbuff + delta;
             abuff.x = abuff.x + delta * walk.x;
             abuff.y = abuff.y + delta * walk.y;
@@ -1330,13 +1402,18 @@ __global__ void __launch_bounds__(256) k_fullscreen(const FsUniforms fs, const f
                                                     int tex_w, int tex_h, int canvas_w, int canvas_h,
                                                     float4 *__restrict__ out_f32, uint32_t *__restrict__ out_rgba8)
 {
+    __shared__ DenoiseTaps taps;
+    if (fs.denoise == 1u) {
+        if (threadIdx.x < PT_DN_COLS) denoise_build_taps(taps, (int)threadIdx.x, fs.res_x, fs.res_y, 5.0f, 1.0f);
+        __syncthreads();
+    }
     const int px = blockIdx.x * 16 + (threadIdx.x & 15);
     const int py = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (px >= canvas_w || py >= canvas_h) return;
     const float u = (((float)px + 0.5f) / (float)canvas_w) * fs.scaling;
     const float v = (1.0f - ((float)py + 0.5f) / (float)canvas_h) * fs.scaling;
     float4 c4 = sample_repeat(tex, tex_w, tex_h, u, v);
-    if (fs.denoise == 1u) c4 = denoise(tex, tex_w, tex_h, fs.res_x, fs.res_y, u, v, 5.0f, 1.0f, 0.08f);
+    if (fs.denoise == 1u) c4 = denoise(taps, tex, tex_w, tex_h, u, v, 0.08f);
     f3 c = F3(c4.x, c4.y, c4.z);
     if (fs.tonemapping == 1u) c = aces_tonemap(c);
     else if (fs.tonemapping == 2u) c = F3(c.x / (c.x + 1.0f), c.y / (c.y + 1.0f), c.z / (c.z + 1.0f));
