@@ -202,8 +202,9 @@ int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT]);
 int mi3pt_reset_counters(mi3pt_ctx *ctx);
 
 /* Kernel variant: 0 = auto (3), 1 = per-pixel kernel walking the uploaded records,
- * 2 = per-pixel kernel walking node packets, 3 = persistent waves with lane refill
- * (needs child adjacency right == left + 1, which flattenBVH guarantees). */
+ * 2 = per-pixel kernel walking node packets, 3 = persistent waves with lane refill,
+ * 4 = persistent per-lane state machine (the default), 5 = 4 with a walk threshold of 48,
+ * 6 = 4 with the top 64 node packets staged in LDS (measured: no gain). */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
 /* Frame pipelining (default on): with RAYTRACE|ACCUMULATE submits the raytrace kernels of
  * consecutive frames run on two alternating internal streams, so frame f+1 fills the CUs

@@ -68,7 +68,8 @@ struct mi3pt_ctx {
     int storage = MI3PT_STORAGE_F32;
     int variant = 0;
     int walk_min = 32;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
-    int waves_per_cu = 16;
+    int waves_per_cu = 16;      // 8 KB of LDS per one-wave workgroup, 128 VGPRs
+    int top_packets = 64;       // MI3PT_TOP_PACKETS
 
     // Frame pipelining: raytrace kernels of consecutive frames run on two alternating
     // internal streams so that frame f+1 fills the CUs while frame f's last paths drain;
@@ -176,6 +177,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     if (ctx->batch_max < 1) ctx->batch_max = 1;
     if (ctx->batch_max > 16) ctx->batch_max = 16;
     if (const char *e = std::getenv("MI3PT_WAVES_PER_CU")) ctx->waves_per_cu = std::atoi(e);
+    if (const char *e = std::getenv("MI3PT_TOP_PACKETS")) ctx->top_packets = std::atoi(e);
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
     if (hipMalloc(&ctx->d_env, env_bytes) != hipSuccess || hipMalloc(&ctx->d_cdf, env_bytes) != hipSuccess ||
@@ -262,7 +264,7 @@ extern "C" int mi3pt_set_storage(mi3pt_ctx *ctx, int storage)
 extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
-    if (variant < 0 || variant > 5) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..5");
+    if (variant < 0 || variant > 6) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..6");
     if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
     return MI3PT_OK;
@@ -593,6 +595,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.store_f16 = ctx->storage == MI3PT_STORAGE_F16;
     L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
     L.waves_per_cu = ctx->waves_per_cu;
+    L.top_packets = ctx->top_packets;
     return L;
 }
 

@@ -90,6 +90,7 @@ struct RtLaunch {
     uint64_t *wave_times;        // diagnostic: [grid][4] begin / feed-empty / end (100 MHz) + shader cycles, or null
     int32_t store_f16;
     int32_t walk_min;            // state-machine kernel: walk while at least this many lanes are walking
+    int32_t top_packets;         // node packets to stage in LDS per wave (0..64)
     int32_t waves_per_cu;        // persistent kernels: resident one-wave workgroups per CU
 };
 

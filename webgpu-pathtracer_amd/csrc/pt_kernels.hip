@@ -828,11 +828,16 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
 enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
 
 #define PT_SM_LDS_DEPTH 32
+#define PT_SM_TOP_PACKETS 64       // node packets staged in LDS per wave: the top 6 levels of the tree
 #ifndef PT_SM_MIN_WAVES
 #define PT_SM_MIN_WAVES 4
 #endif
 
-template <bool FUSE>
+// TOPLDS = true additionally stages the first PT_SM_TOP_PACKETS node packets in LDS (kernel
+// variant 6).  Measured on MI355X (round 1): no gain -- the kernel is
+// VALU-issue-bound and the top of the tree is L1-resident anyway, while the second load path
+// costs registers -- so the shipped default keeps TOPLDS = false.
+template <bool FUSE, bool TOPLDS>
 __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
 {
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
@@ -840,8 +845,19 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     // wave's slice of a global overflow area, so the 64-entry abort semantics are kept
     // while a wave only needs 8 KB of LDS.
     __shared__ uint32_t stack_lds[PT_SM_LDS_DEPTH * 64];
+    // BVH node packets staged in LDS: packets are numbered breadth-first, so the first
+    // PT_SM_TOP_PACKETS of them ARE the top levels of the tree (raytrace.ts:667-678), which
+    // every ray walks.  One-wave workgroups (a multi-wave workgroup would hold its LDS and
+    // wave slots until its slowest wave has drained) => a private 4 KB copy per wave.
+    __shared__ float4 top_lds[TOPLDS ? PT_SM_TOP_PACKETS * 4 : 1];
     const int lane = threadIdx.x;
     uint32_t *stack = stack_lds + lane;
+    const uint32_t top_cap = (uint32_t)L.top_packets < (uint32_t)PT_SM_TOP_PACKETS ? (uint32_t)L.top_packets : (uint32_t)PT_SM_TOP_PACKETS;
+    const uint32_t ntop = !TOPLDS ? 0u : (L.scene.npackets < top_cap ? L.scene.npackets : top_cap);
+    if (TOPLDS) {
+        for (uint32_t i = (uint32_t)lane; i < ntop * 4u; i += 64u) top_lds[i] = L.scene.packets[i];
+        __syncthreads();
+    }
     uint32_t *ovf = L.stack_overflow + (size_t)blockIdx.x * ((PT_MAX_STACK - PT_SM_LDS_DEPTH) * 64) + lane;
     // LDS and the overflow slice are accessed by separate instructions (a pointer select
     // between the two address spaces would compile to flat_* accesses, which wait for every
@@ -924,10 +940,15 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti;
                     }
                 } else {
-                    const float4 p0 = sc.packets[(size_t)ref * 4 + 0];
-                    const float4 p1 = sc.packets[(size_t)ref * 4 + 1];
-                    const float4 p2 = sc.packets[(size_t)ref * 4 + 2];
-                    const float4 p3 = sc.packets[(size_t)ref * 4 + 3];
+                    float4 p0, p1, p2, p3;
+                    if (TOPLDS && ref < ntop) {       // top of the tree: LDS
+                        p0 = top_lds[ref * 4 + 0]; p1 = top_lds[ref * 4 + 1];
+                        p2 = top_lds[ref * 4 + 2]; p3 = top_lds[ref * 4 + 3];
+                        asm volatile("" : "+v"(p0.x), "+v"(p1.x), "+v"(p2.x), "+v"(p3.x));   // keep these ds_read_b128
+                    } else {
+                        p0 = sc.packets[(size_t)ref * 4 + 0]; p1 = sc.packets[(size_t)ref * 4 + 1];
+                        p2 = sc.packets[(size_t)ref * 4 + 2]; p3 = sc.packets[(size_t)ref * 4 + 3];
+                    }
                     const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
                     if (lref != PT_REF_NONE) {
                         cnt.box++;
@@ -1141,9 +1162,12 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
         if (variant == 3) {
             if (fuse) hipLaunchKernelGGL((k_raytrace_persistent<true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_persistent<false>), grid, block, 0, s, L);
+        } else if (variant == 6) {
+            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, true>), grid, block, 0, s, L);
+            else hipLaunchKernelGGL((k_raytrace_sm<false, true>), grid, block, 0, s, L);
         } else {
-            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true>), grid, block, 0, s, L);
-            else hipLaunchKernelGGL((k_raytrace_sm<false>), grid, block, 0, s, L);
+            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false>), grid, block, 0, s, L);
+            else hipLaunchKernelGGL((k_raytrace_sm<false, false>), grid, block, 0, s, L);
         }
         return;
     }
