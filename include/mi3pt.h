@@ -201,15 +201,17 @@ int mi3pt_raytrace_launch_stats(mi3pt_ctx *ctx, int reset, double *total_ms, uin
 int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT]);
 int mi3pt_reset_counters(mi3pt_ctx *ctx);
 
-/* Kernel variant: 0 = auto (3), 1 = per-pixel kernel walking the uploaded records,
+/* Kernel variant: 0 = auto (4), 1 = per-pixel kernel walking the uploaded records,
  * 2 = per-pixel kernel walking node packets, 3 = persistent waves with lane refill,
  * 4 = persistent per-lane state machine (the default), 5 = 4 with a walk threshold of 48,
  * 6 = 4 with the top 64 node packets staged in LDS (measured: no gain). */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
-/* Frame pipelining (default on): with RAYTRACE|ACCUMULATE submits the raytrace kernels of
- * consecutive frames run on two alternating internal streams, so frame f+1 fills the CUs
- * while the last paths of frame f drain; the running mean stays ordered on the context's
- * stream and results are bit-identical.  Off: one fused kernel per frame on the stream. */
+/* Frame pipelining (default on): RAYTRACE|ACCUMULATE submits are queued; up to 16 consecutive
+ * frames whose uniforms differ only in `frame` run as one raytrace launch plus one ordered
+ * multi-frame running mean, and launches alternate between two internal streams so the next
+ * one fills the CUs while the last paths of this one drain.  Any call that observes or
+ * changes device state flushes the queue first; results are bit-identical.  Off: one fused
+ * kernel per frame on the context's stream, launched inside mi3pt_submit. */
 int mi3pt_set_pipelining(mi3pt_ctx *ctx, int enabled);
 
 /* ---- component probes on the device (parity tests of the pieces) ----

@@ -228,6 +228,7 @@ napi_value Destroy(napi_env env, napi_callback_info info)
 CTX_INT_FN(SetStorage, mi3pt_set_storage)
 CTX_INT_FN(SetKernelVariant, mi3pt_set_kernel_variant)
 CTX_INT_FN(EnableTiming, mi3pt_enable_timing)
+CTX_INT_FN(SetPipelining, mi3pt_set_pipelining)
 CTX_VOID_FN(Reset, mi3pt_reset)
 CTX_VOID_FN(Sync, mi3pt_sync)
 CTX_VOID_FN(Flush, mi3pt_flush)
@@ -319,6 +320,42 @@ napi_value ReadTexture(napi_env env, napi_callback_info info)
     MI3PT_TRY(mi3pt_read_texture(ctx, which, static_cast<float *>(data), (size_t)nfloats));
     NAPI_OK(napi_create_typedarray(env, napi_float32_array, (size_t)nfloats, ab, 0, &ta));
     return ta;
+}
+
+// writeTexture(ctx, which, Float32Array) : GPUQueue.writeTexture for the HDR images
+napi_value WriteTexture(napi_env env, napi_callback_info info)
+{
+    Args a;
+    mi3pt_ctx *ctx;
+    int32_t which;
+    void *data;
+    size_t n;
+    if (!get_args(env, info, a, 3) || !get_ctx(env, a.v[0], &ctx) || !get_i32(env, a.v[1], &which) ||
+        !get_bytes(env, a.v[2], &data, &n))
+        return nullptr;
+    MI3PT_TRY(mi3pt_write_texture(ctx, which, static_cast<const float *>(data), n / 4));
+    return undefined(env);
+}
+
+// raytraceLaunchStats(ctx, reset) -> { totalMs, launches, frames }
+napi_value RaytraceLaunchStats(napi_env env, napi_callback_info info)
+{
+    Args a;
+    mi3pt_ctx *ctx;
+    int32_t reset;
+    if (!get_args(env, info, a, 2) || !get_ctx(env, a.v[0], &ctx) || !get_i32(env, a.v[1], &reset)) return nullptr;
+    double ms = 0.0;
+    uint64_t launches = 0, frames = 0;
+    MI3PT_TRY(mi3pt_raytrace_launch_stats(ctx, reset, &ms, &launches, &frames));
+    napi_value obj, v;
+    NAPI_OK(napi_create_object(env, &obj));
+    NAPI_OK(napi_create_double(env, ms, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "totalMs", v));
+    NAPI_OK(napi_create_double(env, (double)launches, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "launches", v));
+    NAPI_OK(napi_create_double(env, (double)frames, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "frames", v));
+    return obj;
 }
 
 // readCanvasRgba8(ctx, nbytes) -> Uint8Array
@@ -461,7 +498,8 @@ napi_value Init(napi_env env, napi_value exports)
         { "sync", Sync }, { "flush", Flush }, { "readTexture", ReadTexture }, { "readCanvasRgba8", ReadCanvasRgba8 },
         { "enableTiming", EnableTiming }, { "passTimeUs", PassTimeUs }, { "getCounters", GetCounters },
         { "resetCounters", ResetCounters }, { "hostBuildBvhF64", HostBuildBvhF64 }, { "hostBuildBvh", HostBuildBvh },
-        { "hostEnvCdf", HostEnvCdf },
+        { "hostEnvCdf", HostEnvCdf }, { "setPipelining", SetPipelining }, { "writeTexture", WriteTexture },
+        { "raytraceLaunchStats", RaytraceLaunchStats },
     };
     for (const auto &f : fns) {
         napi_value v;

@@ -104,4 +104,9 @@ export class Renderer {
   /** the fullscreen pass's target, row 0 = top */
   readCanvasFloat(): Float32Array; readCanvas(): Uint8Array;
   counters(): { rays: number; boxTests: number; triTests: number; hits: number; misses: number; stackOverflows: number; pixels: number };
+  /** write the HDR accumulation image back (checkpoint / resume, gathered multi-GPU image) */
+  writeAccumulation(data: Float32Array): void;
+  /** launch the sample frames render() has queued, without waiting for them */
+  flush(): void;
+  raytraceLaunchStats(reset?: boolean): { totalMs: number; launches: number; frames: number };
 }

@@ -180,6 +180,11 @@ class Renderer {
   readCanvasFloat() { return this.native.readTexture(this.handle, TEX_CANVAS, this._height * this._width * 4); }
   readCanvas() { return this.native.readCanvasRgba8(this.handle, this._height * this._width * 4); }
   counters() { return this.native.getCounters(this.handle); }
+  // write the HDR accumulation image back (checkpoint/resume; a gathered multi-GPU image)
+  writeAccumulation(data) { this.native.writeTexture(this.handle, TEX_ACCUMULATION, data); }
+  // launch queued sample frames now without waiting for them (render() only queues them)
+  flush() { this.native.flush(this.handle); }
+  raytraceLaunchStats(reset) { return this.native.raytraceLaunchStats(this.handle, reset ? 1 : 0); }
 }
 
 module.exports = { Renderer, loadNative };
