@@ -1,0 +1,91 @@
+// Exhaustive check of the division-free slab quotients used by the raytrace kernel.
+//
+// For binary32 n, d (normal, and no intermediate under/overflow -- the kernel's guards) the
+// sequence
+//      y  = RN(1/d)                 (IEEE division, once per ray and axis)
+//      q0 = RN(n*y)
+//      q1 = RN(q0 + RN(n - d*q0)*y)         3 VALU ops per quotient   ("short" form)
+//      q2 = RN(q1 + RN(n - d*q1)*y)         5 VALU ops per quotient   ("long" form, Markstein)
+// is compared with RN(n/d) for EVERY pair of significands (2^23 x 2^23).  All operations are
+// round-to-nearest and commute with scaling by powers of two and with sign changes, so the
+// significand pairs in [1,2) x [1,2) cover every input the guards admit.
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+//         profiles/div_proof.hip -o /tmp/div_proof && /tmp/div_proof [first_d_chunk] [n_chunks]
+//
+// Output: mismatch counts of the short and long forms (and of q0 alone, to show the check has
+// teeth), and the d significands for which the short form fails, if any.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+struct Result {
+    unsigned long long bad_short, bad_long, bad_q0;
+    unsigned int nbad_d;
+    unsigned int bad_d[256];
+    unsigned int bad_n[256];
+};
+
+// one thread per d significand of the chunk; loops over all 2^23 n significands
+__global__ void __launch_bounds__(256) k_check(uint32_t d_first, Result *res)
+{
+    const uint32_t dm = d_first + blockIdx.x * blockDim.x + threadIdx.x;
+    const float d = __uint_as_float(0x3f800000u | dm);
+    const float y = 1.0f / d;
+    unsigned int bs = 0, bl = 0, b0 = 0, first_n = 0xffffffffu;
+#pragma unroll 4
+    for (uint32_t nm = 0; nm < (1u << 23); nm++) {
+        const float n = __uint_as_float(0x3f800000u | nm);
+        const float want = n / d;
+        const float q0 = n * y;
+        const float q1 = fmaf(fmaf(-d, q0, n), y, q0);
+        const float q2 = fmaf(fmaf(-d, q1, n), y, q1);
+        b0 += (q0 != want);
+        const bool s = (q1 != want);
+        if (s && first_n == 0xffffffffu) first_n = nm;
+        bs += s;
+        bl += (q2 != want);
+    }
+    if (bs | bl | b0) {
+        atomicAdd(&res->bad_short, (unsigned long long)bs);
+        atomicAdd(&res->bad_long, (unsigned long long)bl);
+        atomicAdd(&res->bad_q0, (unsigned long long)b0);
+    }
+    if (bs) {
+        const unsigned int slot = atomicAdd(&res->nbad_d, 1u);
+        if (slot < 256) { res->bad_d[slot] = dm; res->bad_n[slot] = first_n; }
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const uint32_t chunk = 1u << 18;                       // d significands per launch
+    const uint32_t nchunks_all = (1u << 23) / chunk;       // 32
+    uint32_t first = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 0;
+    uint32_t count = argc > 2 ? (uint32_t)std::atoi(argv[2]) : nchunks_all - first;
+    if (first >= nchunks_all) return 2;
+    if (first + count > nchunks_all) count = nchunks_all - first;
+    Result *dres, h{};
+    CHECK(hipMalloc((void **)&dres, sizeof(Result)));
+    CHECK(hipMemset(dres, 0, sizeof(Result)));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t c = first; c < first + count; c++) {
+        hipLaunchKernelGGL(k_check, dim3(chunk / 256), dim3(256), 0, 0, c * chunk, dres);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(&h, dres, sizeof(Result), hipMemcpyDeviceToHost));
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("d chunk %u/%u done (%.1f s): pairs %.4g  mismatches q0 %llu  short(3 ops) %llu  long(5 ops) %llu  failing d %u\n",
+                    c + 1, nchunks_all, s, (double)(c - first + 1) * chunk * (double)(1u << 23), h.bad_q0, h.bad_short,
+                    h.bad_long, h.nbad_d);
+        std::fflush(stdout);
+    }
+    for (unsigned int i = 0; i < h.nbad_d && i < 256; i++)
+        std::printf("short form fails for d significand 0x%06x (first n significand 0x%06x)\n", h.bad_d[i], h.bad_n[i]);
+    std::printf("RESULT pairs %.6g  q0 %llu  short %llu  long %llu  failing_d %u\n",
+                (double)count * chunk * (double)(1u << 23), h.bad_q0, h.bad_short, h.bad_long, h.nbad_d);
+    return 0;
+}

@@ -60,8 +60,10 @@ def test_fp16_round_trip_is_round_to_nearest_even(orc):
 
 
 def test_exact_division_with_a_prepared_reciprocal(orc):
-    """q2 = fma(fma(-d,q1,n),y,q1) with y = RN(1/d) is the correctly rounded quotient under
-    the guards the kernel checks per ray ('Exact slab test without divisions')."""
+    """q1 = fma(fma(-d,q0,n),y,q0) with y = RN(1/d), q0 = RN(n*y) is the correctly rounded quotient
+    over the exponent range the kernel's guards admit, incl. divisors whose significand is all
+    ones ('Exact slab test without divisions'; the exhaustive significand-pair check
+    is profiles/div_proof.hip, run on the device)."""
     lib = orc.lib()
     lib.orc_check_div_pre.restype = ctypes.c_uint64
     lib.orc_check_div_pre.argtypes = [ctypes.c_uint64, ctypes.c_uint64]

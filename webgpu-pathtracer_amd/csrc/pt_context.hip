@@ -56,7 +56,7 @@ struct mi3pt_ctx {
     bool output_is_accum = false;
     uint64_t *d_block_counters = nullptr;
     uint32_t *d_tile_counter = nullptr;
-    uint32_t *d_stack_overflow = nullptr; // [2 parities][4096 waves][32][64] overflow stack entries
+    uint32_t *d_stack_overflow = nullptr; // [2 parities][PT_MAX_RESIDENT_WAVES][32][64] overflow stack entries
     uint64_t *d_wave_times = nullptr;     // diagnostic stamps, allocated by mi3pt_debug_wave_times(enable)
     int wave_times_slots = 0;
     int nblocks = 0;
@@ -182,7 +182,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
     if (hipMalloc(&ctx->d_env, env_bytes) != hipSuccess || hipMalloc(&ctx->d_cdf, env_bytes) != hipSuccess ||
         hipMalloc((void **)&ctx->d_tile_counter, 256) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * 4096 * 32 * 64 * 4) != hipSuccess) {
+        hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * 32 * 64 * 4) != hipSuccess) {
         mi3pt_destroy(ctx);
         return pt_set_error(MI3PT_ERR_HIP, "hipMalloc(environment) failed");
     }
@@ -411,7 +411,8 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
         }
         p.lref = ref_of(left);
         p.rref = ref_of(right);
-        p.flags = ((left >= 0 && !box_safe((size_t)left)) ? 1u : 0u) | ((right >= 0 && !box_safe((size_t)right)) ? 2u : 0u);
+        p.flags = ((left >= 0 && !box_safe((size_t)left)) ? 1u : 0u) | ((right >= 0 && !box_safe((size_t)right)) ? 2u : 0u) |
+                  ((left < 0 || right < 0) ? 4u : 0u);      // bit2: a child is missing (never from flattenBVH)
     }
     if (int rc = replace_buffer(ctx, &ctx->d_nodes, bytes, nbytes)) return rc;
     if (int rc = replace_buffer(ctx, &ctx->d_packets, pk.data(), pk.size() * sizeof(pt::NodePacket))) return rc;
@@ -646,7 +647,7 @@ static int flush_pending(mi3pt_ctx *ctx)
     L.nframes = n;
     L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
     L.tile_counter = ctx->d_tile_counter + par * 32;
-    L.stack_overflow = ctx->d_stack_overflow + (size_t)par * 4096 * 32 * 64;
+    L.stack_overflow = ctx->d_stack_overflow + (size_t)par * pt::PT_MAX_RESIDENT_WAVES * 32 * 64;
     if (ctx->timing) {
         if (int rc = collect_rt_time(ctx, par)) return rc;      // the launch of two batches ago
         HIP_TRY(hipEventRecord(ctx->ev_rt[par][0], rs));
@@ -926,7 +927,7 @@ extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out,
                                       size_t *slots_out)
 {
     if (int rc = require_idle(ctx)) return rc;
-    const int slots = 256 * 16;
+    const int slots = pt::PT_MAX_RESIDENT_WAVES;
     if (!out) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (enable && !ctx->d_wave_times) {

@@ -5,6 +5,11 @@
 
 namespace pt {
 
+// Upper bound on the persistent kernels' grid (256 CUs x 24 waves); sizes the per-wave
+// overflow-stack slices and diagnostic slots.
+constexpr int PT_MAX_RESIDENT_WAVES = 256 * 24;
+
+
 // per-pass counters, see mi3pt_counter in include/mi3pt.h
 enum { CNT_RAYS, CNT_BOX, CNT_TRI, CNT_HIT, CNT_MISS, CNT_OVERFLOW, CNT_PIXELS, CNT_RESERVED, CNT_COUNT };
 

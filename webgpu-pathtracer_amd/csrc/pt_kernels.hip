@@ -105,18 +105,21 @@ PT_DEV bool ray_aabb(const f3 &o, const f3 &d, float mnx, float mny, float mnz,
 // The same slab test with the twelve IEEE divisions of a node's two boxes replaced by
 // a per-ray reciprocal.  All six quotients of a box share the ray's three divisors, so
 // y = RN(1/d) is formed once per path segment (one true division per axis) and each
-// quotient is recovered EXACTLY as RN(n/d) by two Newton corrections with exact fma
-// residuals (Markstein's theorem: with y the correctly rounded reciprocal and q1 a
-// faithful quotient, RN(q1 + (n - d*q1)*y) is the correctly rounded n/d, provided the
-// significand of d is not all ones and nothing under/overflows):
-//     q0 = n*y;  q1 = fma(fma(-d, q0, n), y, q0);  q2 = fma(fma(-d, q1, n), y, q1)
-// 5 VALU ops instead of the 11 of the hardware division expansion.  The conditions
-// are checked per ray (RayPre::slow: direction significand / range, origin components 0
-// or within [2^-70, 2^60]) and per box (a packet flag set at upload for the rare boxes
-// with a non-zero coordinate outside [2^-70, 2^60], e.g. the 1e-33 residues three.js's
-// SphereGeometry leaves at the poles); a test that fails them takes ray_aabb() above.  tests/test_gpu_parity.py holds this kernel
-// bit-identical to the plain-division kernels; oracle-side evidence for the identity
-// is tests/test_exact_division.py (CPU, brute force).
+// quotient is recovered EXACTLY as RN(n/d) by one Newton correction with an exact fma
+// residual:
+//     q0 = n*y;  q1 = fma(fma(-d, q0, n), y, q0)
+// 3 VALU ops instead of the 11 of the hardware division expansion.  That q1 == RN(n/d)
+// for every binary32 n, d is established by exhaustion: profiles/div_proof.hip checks all
+// 2^23 x 2^23 significand pairs on the device (7.04e13 pairs, 0 mismatches -- log in
+// profiles/r01_g_div_proof_exhaustive.log; q0 alone is wrong for 27 % of them), and every
+// operation is round-to-nearest, so the identity carries over to all signs and exponents
+// as long as nothing under- or overflows.  That proviso is checked per ray
+// (RayPre::slow: |d| within [1e-6, 2^20], origin components 0 or within [2^-70, 2^60])
+// and per box (a packet flag set at upload for the rare boxes with a non-zero coordinate
+// outside [2^-70, 2^60], e.g. the 1e-33 residues three.js's SphereGeometry leaves at the
+// poles); a test that fails it takes ray_aabb() above.  tests/test_gpu_parity.py holds
+// this kernel bit-identical to the plain-division kernels; tests/test_math_oracle.py
+// samples the identity over the admitted exponent range on the CPU.
 // ---------------------------------------------------------------------------------
 struct RayPre {
     float ix, iy, iz;        // RN(1/d) per axis
@@ -126,8 +129,7 @@ struct RayPre {
 PT_DEV float div_pre(float n, float d, float y)
 {
     const float q0 = n * y;
-    const float q1 = fmaf(fmaf(-d, q0, n), y, q0);
-    return fmaf(fmaf(-d, q1, n), y, q1);
+    return fmaf(fmaf(-d, q0, n), y, q0);
 }
 
 PT_DEV bool safe_magnitude(float v)
@@ -146,10 +148,8 @@ PT_DEV RayPre ray_prepare(const f3 &o, const f3 &d, uint32_t scene_flags)
     p.ix = 1.0f / d.x;
     p.iy = 1.0f / d.y;
     p.iz = 1.0f / d.z;
-    // Markstein's exception (significand all ones; a 4-bit margin is kept) and range guards
-    const bool bad_x = (__float_as_uint(d.x) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.x) > 1048576.0f;
-    const bool bad_y = (__float_as_uint(d.y) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.y) > 1048576.0f;
-    const bool bad_z = (__float_as_uint(d.z) & 0x007fffffu) >= 0x007ffff0u || fabsf(d.z) > 1048576.0f;
+    // range guards (no residual may under- or overflow)
+    const bool bad_x = fabsf(d.x) > 1048576.0f, bad_y = fabsf(d.y) > 1048576.0f, bad_z = fabsf(d.z) > 1048576.0f;
     const bool slow = px || py || pz || bad_x || bad_y || bad_z || !safe_magnitude(o.x) ||
                       !safe_magnitude(o.y) || !safe_magnitude(o.z) || !(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z);
     p.flags = slow ? 8u : 0u;
@@ -160,6 +160,18 @@ PT_DEV bool ray_aabb_pre(const f3 &o, const f3 &d, const RayPre &p, bool box_uns
                          float mxx, float mxy, float mxz)
 {
     if ((p.flags & 8u) || box_unsafe) return ray_aabb(o, d, mnx, mny, mnz, mxx, mxy, mxz);
+    const float ax = div_pre(mnx - o.x, d.x, p.ix), bx = div_pre(mxx - o.x, d.x, p.ix);
+    const float ay = div_pre(mny - o.y, d.y, p.iy), by = div_pre(mxy - o.y, d.y, p.iy);
+    const float az = div_pre(mnz - o.z, d.z, p.iz), bz = div_pre(mxz - o.z, d.z, p.iz);
+    const float tmin = fmaxf(fmaxf(fmaxf(-PT_INF, fminf(ax, bx)), fminf(ay, by)), fminf(az, bz));
+    const float tmax = fminf(fminf(fminf(PT_INF, fmaxf(ax, bx)), fmaxf(ay, by)), fmaxf(az, bz));
+    return !(tmin > tmax) && (tmax >= fmaxf(0.0f, tmin));
+}
+
+// ray_aabb_pre() for a ray and a box that both passed the guards (no fallback inside)
+PT_DEV bool ray_aabb_fast(const f3 &o, const f3 &d, const RayPre &p, float mnx, float mny, float mnz,
+                          float mxx, float mxy, float mxz)
+{
     const float ax = div_pre(mnx - o.x, d.x, p.ix), bx = div_pre(mxx - o.x, d.x, p.ix);
     const float ay = div_pre(mny - o.y, d.y, p.iy), by = div_pre(mxy - o.y, d.y, p.iy);
     const float az = div_pre(mnz - o.z, d.z, p.iz), bz = div_pre(mxz - o.z, d.z, p.iz);
@@ -837,6 +849,7 @@ enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
 // variant 6).  Measured on MI355X (round 1): no gain -- the kernel is
 // VALU-issue-bound and the top of the tree is L1-resident anyway, while the second load path
 // costs registers -- so the shipped default keeps TOPLDS = false.
+// (5 waves per SIMD = 96 VGPRs spills 53 registers and runs 28 % slower: profiles/r01_g_occupancy_*.log)
 template <bool FUSE, bool TOPLDS>
 __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
 {
@@ -918,13 +931,66 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     bool feed_empty = false;
 
     for (;;) {
+        // walk phase: an inner loop of its own, so that the path state the walk does not
+        // touch stays put in its registers
+        bool serviceable;
+        for (;;) {
         const unsigned long long walking = __ballot(mode == M_TRAV);
-        const bool serviceable = __ballot(mode == M_SHADE) != 0ull ||
-                                 (!feed_empty && __ballot(mode == M_DEAD) != 0ull);
+        serviceable = __ballot(mode == M_SHADE) != 0ull || (!feed_empty && __ballot(mode == M_DEAD) != 0ull);
         const int nwalk = (int)__popcll(walking);
-        if (nwalk > 0 && (nwalk >= L.walk_min || !serviceable)) {
+        if (!(nwalk > 0 && (nwalk >= L.walk_min || !serviceable))) break;
+        {
             // ---- walk step: one pop per walking lane (raytrace.wgsl:166-200)
             if (L.wave_times) { st_walk_steps++; st_walk_lanes += (uint32_t)nwalk; }
+            // Wave-uniform choice: when no walking lane needs the plain-division test or the
+            // overflow part of the stack, the step runs a version without those branches
+            // (stack accesses are plain LDS, both child boxes are tested and pushed without
+            // divergence); packets with a guard bit take the generic child handling.
+            const bool trav = mode == M_TRAV;
+            if (__ballot(trav && ((pre.flags & 8u) != 0u || sp >= PT_SM_LDS_DEPTH)) == 0ull) {
+                if (trav) {
+                    sp--;
+                    const uint32_t ref = stack[sp * 64];
+                    if (L.wave_times) st_leaf_lanes += (uint32_t)__popcll(__ballot((ref & PT_REF_LEAF) != 0u));
+                    if (ref & PT_REF_LEAF) {
+                        const uint32_t ti = ref & 0x7fffffffu;
+                        const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
+                        const float4 pb = sc.tripk[(size_t)ti * 3 + 1];
+                        const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
+                        cnt.tri++;
+                        float t, u, v;
+                        if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
+                            best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti;
+                        }
+                    } else {
+                        const float4 p0 = sc.packets[(size_t)ref * 4 + 0], p1 = sc.packets[(size_t)ref * 4 + 1];
+                        const float4 p2 = sc.packets[(size_t)ref * 4 + 2], p3 = sc.packets[(size_t)ref * 4 + 3];
+                        const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
+                        const uint32_t pf = __float_as_uint(p3.z);
+                        if (pf == 0u) {
+                            cnt.box += 2;
+                            const bool hl = ray_aabb_fast(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                            const bool hr = ray_aabb_fast(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
+                            // sp <= PT_SM_LDS_DEPTH - 2 here: both slots exist; a slot above sp is dead
+                            stack[sp * 64] = lref;
+                            sp += hl ? 1 : 0;
+                            stack[sp * 64] = rref;
+                            sp += hr ? 1 : 0;
+                        } else {
+                            if (lref != PT_REF_NONE) {
+                                cnt.box++;
+                                if (ray_aabb_pre(o, d, pre, (pf & 1u) != 0u, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y)) { stack[sp * 64] = lref; sp++; }
+                            }
+                            if (rref != PT_REF_NONE) {
+                                cnt.box++;
+                                if (ray_aabb_pre(o, d, pre, (pf & 2u) != 0u, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w)) { stack[sp * 64] = rref; sp++; }
+                            }
+                        }
+                    }
+                    if (sp == 0) mode = M_SHADE;
+                }
+                continue;
+            }
             if (mode == M_TRAV) {
                 sp--;
                 const uint32_t ref = st_load(sp);
@@ -962,7 +1028,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (sp >= PT_MAX_STACK) { cnt.overflow++; mode = M_SHADE; }     // :167-171
                 else if (sp == 0) mode = M_SHADE;
             }
-            continue;
+        }
         }
         if (!serviceable) break;      // nobody walking, nothing waiting, no jobs left
 
@@ -1141,7 +1207,7 @@ int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu)
 {
     const int ntiles = raytrace_grid_blocks(tile);
     if (waves_per_cu <= 0 || waves_per_cu > 16) waves_per_cu = 16;   // VGPR-limited: 4 waves per SIMD
-    const int resident = 256 * waves_per_cu;
+    const int resident = 256 * waves_per_cu;                          // <= PT_MAX_RESIDENT_WAVES
     return ntiles < resident ? ntiles : resident;
 }
 
