@@ -201,10 +201,13 @@ int mi3pt_raytrace_launch_stats(mi3pt_ctx *ctx, int reset, double *total_ms, uin
 int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT]);
 int mi3pt_reset_counters(mi3pt_ctx *ctx);
 
-/* Kernel variant: 0 = auto (4), 1 = per-pixel kernel walking the uploaded records,
+/* Kernel variant: 0 = auto, 1 = per-pixel kernel walking the uploaded records,
  * 2 = per-pixel kernel walking node packets, 3 = persistent waves with lane refill,
  * 4 = persistent per-lane state machine (the default), 5 = 4 with a walk threshold of 48,
- * 6 = 4 with the top 64 node packets staged in LDS (measured: no gain). */
+ * 6 = 4 with the top 64 node packets staged in LDS (measured: no gain),
+ * 7 = 4 with leaf tests deferred into triangle steps of their own; needs a proper tree whose
+ * worst-case stack stays below 29 entries (checked at upload), otherwise 4 runs.  auto = 7
+ * when the scene allows it, else 4.  All variants produce the same bits. */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
 /* Frame pipelining (default on): RAYTRACE|ACCUMULATE submits are queued; up to 16 consecutive
  * frames whose uniforms differ only in `frame` run as one raytrace launch plus one ordered
@@ -223,10 +226,11 @@ int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n, float *ou
  * 8 fp16 round trip, 9 sqrt, 10 a/b.  b may be NULL for unary functions. */
 int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n);
 
-/* Diagnostic record of the last persistent raytrace launch: 8 x uint64 per resident wave
+/* Diagnostic record of the last persistent raytrace launch: 16 x uint64 per resident wave
  * (begin, work-queue-empty, end on the 100 MHz wall clock; shader cycles begin->end; then
  * packed step statistics: walk steps | walking lanes, service steps | leaf lanes,
- * shaded lanes | hit lanes, path starts | segment starts).
+ * shaded lanes | hit lanes, path starts | segment starts; [8] triangle steps of the
+ * deferred-leaf walk; [9..15] reserved).
  * out == NULL: enable != 0 allocates the buffer, enable == 0 frees it. */
 int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out, size_t capacity_slots, size_t *slots_out);
 

@@ -26,6 +26,8 @@ ctx = capi.Context(0)
 pc.upload_scene(ctx, sc, env)
 ctx.resize(w, h)
 ctx.enable_wave_times(True)
+if os.environ.get("VARIANT"):
+    ctx.set_kernel_variant(int(os.environ["VARIANT"]))
 frame = 2
 for _ in range(2):                       # warm-up batch, then the measured one
     for _ in range(nframes):
@@ -68,8 +70,12 @@ service_steps, leaf_lanes = hi(raw[:, 5]).sum(), lo(raw[:, 5]).sum()
 shade_lanes, hit_lanes = hi(raw[:, 6]).sum(), lo(raw[:, 6]).sum()
 path_lanes, segment_lanes = hi(raw[:, 7]).sum(), lo(raw[:, 7]).sum()
 print(f"walk steps {walk_steps} ({walk_steps / nframes / 1e6:.3f} M per frame), mean walking lanes/step "
-      f"{walk_lanes / max(walk_steps, 1):.1f}, of which on a leaf {leaf_lanes / max(walk_steps, 1):.1f}")
+      f"{walk_lanes / max(walk_steps, 1):.1f}" + ("" if raw[:, 8].any() else f", of which on a leaf {leaf_lanes / max(walk_steps, 1):.1f}"))
 print(f"service steps {service_steps} ({service_steps / nframes / 1e3:.1f} k per frame), lanes shaded/step "
       f"{shade_lanes / max(service_steps, 1):.1f} (hits {hit_lanes / max(service_steps, 1):.1f}), path starts/step "
       f"{path_lanes / max(service_steps, 1):.1f}, segment starts/step {segment_lanes / max(service_steps, 1):.1f}")
-print(f"steps per wave: walk {walk_steps / len(raw):.0f}  service {service_steps / len(raw):.0f}")
+tri_steps = raw[:, 8].astype(np.int64).sum() if raw.shape[1] > 8 else 0
+if tri_steps:
+    print(f"deferred-leaf walk: the walk steps above are node steps; triangle steps {tri_steps} "
+          f"({tri_steps / nframes / 1e6:.3f} M per frame), lanes/triangle step {leaf_lanes / tri_steps:.1f}")
+print(f"steps per wave: walk {walk_steps / len(raw):.0f}  triangle {tri_steps / len(raw):.0f}  service {service_steps / len(raw):.0f}")

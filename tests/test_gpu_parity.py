@@ -149,7 +149,7 @@ def test_stack_overflow_abort_matches_oracle(gpu_ctx, orc, variant, depth):
     ctx.set_kernel_variant(0)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7])
 def test_stack_overflow_inside_a_frame(gpu_ctx, orc, env, variant):
     """The 64-entry abort must also come out right inside the full raytrace pass of every
     kernel variant (the persistent kernels keep the stack pointer across steps)."""
@@ -184,6 +184,61 @@ def test_stack_overflow_inside_a_frame(gpu_ctx, orc, env, variant):
     ctx.set_kernel_variant(0)
 
 
+def _coincident_sheets_scene(copies=12, segments=3):
+    """`copies` coincident subdivided quads, each with its own emissive material: every hit is a
+    `copies`-way tie in t, so the colour of a pixel says which leaf the walk visited first."""
+    import math
+    from mi3pt_host import scenes as S
+    q = S.quaternion_from_axis_angle((1.0, 0.0, 0.0), -math.pi / 2)
+    parts = [S.flatten_mesh(S.plane_geometry(3, 3, segments, segments), S.compose_matrix(quaternion=q), i)
+             for i in range(copies)]
+    # a second, tilted stack crossing the first one: ties between leaves of different subtrees
+    q2 = S.quaternion_from_axis_angle((0.0, 0.0, 1.0), 0.6)
+    parts += [S.flatten_mesh(S.plane_geometry(2, 2, segments, segments), S.compose_matrix(position=(0, 0.3, 0), quaternion=q2), i)
+              for i in range(copies)]
+    mats = [dict(color=(0.2 + 0.05 * i, 0.9 - 0.06 * i, 0.5), roughness=1.0, metalness=0.0, specularColor=(1, 1, 1),
+                 emissive=(0.03 * (i + 1), 0.5 / (i + 1), 0.1 * (i % 3)), emissiveIntensity=1.0) for i in range(copies)]
+    sc = S.Scene(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
+                 np.concatenate([p[2] for p in parts]), mats, "coincident sheets")
+    sc.build_bvh()
+    return sc
+
+
+def test_equal_t_ties_keep_the_first_visited_leaf_in_every_kernel(gpu_ctx, orc, env):
+    """raytrace.wgsl:180 (strict '<'): of equal-t hits the first visited leaf wins.  The
+    deferred-leaf kernel (7) tests leaves out of order and resolves ties by visiting rank."""
+    sc = _coincident_sheets_scene()
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, sc, env)
+    ctx.set_tile(0, 1, 8)
+    w, h = 96, 64
+    ctx.resize(w, h)
+    frames = (2, 3)
+    want = np.zeros((h, w, 4), np.float32)
+    osc = pc.oracle_scene(orc, sc, env)
+    ocnt = None
+    for f in frames:
+        img, c = orc.raytrace(osc, pc.rt_uniforms(sc, w, h, frame=f, bounces=3).tobytes(), w, h)
+        want = orc.accumulate(pc.acc_uniforms(w, h, f).tobytes(), w, h, img, want)
+        ocnt = c if ocnt is None else {k: ocnt[k] + c[k] for k in c}
+    picked = set()
+    for variant in (2, 4, 7):
+        ctx.set_kernel_variant(variant)
+        ctx.reset()
+        ctx.reset_counters()
+        for f in frames:
+            pc.gpu_frame(ctx, pc.rt_uniforms(sc, w, h, frame=f, bounces=3), pc.acc_uniforms(w, h, f),
+                         capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+        got = ctx.read_texture(capi.TEX_ACCUMULATION)
+        cnt = ctx.counters()
+        assert pc.same_bits(got, want), f"variant {variant}: " + pc.describe_diff(got, want)
+        for k in ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels"):
+            assert cnt[k] == ocnt[k], f"variant {variant} counter {k}: gpu {cnt[k]} oracle {ocnt[k]}"
+        picked.add(got.tobytes())
+    assert len(picked) == 1
+    ctx.set_kernel_variant(0)
+
+
 # ---------------------------------------------------------------- whole passes
 
 FRAME_CASES = [
@@ -200,7 +255,7 @@ FRAME_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("case", FRAME_CASES, ids=[f"{c[0]}x{c[1]}-b{c[2]}-s{c[3]}-a{c[4]}" for c in FRAME_CASES])
 def test_raytrace_pass_bit_identical(gpu_ctx, orc, demo, env, case, variant):
     w, h, bounces, spf, aperture, focal, frame, rotation = case
@@ -400,15 +455,15 @@ def test_full_hd_properties(gpu_ctx, orc, demo, env):
     u = pc.rt_uniforms(demo, w, h, frame=2, bounces=8)
     a = pc.acc_uniforms(w, h, 2)
     images = {}
-    for variant in (1, 2, 3, 4, 5, 6):
+    for variant in (1, 2, 3, 4, 5, 6, 7):
         ctx.set_kernel_variant(variant)
         ctx.reset()
         ctx.reset_counters()
         pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
         images[variant] = (ctx.read_texture(capi.TEX_ACCUMULATION), ctx.counters())
-    assert all(pc.same_bits(images[v][0], images[2][0]) for v in (1, 3, 4, 5, 6))
+    assert all(pc.same_bits(images[v][0], images[2][0]) for v in (1, 3, 4, 5, 6, 7))
     strip = lambda c: {k: v for k, v in c.items() if k != "reserved"}   # (reserved = fallback-slab count)
-    assert all(strip(images[v][1]) == strip(images[2][1]) for v in (1, 3, 4, 5, 6))
+    assert all(strip(images[v][1]) == strip(images[2][1]) for v in (1, 3, 4, 5, 6, 7))
     cnt = images[2][1]
     # the prepared-reciprocal slab test is really in use: only a small share of segments falls back
     assert images[4][1]["reserved"] < 0.05 * cnt["rays"]

@@ -39,6 +39,8 @@ struct mi3pt_ctx {
     // scene (device)
     void *d_tris = nullptr, *d_nodes = nullptr, *d_mats = nullptr, *d_env = nullptr, *d_cdf = nullptr;
     void *d_packets = nullptr, *d_tripk = nullptr;
+    void *d_leaf_rank = nullptr;          // per triangle: position of its leaf in the reference's visiting order
+    int leaf_cap = 0;                     // LDS slots left for deferred leaves (0 = scene must be walked in order)
     size_t ntris = 0, nnodes = 0, nmats = 0, npackets = 0;
     uint32_t root_ref = 0;
     uint32_t scene_flags = 0;
@@ -67,6 +69,7 @@ struct mi3pt_ctx {
 
     int storage = MI3PT_STORAGE_F32;
     int variant = 0;
+    int leaf_min = 32;          // deferred-leaf walk: lanes with a parked leaf that trigger a triangle step (MI3PT_LEAF_MIN)
     int walk_min = 32;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
     int waves_per_cu = 16;      // 8 KB of LDS per one-wave workgroup, 128 VGPRs
     int top_packets = 64;       // MI3PT_TOP_PACKETS
@@ -177,6 +180,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     if (ctx->batch_max < 1) ctx->batch_max = 1;
     if (ctx->batch_max > 16) ctx->batch_max = 16;
     if (const char *e = std::getenv("MI3PT_WAVES_PER_CU")) ctx->waves_per_cu = std::atoi(e);
+    if (const char *e = std::getenv("MI3PT_LEAF_MIN")) ctx->leaf_min = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_TOP_PACKETS")) ctx->top_packets = std::atoi(e);
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
@@ -221,7 +225,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
     for (int k = 0; k < 2; k++)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     free_textures(ctx);
-    for (void *p : { ctx->d_tris, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk,
+    for (void *p : { ctx->d_tris, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
                      (void *)ctx->d_tile_counter, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
@@ -264,7 +268,7 @@ extern "C" int mi3pt_set_storage(mi3pt_ctx *ctx, int storage)
 extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
-    if (variant < 0 || variant > 6) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..6");
+    if (variant < 0 || variant > 7) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..7");
     if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
     return MI3PT_OK;
@@ -414,8 +418,49 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
         p.flags = ((left >= 0 && !box_safe((size_t)left)) ? 1u : 0u) | ((right >= 0 && !box_safe((size_t)right)) ? 2u : 0u) |
                   ((left < 0 || right < 0) ? 4u : 0u);      // bit2: a child is missing (never from flattenBVH)
     }
+    // Order analysis for the deferred-leaf kernel (pt_kernels.hip, DEFER): the reference walk
+    // visits leaves in a fixed order (node, right subtree, left subtree: left is pushed first,
+    // raytrace.wgsl:184-198) and keeps the FIRST of equal-t hits.  If the buffer is a proper
+    // tree (every node reached exactly once, every triangle owned by at most one leaf, no
+    // missing child) that order is a per-triangle rank, and testing leaves in any order and
+    // resolving ties by rank gives the same hit -- provided the 64-entry abort cannot fire,
+    // i.e. the walk's worst-case stack occupancy (every box hit) stays below 64.
+    std::vector<uint32_t> leaf_rank((size_t)(max_tri + 1 > 0 ? max_tri + 1 : 1), 0xffffffffu);
+    int leaf_cap = 0;
+    {
+        std::vector<uint32_t> st;
+        std::vector<uint8_t> seen(n, 0);
+        st.push_back(0);
+        size_t visited = 0, worst = 0;
+        uint32_t rank = 0;
+        bool proper = true;
+        while (!st.empty() && proper) {
+            if (st.size() > worst) worst = st.size();
+            const uint32_t node = st.back();
+            st.pop_back();
+            if (seen[node]) { proper = false; break; }
+            seen[node] = 1;
+            visited++;
+            const uint8_t *r = src + (size_t)node * MI3PT_BVHNODE_STRIDE;
+            if (ldi(r, 28) == 1) {
+                const int32_t ti = ldi(r, 40);
+                if (leaf_rank[(size_t)ti] != 0xffffffffu) { proper = false; break; }
+                leaf_rank[(size_t)ti] = rank++;
+            } else {
+                const int32_t left = ldi(r, 32), right = ldi(r, 36);
+                if (left < 0 || right < 0) { proper = false; break; }
+                st.push_back((uint32_t)left);
+                st.push_back((uint32_t)right);
+            }
+        }
+        // LDS holds 32 entries per lane: the node stack from the bottom, deferred leaves from the top
+        if (proper && worst <= 28) leaf_cap = 32 - (int)worst;
+        (void)visited;      // nodes the root does not reach are never walked by the reference either
+    }
     if (int rc = replace_buffer(ctx, &ctx->d_nodes, bytes, nbytes)) return rc;
     if (int rc = replace_buffer(ctx, &ctx->d_packets, pk.data(), pk.size() * sizeof(pt::NodePacket))) return rc;
+    if (int rc = replace_buffer(ctx, &ctx->d_leaf_rank, leaf_rank.data(), leaf_rank.size() * sizeof(uint32_t))) return rc;
+    ctx->leaf_cap = leaf_cap;
     ctx->nnodes = n;
     ctx->npackets = npackets;
     ctx->root_ref = ref_of(0);
@@ -539,6 +584,8 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.env = static_cast<const float4 *>(ctx->d_env);
     s.packets = static_cast<const float4 *>(ctx->d_packets);
     s.tripk = static_cast<const float4 *>(ctx->d_tripk);
+    s.leaf_rank = static_cast<const uint32_t *>(ctx->d_leaf_rank);
+    s.leaf_cap = ctx->leaf_cap;
     s.ntris = (uint32_t)ctx->ntris; s.nnodes = (uint32_t)ctx->nnodes; s.nmats = (uint32_t)ctx->nmats;
     s.npackets = (uint32_t)ctx->npackets;
     s.root_ref = ctx->root_ref;
@@ -561,7 +608,13 @@ static int check_scene(const mi3pt_ctx *ctx)
 }
 
 // 0 = auto -> the persistent kernel; the probes only know the two per-ray walks.
-static int pick_variant(const mi3pt_ctx *ctx) { return ctx->variant == 0 ? 4 : ctx->variant; }
+static int pick_variant(const mi3pt_ctx *ctx)
+{
+    const bool defer_ok = ctx->leaf_cap >= 4;      // see mi3pt_upload_bvh: leaves may be tested out of order
+    if (ctx->variant == 0) return defer_ok ? 7 : 4;
+    if (ctx->variant == 7 && !defer_ok) return 4;
+    return ctx->variant;
+}
 // the walk the probe runs: 1 = uploaded records, 2 = packets, 3 = packets + prepared-reciprocal slab test
 static int pick_walk(const mi3pt_ctx *ctx) { return ctx->variant == 0 ? 3 : (ctx->variant >= 4 ? 3 : (ctx->variant == 3 ? 2 : ctx->variant)); }
 
@@ -595,6 +648,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.stack_overflow = ctx->d_stack_overflow;
     L.store_f16 = ctx->storage == MI3PT_STORAGE_F16;
     L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
+    L.leaf_min = ctx->leaf_min;
     L.waves_per_cu = ctx->waves_per_cu;
     L.top_packets = ctx->top_packets;
     return L;
@@ -931,8 +985,8 @@ extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out,
     if (!out) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (enable && !ctx->d_wave_times) {
-            HIP_TRY(hipMalloc((void **)&ctx->d_wave_times, (size_t)slots * 64));
-            HIP_TRY(hipMemset(ctx->d_wave_times, 0, (size_t)slots * 64));
+            HIP_TRY(hipMalloc((void **)&ctx->d_wave_times, (size_t)slots * 128));
+            HIP_TRY(hipMemset(ctx->d_wave_times, 0, (size_t)slots * 128));
             ctx->wave_times_slots = slots;
         } else if (!enable && ctx->d_wave_times) {
             (void)hipFree(ctx->d_wave_times);
@@ -943,7 +997,7 @@ extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out,
     }
     if (!ctx->d_wave_times) return pt_set_error(MI3PT_ERR_STATE, "wave times are not enabled");
     if (capacity_slots < (size_t)ctx->wave_times_slots) return pt_set_error(MI3PT_ERR_INVALID, "buffer too small");
-    HIP_TRY(hipMemcpyAsync(out, ctx->d_wave_times, (size_t)ctx->wave_times_slots * 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_wave_times, (size_t)ctx->wave_times_slots * 128, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (slots_out) *slots_out = (size_t)ctx->wave_times_slots;
     return MI3PT_OK;

@@ -47,6 +47,8 @@ struct SceneRefs {
     const float4 *env;      // rgba32float texels
     const float4 *packets;  // NodePacket array (internal nodes, breadth-first), or null
     const float4 *tripk;    // TriPacket array, or null
+    const uint32_t *leaf_rank;  // per triangle: rank of its leaf in the reference's visiting order
+    int32_t leaf_cap;       // > 0: leaves may be tested out of order; LDS slots available for deferred leaves
     uint32_t ntris, nnodes, nmats, npackets;
     uint32_t root_ref;      // reference of node 0 in packet terms
     uint32_t flags;         // bit0: every ROOT box coordinate is 0 or within [2^-70, 2^60]
@@ -95,6 +97,7 @@ struct RtLaunch {
     uint64_t *wave_times;        // diagnostic: [grid][4] begin / feed-empty / end (100 MHz) + shader cycles, or null
     int32_t store_f16;
     int32_t walk_min;            // state-machine kernel: walk while at least this many lanes are walking
+    int32_t leaf_min;            // deferred-leaf walk: run a triangle step once this many lanes have a leaf parked
     int32_t top_packets;         // node packets to stage in LDS per wave (0..64)
     int32_t waves_per_cu;        // persistent kernels: resident one-wave workgroups per CU
 };

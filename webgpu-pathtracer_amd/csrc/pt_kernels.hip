@@ -849,8 +849,8 @@ enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
 // variant 6).  Measured on MI355X (round 1): no gain -- the kernel is
 // VALU-issue-bound and the top of the tree is L1-resident anyway, while the second load path
 // costs registers -- so the shipped default keeps TOPLDS = false.
-// (5 waves per SIMD = 96 VGPRs spills 53 registers and runs 28 % slower: profiles/r01_g_occupancy_*.log)
-template <bool FUSE, bool TOPLDS>
+// (5 waves per SIMD = 96 VGPRs spills 53 registers and runs 28 % slower: profiles/r01_g_rejected_experiments.log)
+template <bool FUSE, bool TOPLDS, bool DEFER>
 __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
 {
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
@@ -907,7 +907,8 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     uint64_t t_empty_rt = 0ull;
     // diagnostic step statistics (wave-uniform; stored with the stamps)
     uint32_t st_walk_steps = 0, st_walk_lanes = 0, st_leaf_lanes = 0, st_service_steps = 0;
-    uint32_t st_shade_lanes = 0, st_hit_lanes = 0, st_path_lanes = 0, st_segment_lanes = 0;
+    uint32_t st_shade_lanes = 0, st_hit_lanes = 0, st_path_lanes = 0, st_segment_lanes = 0, st_tri_steps = 0;
+    const int lcap = L.scene.leaf_cap;      // DEFER: capacity of a lane's leaf list
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
     int mode = M_DEAD;
@@ -915,6 +916,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     uint32_t gx = 0u, gy = 0u, ly = 0u, seed = 0u, slot = 0u;
     int32_t bounce = 0, sample = 0;
     int sp = 0;
+    int nl = 0;              // DEFER: leaves waiting in this lane's list (LDS slots 31, 30, ...)
     Best best;
     best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
     RayPre pre;
@@ -939,6 +941,71 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         serviceable = __ballot(mode == M_SHADE) != 0ull || (!feed_empty && __ballot(mode == M_DEAD) != 0ull);
         const int nwalk = (int)__popcll(walking);
         if (!(nwalk > 0 && (nwalk >= L.walk_min || !serviceable))) break;
+        if (DEFER) {
+            // ---- deferred-leaf walk (scenes whose leaves may be tested in any order: SceneRefs::
+            // leaf_cap > 0).  In the in-order walk below a step runs the box tests for ~39 lanes
+            // AND the triangle test for ~11, one after the other.  Here a leaf whose box is hit is
+            // parked in the lane's leaf list (LDS slots 31 downwards; the node stack grows from
+            // slot 0) while the lane goes on descending; the triangle test runs as a step of its
+            // own once enough lanes have a leaf parked (or nothing else is left to do).  The set
+            // of boxes and triangles tested is the one of the reference walk (it has no culling),
+            // so the counters are unchanged, and the closest hit is the same because equal-t hits
+            // are resolved by the leaf's rank in the reference's visiting order (strict '<' there
+            // keeps the first visited, raytrace.wgsl:180).
+            const bool trav = mode == M_TRAV;
+            const bool has_node = trav && sp > 0, has_leaf = trav && nl > 0;
+            const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
+            const bool full = __ballot(trav && nl > lcap - 2) != 0ull;      // a node step may park two more
+            if (full || n_node == 0 || n_leaf >= L.leaf_min) {
+                if (L.wave_times) { st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; }
+                if (has_leaf) {
+                    nl--;
+                    const uint32_t ti = stack[(PT_SM_LDS_DEPTH - 1 - nl) * 64];
+                    const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
+                    const float4 pb = sc.tripk[(size_t)ti * 3 + 1];
+                    const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
+                    cnt.tri++;
+                    float t, u, v;
+                    if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v)) {
+                        bool take = t < best.t;
+                        if (t == best.t && best.tri >= 0)      // rare: the earlier leaf of the reference order wins
+                            take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
+                        if (take) { best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti; }
+                    }
+                    if (sp == 0 && nl == 0) mode = M_SHADE;
+                }
+            } else {
+                if (L.wave_times) { st_walk_steps++; st_walk_lanes += (uint32_t)n_node; }
+                if (has_node) {
+                    sp--;
+                    const uint32_t ref = stack[sp * 64];
+                    const float4 p0 = sc.packets[(size_t)ref * 4 + 0], p1 = sc.packets[(size_t)ref * 4 + 1];
+                    const float4 p2 = sc.packets[(size_t)ref * 4 + 2], p3 = sc.packets[(size_t)ref * 4 + 3];
+                    const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
+                    const uint32_t pf = __float_as_uint(p3.z);
+                    cnt.box += 2;                  // proper tree: both children exist
+                    bool hl, hr;
+                    if (((pre.flags & 8u) | pf) == 0u) {
+                        hl = ray_aabb_fast(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                        hr = ray_aabb_fast(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
+                    } else {
+                        hl = ray_aabb_pre(o, d, pre, (pf & 1u) != 0u, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                        hr = ray_aabb_pre(o, d, pre, (pf & 2u) != 0u, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
+                    }
+                    // sp + nl <= 30 here (leaf_cap = 32 - worst-case stack, nl <= leaf_cap - 2), so slot sp
+                    // and slot 31 - nl are both free: the stores are unconditional, the counts select
+                    const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
+                    stack[(ll ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = ll ? (lref & 0x7fffffffu) : lref;
+                    nl += (hl && ll) ? 1 : 0;
+                    sp += (hl && !ll) ? 1 : 0;
+                    stack[(rl ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = rl ? (rref & 0x7fffffffu) : rref;
+                    nl += (hr && rl) ? 1 : 0;
+                    sp += (hr && !rl) ? 1 : 0;
+                    if (sp == 0 && nl == 0) mode = M_SHADE;
+                }
+            }
+            continue;
+        }
         {
             // ---- walk step: one pop per walking lane (raytrace.wgsl:166-200)
             if (L.wave_times) { st_walk_steps++; st_walk_lanes += (uint32_t)nwalk; }
@@ -1163,8 +1230,13 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (pre.flags & 8u) cnt.slow++;
                 cnt.box++;
                 if (ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
-                    st_store(0, sc.root_ref);
-                    sp = 1;
+                    if (DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
+                        stack[(PT_SM_LDS_DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu;
+                        sp = 0; nl = 1;
+                    } else {
+                        st_store(0, sc.root_ref);
+                        sp = 1; nl = 0;
+                    }
                     mode = M_TRAV;
                 }
             }
@@ -1172,7 +1244,8 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     }
 
     if (L.wave_times && lane == 0) {
-        uint64_t *w = L.wave_times + (size_t)blockIdx.x * 8;
+        uint64_t *w = L.wave_times + (size_t)blockIdx.x * 16;
+        w[8] = st_tri_steps;
         w[0] = t_begin_rt;
         w[1] = t_empty_rt;
         w[2] = __builtin_amdgcn_s_memrealtime();
@@ -1229,11 +1302,14 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
             if (fuse) hipLaunchKernelGGL((k_raytrace_persistent<true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_persistent<false>), grid, block, 0, s, L);
         } else if (variant == 6) {
-            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, true>), grid, block, 0, s, L);
-            else hipLaunchKernelGGL((k_raytrace_sm<false, true>), grid, block, 0, s, L);
+            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, true, false>), grid, block, 0, s, L);
+            else hipLaunchKernelGGL((k_raytrace_sm<false, true, false>), grid, block, 0, s, L);
+        } else if (variant == 7) {
+            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true>), grid, block, 0, s, L);
+            else hipLaunchKernelGGL((k_raytrace_sm<false, false, true>), grid, block, 0, s, L);
         } else {
-            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false>), grid, block, 0, s, L);
-            else hipLaunchKernelGGL((k_raytrace_sm<false, false>), grid, block, 0, s, L);
+            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, false>), grid, block, 0, s, L);
+            else hipLaunchKernelGGL((k_raytrace_sm<false, false, false>), grid, block, 0, s, L);
         }
         return;
     }

@@ -309,7 +309,7 @@ class Context:
         self._c(self.lib.mi3pt_debug_wave_times(self.handle, int(enabled), None, 0, None))
 
     def wave_times(self):
-        out = np.zeros((6144, 8), np.uint64)
+        out = np.zeros((6144, 16), np.uint64)
         n = ctypes.c_size_t()
         self._c(self.lib.mi3pt_debug_wave_times(self.handle, 1, _ptr(out), len(out), ctypes.byref(n)))
         return out[:n.value]
