@@ -15,11 +15,17 @@
 //
 // Output: mismatch counts of the short and long forms (and of q0 alone, to show the check has
 // teeth), and the d significands for which the short form fails, if any.
+//
+// `div_proof rcp` instead checks, for ALL 2^32 binary32 inputs d, whether one Newton step on the
+// hardware reciprocal,  y0 = v_rcp_f32(d);  y1 = RN(y0 + RN(1 - d*y0)*y0),  equals RN(1/d)
+// (the IEEE division the compiler expands to 11 instructions), and prints the magnitude range
+// of d over which it always does.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <string>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -61,8 +67,56 @@ __global__ void __launch_bounds__(256) k_check(uint32_t d_first, Result *res)
     }
 }
 
+struct RcpResult {
+    unsigned long long bad, bad_raw;
+    unsigned int min_bad_abs, max_bad_abs;     // magnitude bits of failing |d| inside [2^-64, 2^64]
+    unsigned long long bad_inside;
+    unsigned int first_bad[16];
+    unsigned int nfirst;
+};
+
+__global__ void __launch_bounds__(256) k_check_rcp(uint32_t first, RcpResult *res)
+{
+    const uint32_t bits = first + blockIdx.x * blockDim.x + threadIdx.x;
+    const float d = __uint_as_float(bits);
+    const float want = 1.0f / d;
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float y1 = fmaf(fmaf(-d, y0, 1.0f), y0, y0);
+    const bool nan_both = (want != want) && (y1 != y1);
+    if (y0 != want && !((want != want) && (y0 != y0))) atomicAdd(&res->bad_raw, 1ull);
+    if (y1 != want && !nan_both) {
+        atomicAdd(&res->bad, 1ull);
+        const uint32_t mag = bits & 0x7fffffffu;
+        if (mag >= 0x1f800000u && mag <= 0x5f800000u) {        // 2^-64 .. 2^64
+            atomicAdd(&res->bad_inside, 1ull);
+            atomicMin(&res->min_bad_abs, mag);
+            atomicMax(&res->max_bad_abs, mag);
+            const unsigned int slot = atomicAdd(&res->nfirst, 1u);
+            if (slot < 16) res->first_bad[slot] = bits;
+        }
+    }
+}
+
+static int check_rcp()
+{
+    RcpResult *dres, h{};
+    h.min_bad_abs = 0xffffffffu;
+    CHECK(hipMalloc((void **)&dres, sizeof(RcpResult)));
+    CHECK(hipMemcpy(dres, &h, sizeof(RcpResult), hipMemcpyHostToDevice));
+    for (uint32_t c = 0; c < 256; c++) {
+        hipLaunchKernelGGL(k_check_rcp, dim3((1u << 24) / 256), dim3(256), 0, 0, c << 24, dres);
+        CHECK(hipDeviceSynchronize());
+    }
+    CHECK(hipMemcpy(&h, dres, sizeof(RcpResult), hipMemcpyDeviceToHost));
+    std::printf("RESULT rcp: all 2^32 inputs; v_rcp_f32 alone differs from RN(1/d) for %llu; after one Newton step %llu differ, "
+                "%llu of them with |d| in [2^-64, 2^64]\n", h.bad_raw, h.bad, h.bad_inside);
+    for (unsigned int i = 0; i < h.nfirst && i < 16; i++) std::printf("  failing d bits 0x%08x\n", h.first_bad[i]);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "rcp") return check_rcp();
     const uint32_t chunk = 1u << 18;                       // d significands per launch
     const uint32_t nchunks_all = (1u << 23) / chunk;       // 32
     uint32_t first = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 0;

@@ -132,6 +132,18 @@ PT_DEV float div_pre(float n, float d, float y)
     return fmaf(fmaf(-d, q0, n), y, q0);
 }
 
+// RN(1/d) without the 11-instruction division expansion: one Newton step on the hardware
+// reciprocal.  profiles/div_proof.hip (mode "rcp") checks ALL 2^32 inputs on gfx950: the result
+// equals the IEEE quotient 1.0f/d for every |d| in [2^-64, 2^64] (v_rcp_f32 alone is off for
+// 5e8 of them); outside that range, and for NaN, the plain division is used.
+PT_DEV float rcp_exact(float d)
+{
+    const float a = fabsf(d);
+    if (!(a >= 5.421010862427522e-20f && a <= 1.8446744073709552e19f)) return 1.0f / d;
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, y0, 1.0f), y0, y0);
+}
+
 PT_DEV bool safe_magnitude(float v)
 {
     const float a = fabsf(v);
@@ -145,9 +157,9 @@ PT_DEV RayPre ray_prepare(const f3 &o, const f3 &d, uint32_t scene_flags)
     // A parallel axis (|d| < EPSILON, raytrace.wgsl:129-133) is rare; such rays take the
     // plain test, which keeps selects out of the fast path below.
     const bool px = fabsf(d.x) < PT_EPSILON, py = fabsf(d.y) < PT_EPSILON, pz = fabsf(d.z) < PT_EPSILON;
-    p.ix = 1.0f / d.x;
-    p.iy = 1.0f / d.y;
-    p.iz = 1.0f / d.z;
+    p.ix = rcp_exact(d.x);
+    p.iy = rcp_exact(d.y);
+    p.iz = rcp_exact(d.z);
     // range guards (no residual may under- or overflow)
     const bool bad_x = fabsf(d.x) > 1048576.0f, bad_y = fabsf(d.y) > 1048576.0f, bad_z = fabsf(d.z) > 1048576.0f;
     const bool slow = px || py || pz || bad_x || bad_y || bad_z || !safe_magnitude(o.x) ||
@@ -190,7 +202,7 @@ PT_DEV bool ray_triangle(const f3 &o, const f3 &d, const f3 &a, const f3 &b, con
     const f3 h = cross(d, edge2);
     const float det = dot(edge1, h);
     if (det > -PT_EPSILON && det < PT_EPSILON) return false;
-    const float f = 1.0f / det;
+    const float f = rcp_exact(det);
     const f3 s = o - a;
     const float u = f * dot(s, h);
     if (u < 0.0f || u > 1.0f) return false;
@@ -938,7 +950,8 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         bool serviceable;
         for (;;) {
         const unsigned long long walking = __ballot(mode == M_TRAV);
-        serviceable = __ballot(mode == M_SHADE) != 0ull || (!feed_empty && __ballot(mode == M_DEAD) != 0ull);
+        // a lane that is not walking waits for shading or (while jobs are left) for a new job
+        serviceable = feed_empty ? (__ballot(mode == M_SHADE) != 0ull) : (walking != ~0ull);
         const int nwalk = (int)__popcll(walking);
         if (!(nwalk > 0 && (nwalk >= L.walk_min || !serviceable))) break;
         if (DEFER) {
