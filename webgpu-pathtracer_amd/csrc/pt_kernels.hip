@@ -906,12 +906,21 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     const int ntiles = ntiles_frame * L.nframes;
     const uint32_t res_w = (uint32_t)un.res_x, res_h = (uint32_t)un.res_y;
 
-    const CameraFrame cf = camera_frame(un);
+    // Launch-invariant values are computed (or loaded) by vector instructions and would sit in
+    // vector registers for the whole kernel; they are the same in every lane, so readfirstlane
+    // moves them to scalar registers and frees ~25 VGPRs for the walk.
+    auto uni = [](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+    auto uni3 = [&](const f3 &a) { return F3(uni(a.x), uni(a.y), uni(a.z)); };
+    CameraFrame cf = camera_frame(un);
+    cf.t = uni(cf.t); cf.r = uni(cf.r); cf.w = uni3(cf.w); cf.u_dir = uni3(cf.u_dir); cf.v_dir = uni3(cf.v_dir);
     const f3 cam_pos = F3(un.cam_pos[0], un.cam_pos[1], un.cam_pos[2]);
     float sinr, cosr;
     ptm::sincos(un.env_rotation, sinr, cosr);
+    sinr = uni(sinr); cosr = uni(cosr);
     float4 root0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), root1 = root0;
     if (sc.nnodes != 0) { root0 = sc.nodes[0]; root1 = sc.nodes[1]; }
+    root0 = make_float4(uni(root0.x), uni(root0.y), uni(root0.z), uni(root0.w));
+    root1 = make_float4(uni(root1.x), uni(root1.y), uni(root1.z), uni(root1.w));
 
     // diagnostic stamps (only when a buffer is bound): wall clock (100 MHz) and shader clock
     const uint64_t t_begin_rt = L.wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
