@@ -1,0 +1,286 @@
+"""Asset ingestion: glTF / GLB / OBJ meshes placed like src/main.ts:251-279
+and Radiance .hdr environment maps (main.ts:41-46), in the Python host and the Node host.  The
+files are generated here (there are no sample assets in the reference's tests)."""
+import json
+import math
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from mi3pt_host import capi, layout, meshio, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JS = os.path.join(ROOT, "webgpu-pathtracer_amd", "js")
+NODE = shutil.which("node")
+
+
+def _pad4(b, fill=b"\x00"):
+    return b + fill * ((4 - len(b) % 4) % 4)
+
+
+def make_glb():
+    """Two root nodes: a TRS node with a child given by a matrix (both with meshes), and a two-primitive
+    mesh; interleaved position/normal view with byteStride, u16 and u32 indices, one primitive
+    without normals, one non-indexed primitive (dropped by the reference's flatten)."""
+    sphere = scenes.sphere_geometry(0.7, 12, 8)
+    box = scenes.box_geometry(1.0, 0.5, 0.25)
+    plane = scenes.plane_geometry(2.0, 1.0, 3, 2)
+    blob = b""
+    views, accessors = [], []
+
+    def add_view(data, stride=None):
+        nonlocal blob
+        off = len(blob)
+        blob = _pad4(blob + data)
+        v = {"buffer": 0, "byteOffset": off, "byteLength": len(data)}
+        if stride:
+            v["byteStride"] = stride
+        views.append(v)
+        return len(views) - 1
+
+    def add_accessor(view, ctype, count, atype, offset=0):
+        accessors.append({"bufferView": view, "componentType": ctype, "count": count, "type": atype, "byteOffset": offset})
+        return len(accessors) - 1
+
+    # sphere: interleaved position+normal (stride 24), u16 indices
+    v, n, i = sphere
+    inter = np.concatenate([v.astype("<f4"), n.astype("<f4")], axis=1).tobytes()
+    sv = add_view(inter, 24)
+    s_pos, s_nrm = add_accessor(sv, 5126, len(v), "VEC3", 0), add_accessor(sv, 5126, len(v), "VEC3", 12)
+    s_idx = add_accessor(add_view(i.astype("<u2").tobytes()), 5123, len(i), "SCALAR")
+    # box: separate views, u32 indices
+    v, n, i = box
+    b_pos = add_accessor(add_view(v.astype("<f4").tobytes()), 5126, len(v), "VEC3")
+    b_nrm = add_accessor(add_view(n.astype("<f4").tobytes()), 5126, len(v), "VEC3")
+    b_idx = add_accessor(add_view(i.astype("<u4").tobytes()), 5125, len(i), "SCALAR")
+    # plane: no normals (computeVertexNormals), u8 indices
+    v, n, i = plane
+    p_pos = add_accessor(add_view(v.astype("<f4").tobytes()), 5126, len(v), "VEC3")
+    p_idx = add_accessor(add_view(i.astype("<u1").tobytes()), 5121, len(i), "SCALAR")
+    # a non-indexed triangle soup
+    soup = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], "<f4")
+    t_pos = add_accessor(add_view(soup.tobytes()), 5126, 3, "VEC3")
+    q = scenes.quaternion_from_axis_angle((0.0, 0.6, 0.8), 0.9)
+    child = scenes.compose_matrix((0.3, -0.2, 0.1), scenes.quaternion_from_axis_angle((1.0, 0.0, 0.0), -0.4), (0.5, 0.75, -1.25))
+    gltf = {
+        "asset": {"version": "2.0"},
+        "scene": 0,
+        "scenes": [{"nodes": [0, 2]}],
+        "nodes": [
+            {"name": "trs", "mesh": 0, "translation": [0.5, 1.0, -0.25], "rotation": list(q), "scale": [1.5, 1.0, 0.8], "children": [1]},
+            {"name": "matrix child", "mesh": 1, "matrix": child},
+            {"name": "two primitives", "mesh": 2, "translation": [-1.0, 0.0, 0.5]},
+        ],
+        "meshes": [
+            {"primitives": [{"attributes": {"POSITION": s_pos, "NORMAL": s_nrm}, "indices": s_idx}]},
+            {"primitives": [{"attributes": {"POSITION": b_pos, "NORMAL": b_nrm}, "indices": b_idx, "mode": 4}]},
+            {"primitives": [{"attributes": {"POSITION": p_pos}, "indices": p_idx},
+                            {"attributes": {"POSITION": t_pos}},
+                            {"attributes": {"POSITION": p_pos}, "indices": p_idx, "mode": 1}]},
+        ],
+        "buffers": [{"byteLength": len(blob)}],
+        "bufferViews": views,
+        "accessors": accessors,
+    }
+    js = _pad4(json.dumps(gltf).encode("utf8"), b" ")
+    body = struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(blob), 0x004E4942) + blob
+    return struct.pack("<III", 0x46546C67, 2, 12 + len(body)) + body, gltf, blob
+
+
+def make_obj():
+    v, n, i = scenes.sphere_geometry(1.0, 8, 6)
+    lines = ["# generated"]
+    lines += [f"v {float(a)!r} {float(b)!r} {float(c)!r}" for a, b, c in v.astype(np.float32)]
+    lines += [f"vn {float(a)!r} {float(b)!r} {float(c)!r}" for a, b, c in n.astype(np.float32)]
+    tri = i.reshape(-1, 3) + 1
+    lines += [f"f {a}//{a} {b}//{b} {c}//{c}" for a, b, c in tri]
+    lines += ["f 10 11 20 19"]                             # a quad without normals -> fan, normals recomputed
+    return "\n".join(lines) + "\n"
+
+
+def make_hdr(width=64, height=16, rle=True):
+    """RGBE file of a smooth gradient with a bright spot; returns (bytes, rgbe array)."""
+    y, x = np.mgrid[0:height, 0:width]
+    rgb = np.stack([0.5 + 0.4 * np.sin(x / 7.0), 0.02 * (y + 1.0), 1e-3 * (x + 1.0) * (y + 1.0)], -1)
+    rgb[3, 5] = (900.0, 450.0, 12.0)
+    m = rgb.max(-1)
+    e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, -128).astype(np.int64)
+    scale = np.where(m > 1e-32, 256.0 / np.power(2.0, e), 0.0)
+    rgbe = np.zeros((height, width, 4), np.uint8)
+    rgbe[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    rgbe[..., 3] = np.where(m > 1e-32, e + 128, 0).astype(np.uint8)
+    rgbe[2, :20] = (7, 7, 7, 120)                          # a run, so the RLE path sees run packets
+    head = b"#?RADIANCE\n# test\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (height, width)
+    if not rle:
+        return head + rgbe.tobytes(), rgbe
+    out = bytearray(head)
+    for row in rgbe:
+        out += bytes([2, 2, width >> 8, width & 255])
+        for c in range(4):
+            chan, i = row[:, c], 0
+            while i < width:
+                run = 1
+                while i + run < width and run < 127 and chan[i + run] == chan[i]:
+                    run += 1
+                if run >= 4:
+                    out += bytes([128 + run, int(chan[i])])
+                    i += run
+                else:
+                    j = i
+                    while j < width and j - i < 128:
+                        if j + 3 < width and chan[j] == chan[j + 1] == chan[j + 2] == chan[j + 3]:
+                            break
+                        j += 1
+                    j = max(j, i + 1)
+                    out += bytes([j - i]) + chan[i:j].tobytes()
+                    i = j
+    return bytes(out), rgbe
+
+
+def test_glb_loads_and_is_placed_like_the_reference(built, tmp_path):
+    glb, gltf, blob = make_glb()
+    root = meshio.load_gltf(glb)
+    names = [n.name for n in root.traverse()]
+    assert names[:3] == ["scene", "trs", "matrix child"]
+    # matrix node: decompose -> compose reproduces the matrix (negative scale through the determinant)
+    child = root.children[0].children[0]
+    m = scenes.compose_matrix(child.position, child.quaternion, child.scale)
+    assert np.allclose(m, gltf["nodes"][1]["matrix"], atol=1e-12) and child.scale[0] < 0
+    # main.ts:268-274: the bounds are taken with the model at (0, 0.5, 0) and scale 1; the scale is
+    # 1 / max(bounds.max) about the model's origin (so the placed model is not a unit box: a quirk kept)
+    root.position = (0.0, 0.5, 0.0)
+    _, hi0 = meshio.bounds_of(root)
+    meshio.place_model(root)
+    assert root.position == (0.0, 0.5, 0.0) and root.scale == (1 / max(hi0),) * 3
+    sc = meshio.to_scene(root)
+    nsphere, nbox, nplane = 12 * 8 * 2 - 2 * 12, 12, 3 * 2 * 2
+    assert len(sc.triangles) == nsphere + nbox + nplane          # the soup and the LINES primitive are dropped
+    assert np.isfinite(sc.positions).all() and np.allclose(np.linalg.norm(sc.normals, axis=-1), 1.0, atol=1e-6)
+    nodes = sc.build_bvh()
+    assert len(nodes) == 2 * len(sc.triangles) - 1
+    # the same file as .gltf with an embedded base64 buffer, and with an external .bin
+    import base64
+    g2 = dict(gltf, buffers=[{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}])
+    sc2 = meshio.to_scene(meshio.place_model(meshio.load_gltf(json.dumps(g2))))
+    assert sc2.triangles.tobytes() == sc.triangles.tobytes()
+    (tmp_path / "m.bin").write_bytes(blob)
+    (tmp_path / "m.gltf").write_text(json.dumps(dict(gltf, buffers=[{"byteLength": len(blob), "uri": "m.bin"}])))
+    sc3 = meshio.load_model_scene(str(tmp_path / "m.gltf"))
+    assert sc3.triangles.tobytes() == sc.triangles.tobytes()
+
+
+def test_gltf_rejections():
+    with pytest.raises(ValueError, match="Draco"):
+        meshio.load_gltf({"asset": {"version": "2.0"}, "extensionsRequired": ["KHR_draco_mesh_compression"]})
+    with pytest.raises(ValueError, match="Unsupported asset"):
+        meshio.load_gltf({"asset": {"version": "1.0"}})
+    with pytest.raises(ValueError, match="bad magic"):
+        meshio._parse_glb(b"nope" + b"\0" * 16)
+    with pytest.raises(ValueError, match="empty"):
+        meshio.to_scene(meshio.load_gltf({"asset": {"version": "2.0"}, "nodes": [{}], "scenes": [{"nodes": [0]}]}))
+
+
+def test_obj_loads(built):
+    root = meshio.load_obj(make_obj())
+    pos, nrm, idx = root.children[0].geometry
+    assert len(idx) % 3 == 0 and idx.max() < len(pos)
+    sc = meshio.to_scene(meshio.place_model(root))
+    assert len(sc.triangles) == len(idx) // 3
+    assert np.allclose(np.linalg.norm(sc.normals, axis=-1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("rle", [True, False])
+def test_hdr_decoder_matches_the_rgbe_definition(rle):
+    data, rgbe = make_hdr(rle=rle)
+    img = meshio.load_hdr(data)
+    assert img.shape == (16, 64, 4) and (img[..., 3] == 1).all()
+    want = (rgbe[..., :3].astype(np.float64) * (np.power(2.0, rgbe[..., 3:].astype(np.float64) - 128.0) / 255.0)).astype(np.float32)
+    assert np.array_equal(img[..., :3], want)
+    assert img[3, 5, 0] > 800 and img[2, 0, 0] == np.float32(7 * 2.0 ** -8 / 255)
+    with pytest.raises(ValueError, match="bad initial token"):
+        meshio.load_hdr(b"P6\n1 1\n255\n")
+
+
+def test_loaded_environment_feeds_the_cdf(built):
+    """A decoded 1024x512 map is what Renderer.updateEnvironmentTexture takes (renderer.ts:132-157)."""
+    data, _ = make_hdr(width=1024, height=512)
+    env = meshio.load_hdr(data)
+    assert env.shape == (layout.ENV_HEIGHT, layout.ENV_WIDTH, 4)
+    cdf = capi.host_env_cdf(env)
+    assert cdf.shape == env.shape and cdf[0, 0, 0] == 0.0 and np.all(np.diff(cdf[:, 0, 0]) >= 0)
+
+
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+def test_node_loaders_give_the_same_bytes(built, tmp_path):
+    glb, _, _ = make_glb()
+    (tmp_path / "model.glb").write_bytes(glb)
+    (tmp_path / "model.obj").write_text(make_obj())
+    hdr, _ = make_hdr()
+    (tmp_path / "env.hdr").write_bytes(hdr)
+    for name in ("model.glb", "model.obj"):
+        out = tmp_path / (name + ".out")
+        out.mkdir()
+        r = subprocess.run([NODE, os.path.join(JS, "tools", "dump_model.js"), str(tmp_path / name), str(out), "--hdr",
+                            str(tmp_path / "env.hdr")], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        summary = json.loads(r.stdout)
+        sc = meshio.load_model_scene(str(tmp_path / name))
+        sc.build_bvh()
+        assert summary["triangles"] == len(sc.triangles) and summary["width"] == 64 and summary["height"] == 16
+        assert (out / "triangles.bin").read_bytes() == sc.triangles.tobytes()
+        assert (out / "materials.bin").read_bytes() == sc.material_bytes.tobytes()
+        assert (out / "nodes.bin").read_bytes() == sc.nodes.tobytes()
+        assert (out / "env.f32").read_bytes() == meshio.load_hdr(hdr).tobytes()
+    r = subprocess.run([NODE, "-e", "const pt=require(process.argv[1]); try { new pt.GLTFLoader().parse({asset:{version:'2.0'},"
+                        "extensionsRequired:['KHR_draco_mesh_compression']}); } catch (e) { console.log(e.message); }", JS],
+                       capture_output=True, text=True, timeout=60)
+    assert "Draco" in r.stdout
+
+
+REF_ENV = "/root/reference/public/static/env"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_ENV), reason="the reference checkout (with its demo .hdr maps) is not on this machine")
+def test_the_reference_demo_environment_maps_decode(built, tmp_path):
+    """main.ts:29-46: the three 1k Radiance maps the demo cycles through.  They are read in place
+    (never copied); both hosts must decode them to the same 1024x512 float texels, which
+    Renderer.updateEnvironmentTexture accepts (renderer.ts:132-143)."""
+    names = sorted(n for n in os.listdir(REF_ENV) if n.endswith(".hdr"))
+    assert len(names) == 3
+    for name in names:
+        img = meshio.load_hdr(os.path.join(REF_ENV, name))
+        assert img.shape == (layout.ENV_HEIGHT, layout.ENV_WIDTH, 4) and np.isfinite(img).all() and (img[..., :3] >= 0).all()
+        assert 0.1 < float(img[..., :3].mean()) < 10 and float(img[..., :3].max()) > 100      # sky + sun / lamps
+        if NODE is not None:
+            r = subprocess.run([NODE, os.path.join(JS, "tools", "dump_model.js"), "-", str(tmp_path), "--hdr",
+                                os.path.join(REF_ENV, name)], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert (tmp_path / "env.f32").read_bytes() == img.tobytes()
+
+
+@pytest.mark.gpu
+def test_loaded_model_and_environment_render_like_the_oracle(gpu_ctx, orc, tmp_path):
+    """A generated .glb placed like main.ts:268-279 under a decoded .hdr map: device == oracle."""
+    import ptcommon as pc
+    glb, _, _ = make_glb()
+    sc = meshio.to_scene(meshio.place_model(meshio.load_gltf(glb)))
+    sc.build_bvh()
+    hdr, _ = make_hdr(width=1024, height=512)
+    env = meshio.load_hdr(hdr)
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, sc, env)
+    ctx.set_tile(0, 1, 8)
+    w, h = 80, 48
+    ctx.resize(w, h)
+    ctx.reset_counters()
+    u = pc.rt_uniforms(sc, w, h, frame=2, bounces=4)
+    pc.gpu_frame(ctx, u)
+    got, cnt = ctx.read_texture(capi.TEX_OUTPUT), ctx.counters()
+    want, ocnt = orc.raytrace(pc.oracle_scene(orc, sc, env), u.tobytes(), w, h)
+    assert pc.same_bits(got, want), pc.describe_diff(got, want)
+    assert cnt["hits"] == ocnt["hits"] > 0 and cnt["tri_tests"] == ocnt["tri_tests"]
+    ctx.resize(64, 64)

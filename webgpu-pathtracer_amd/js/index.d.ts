@@ -110,3 +110,17 @@ export class Renderer {
   flush(): void;
   raytraceLaunchStats(reset?: boolean): { totalMs: number; launches: number; frames: number };
 }
+
+/** src/main.ts:251-266 -- .glb / .gltf (no Draco) to a node hierarchy of indexed meshes */
+export class GLTFLoader {
+  parse(data: ArrayBuffer | Uint8Array | string | object, baseDir?: string): { scene: Object3D; scenes: Object3D[]; asset: object };
+  load(file: string): { scene: Object3D; scenes: Object3D[]; asset: object };
+}
+export class OBJLoader { parse(text: string): Object3D; load(file: string): Object3D; }
+/** src/main.ts:41-46 -- Radiance .hdr to RGBA float texels (FloatType) */
+export class RGBELoader { setDataType(type: number): this; parse(buffer: ArrayBuffer | Uint8Array): DataTexture; load(file: string): DataTexture; }
+/** the `white` material of src/main.ts:49-53 */
+export function whiteMaterial(): RaytracingMaterial;
+/** src/main.ts:268-279: position (0, 0.5, 0), uniform scale 1 / max(bounds.max), one material */
+export function placeModel(model: Object3D, material?: RaytracingMaterial): Object3D;
+export function boundsOfObject(object: Object3D): { min: Vector3; max: Vector3 };

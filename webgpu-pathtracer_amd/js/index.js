@@ -5,6 +5,7 @@
 module.exports = Object.assign({},
   require('./src/renderer'),
   require('./src/scene'),
+  require('./src/loaders'),
   require('./src/math3'),
   require('./src/layout'),
   require('./src/timing'),

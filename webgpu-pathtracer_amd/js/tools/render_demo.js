@@ -2,6 +2,8 @@
 // Headless equivalent of the reference's main loop (src/main.ts:374-400) on the default
 // scene: N calls of renderer.render(scene, camera), then read-back.
 //   node render_demo.js --env env.f32 --width 64 --height 64 --frames 3 --bounces 4 --out prefix
+//   --hdr file.hdr     a Radiance map (1024x512) instead of raw float texels (main.ts:41-46)
+//   --model file.glb   replace the default meshes by a loaded model (.glb/.gltf/.obj), main.ts:251-279
 // Writes <prefix>.acc.f32 (accumulation, RGBA float), <prefix>.canvas.rgba8 and prints a
 // JSON summary.  Needs a HIP device.
 const fs = require('fs');
@@ -26,6 +28,15 @@ async function main() {
   if (!diag.supported) throw new Error('HIP device not found.');
   const renderer = await pt.Renderer.create({ enableTimestampQuery: true });
   const { scene, camera } = buildDefaultScene(envData);
+  if (arg('hdr', null)) scene.environment = new pt.RGBELoader().setDataType(pt.FloatType).load(arg('hdr'));
+  const modelPath = arg('model', null);
+  if (modelPath) {
+    const model = /\.obj$/i.test(modelPath) ? new pt.OBJLoader().load(modelPath) : new pt.GLTFLoader().load(modelPath).scene;
+    pt.placeModel(model);
+    scene.clear();
+    scene.add(model);
+    scene.needsUpdate = true;
+  }
   const events = [];
   for (const ev of ['start', 'reset', 'progress', 'complete', 'resize']) renderer.on(ev, () => events.push(ev));
   renderer.frames = frames;
