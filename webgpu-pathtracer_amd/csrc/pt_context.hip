@@ -431,11 +431,14 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
         std::vector<uint32_t> st;
         std::vector<uint8_t> seen(n, 0);
         st.push_back(0);
-        size_t visited = 0, worst = 0;
+        size_t visited = 0, worst = 0, worst_internal = 0, internal = 0;     // stack occupancy: all entries / internal nodes only
         uint32_t rank = 0;
         bool proper = true;
+        auto is_leaf = [&](uint32_t node) { return ldi(src + (size_t)node * MI3PT_BVHNODE_STRIDE, 28) == 1; };
+        if (!is_leaf(0)) internal = 1;
         while (!st.empty() && proper) {
             if (st.size() > worst) worst = st.size();
+            if (internal > worst_internal) worst_internal = internal;
             const uint32_t node = st.back();
             st.pop_back();
             if (seen[node]) { proper = false; break; }
@@ -447,14 +450,18 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
                 if (leaf_rank[(size_t)ti] != 0xffffffffu) { proper = false; break; }
                 leaf_rank[(size_t)ti] = rank++;
             } else {
+                internal--;
                 const int32_t left = ldi(r, 32), right = ldi(r, 36);
                 if (left < 0 || right < 0) { proper = false; break; }
                 st.push_back((uint32_t)left);
                 st.push_back((uint32_t)right);
+                internal += (is_leaf((uint32_t)left) ? 0 : 1) + (is_leaf((uint32_t)right) ? 0 : 1);
             }
         }
-        // LDS holds 32 entries per lane: the node stack from the bottom, deferred leaves from the top
-        if (proper && worst <= 28) leaf_cap = 32 - (int)worst;
+        // The 64-entry abort (raytrace.wgsl:167-171) counts leaves too: it cannot fire while the
+        // worst case stays below 64.  LDS holds 32 entries per lane: the node stack (internal
+        // nodes only in the deferred walk) from the bottom, parked leaves from the top.
+        if (proper && worst < 64 && worst_internal <= 28) leaf_cap = 32 - (int)worst_internal;
         (void)visited;      // nodes the root does not reach are never walked by the reference either
     }
     if (int rc = replace_buffer(ctx, &ctx->d_nodes, bytes, nbytes)) return rc;
