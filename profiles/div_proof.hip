@@ -97,6 +97,52 @@ __global__ void __launch_bounds__(256) k_check_rcp(uint32_t first, RcpResult *re
     }
 }
 
+struct SqrtResult { unsigned long long bad_raw, bad_a, bad_b, bad_a_in, bad_b_in; unsigned int first_a[8], first_b[8], na, nb; };
+
+// all positive floats: candidates for a cheaper correctly rounded sqrt
+//   A: s0 = v_sqrt_f32(x); s1 = fma(fma(-s0, s0, x) * 0.5, v_rcp_f32(s0), s0)
+//   B: y = v_rsq_f32(x); s0 = x*y; s1 = fma(fma(-s0, s0, x), 0.5*y, s0)
+__global__ void __launch_bounds__(256) k_check_sqrt(uint32_t first, SqrtResult *res)
+{
+    const uint32_t bits = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (bits >= 0x7f800000u) return;
+    const float x = __uint_as_float(bits);
+    const float want = sqrtf(x);
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float a = fmaf(fmaf(-s0, s0, x) * 0.5f, __builtin_amdgcn_rcpf(s0), s0);
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float t0 = x * y;
+    const float b = fmaf(fmaf(-t0, t0, x), 0.5f * y, t0);
+    const bool inside = bits >= 0x1f800000u && bits <= 0x5f800000u;       // 2^-64 .. 2^64
+    if (s0 != want) atomicAdd(&res->bad_raw, 1ull);
+    if (a != want) {
+        atomicAdd(&res->bad_a, 1ull);
+        if (inside) { atomicAdd(&res->bad_a_in, 1ull); const unsigned int k = atomicAdd(&res->na, 1u); if (k < 8) res->first_a[k] = bits; }
+    }
+    if (b != want) {
+        atomicAdd(&res->bad_b, 1ull);
+        if (inside) { atomicAdd(&res->bad_b_in, 1ull); const unsigned int k = atomicAdd(&res->nb, 1u); if (k < 8) res->first_b[k] = bits; }
+    }
+}
+
+static int check_sqrt()
+{
+    SqrtResult *dres, h{};
+    CHECK(hipMalloc((void **)&dres, sizeof(SqrtResult)));
+    CHECK(hipMemset(dres, 0, sizeof(SqrtResult)));
+    for (uint32_t c = 0; c < 128; c++) {
+        hipLaunchKernelGGL(k_check_sqrt, dim3((1u << 24) / 256), dim3(256), 0, 0, c << 24, dres);
+        CHECK(hipDeviceSynchronize());
+    }
+    CHECK(hipMemcpy(&h, dres, sizeof(SqrtResult), hipMemcpyDeviceToHost));
+    std::printf("RESULT sqrt: all non-negative finite inputs; v_sqrt_f32 alone differs from RN(sqrt x) for %llu; "
+                "form A (sqrt, residual, rcp) %llu differ, %llu with x in [2^-64, 2^64]; form B (rsq) %llu differ, %llu in range\n",
+                h.bad_raw, h.bad_a, h.bad_a_in, h.bad_b, h.bad_b_in);
+    for (unsigned int i = 0; i < h.na && i < 8; i++) std::printf("  form A fails for x bits 0x%08x\n", h.first_a[i]);
+    for (unsigned int i = 0; i < h.nb && i < 8; i++) std::printf("  form B fails for x bits 0x%08x\n", h.first_b[i]);
+    return 0;
+}
+
 static int check_rcp()
 {
     RcpResult *dres, h{};
@@ -117,6 +163,7 @@ static int check_rcp()
 int main(int argc, char **argv)
 {
     if (argc > 1 && std::string(argv[1]) == "rcp") return check_rcp();
+    if (argc > 1 && std::string(argv[1]) == "sqrt") return check_sqrt();
     const uint32_t chunk = 1u << 18;                       // d significands per launch
     const uint32_t nchunks_all = (1u << 23) / chunk;       // 32
     uint32_t first = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 0;

@@ -48,6 +48,44 @@ def test_math_bit_exact(gpu_ctx, orc, fn, name, gen_a, gen_b):
     assert pc.same_bits(got, want), f"{name}: {pc.describe_diff(got, want)}"
 
 
+def _edge_values(rng, n):
+    """Magnitudes over the whole exponent range, with the guard boundaries of the reduced forms,
+    zeros, subnormals and non-finite values mixed in."""
+    v = rng.choice([-1.0, 1.0], n) * rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(-149, 128, n)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, 2.0 ** -64, 2.0 ** 64, 2.0 ** -80, 2.0 ** -40,
+                        2.0 ** 40, 2.0 ** -126, 2.0 ** -149, 3.4e38, np.nextafter(np.float32(2.0 ** -64), np.float32(0)),
+                        np.nextafter(np.float32(2.0 ** 64), np.float32(np.inf))])
+    v[:: max(n // 4096, 1)][: 4096] = rng.choice(special, len(v[:: max(n // 4096, 1)][: 4096]))
+    return np.concatenate([v, special]).astype(np.float32)
+
+
+def test_reduced_sqrt_rcp_normalize_equal_the_ieee_operations(gpu_ctx):
+    """ptm::sqrt_exact / rcp_exact / the normalize built on them (pt_devmath.h) against numpy's
+    correctly rounded float32 sqrt and division, over all exponents and the guard boundaries
+    (the exhaustive checks are profiles/div_proof.hip; this is the regression test)."""
+    rng = np.random.default_rng(77)
+    with np.errstate(all="ignore"):
+        x = _edge_values(rng, 400000)
+        assert pc.same_bits(gpu_ctx.debug_math(11, np.abs(x)), np.sqrt(np.abs(x)))
+        assert pc.same_bits(gpu_ctx.debug_math(11, x[:4096]), np.sqrt(x[:4096]))            # negative -> NaN
+        assert pc.same_bits(gpu_ctx.debug_math(12, x), np.float32(1.0) / x)
+        for scale in (1.0, 2.0 ** -38, 2.0 ** 39, 2.0 ** -70):
+            a = (rng.normal(size=300000) * scale).astype(np.float32)
+            b = (rng.normal(size=300000) * scale * 10.0 ** rng.uniform(-30, 2, 300000)).astype(np.float32)
+            a[::7] = 0.0
+            b[::11] = 0.0
+            b[::13] = a[::13]                                    # z = a - b = 0
+            c = a - b
+            length = np.sqrt((a * a + b * b) + c * c)
+            for fn, comp in ((13, a), (14, b), (15, c)):
+                assert pc.same_bits(gpu_ctx.debug_math(fn, a, b), comp / length), (scale, fn)
+        a, b = _edge_values(rng, 100000), _edge_values(rng, 100000)[::-1].copy()
+        c = a - b
+        length = np.sqrt((a * a + b * b) + c * c)
+        for fn, comp in ((13, a), (14, b), (15, c)):
+            assert pc.same_bits(gpu_ctx.debug_math(fn, a, b), comp / length), fn
+
+
 # ---------------------------------------------------------------- intersection probes
 
 def _random_rays(rng, n, origin_scale=3.0):

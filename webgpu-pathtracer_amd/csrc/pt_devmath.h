@@ -19,6 +19,42 @@ namespace ptm {
 
 PT_DEV float pow2i(int n) { return __uint_as_float((uint32_t)(n + 127) << 23); }
 
+// ---------------------------------------------------------------------------------
+// Correctly rounded division, reciprocal and square root in fewer instructions than the
+// compiler's IEEE expansions (11 / 11 / 14).  Each identity was checked by exhaustion on
+// gfx950 (profiles/div_proof.hip; logs under profiles/r01_g_*_proof_exhaustive.log) and is
+// only applied where no intermediate can leave the normal range; outside, the plain
+// operation runs.  Results are bit-identical to '/', 1.0f / x and sqrtf.
+// ---------------------------------------------------------------------------------
+
+// RN(n/d) given y = RN(1/d): all 2^23 x 2^23 significand pairs checked; the caller guarantees
+// that n is 0 or large enough for the residual to be exact (|n| >= 2^-103) and that n/d stays
+// within the normal range.
+PT_DEV float div_pre(float n, float d, float y)
+{
+    const float q0 = n * y;
+    return fmaf(fmaf(-d, q0, n), y, q0);
+}
+
+// RN(1/d): one Newton step on v_rcp_f32; all 2^32 inputs checked, exact for |d| in [2^-64, 2^64].
+PT_DEV float rcp_exact(float d)
+{
+    const float a = fabsf(d);
+    if (!(a >= 5.421010862427522e-20f && a <= 1.8446744073709552e19f)) return 1.0f / d;
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, y0, 1.0f), y0, y0);
+}
+
+// RN(sqrt x): y = v_rsq_f32(x), s = x*y, s + (x - s*s) * (y/2); all non-negative inputs
+// checked, exact for x in [2^-64, 2^64] (v_sqrt_f32 alone is off for 3.3e8 inputs).
+PT_DEV float sqrt_exact(float x)
+{
+    if (!(x >= 5.421010862427522e-20f && x <= 1.8446744073709552e19f)) return sqrtf(x);
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s = x * y;
+    return fmaf(fmaf(-s, s, x), 0.5f * y, s);
+}
+
 // z * 2^n, single rounding, n in [-150, 254]
 PT_DEV float ldexp1(float z, int n)
 {
@@ -174,7 +210,7 @@ PT_DEV float asin1(float x)
     float z, t;
     if (a > 0.5f) {
         z = 0.5f * (1.0f - a);
-        t = sqrtf(z);
+        t = sqrt_exact(z);
         flag = true;
     } else {
         t = a;

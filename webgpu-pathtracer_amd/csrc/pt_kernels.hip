@@ -34,6 +34,9 @@ namespace pt {
 
 struct f3 { float x, y, z; };
 
+using ptm::div_pre;
+using ptm::rcp_exact;
+
 PT_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 xyz(const float4 &v) { return F3(v.x, v.y, v.z); }
 PT_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -47,10 +50,22 @@ PT_DEV f3 cross(f3 a, f3 b)
 {
     return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-// pinned: normalize(v) = v / sqrt(dot(v, v))
+// pinned: normalize(v) = v / sqrt(dot(v, v)), correctly rounded sqrt and divisions.  The
+// compiler's IEEE expansions cost 14 + 3 x 11 instructions; the same bits come from
+// ptm::sqrt_exact, one exact reciprocal of the length and ptm::div_pre per component whenever
+// no intermediate can underflow (length within [2^-40, 2^40], components 0 or >= 2^-80), which
+// is checked; anything else takes the plain operations.
 PT_DEV f3 normalize(f3 a)
 {
-    const float l = sqrtf(dot(a, a));
+    const float l = ptm::sqrt_exact(dot(a, a));
+    const uint32_t lo = 0x17800000u - 1u;                         // 2^-80
+    const bool comps = ((__float_as_uint(a.x) & 0x7fffffffu) - 1u >= lo) && ((__float_as_uint(a.y) & 0x7fffffffu) - 1u >= lo) &&
+                       ((__float_as_uint(a.z) & 0x7fffffffu) - 1u >= lo);      // 0 wraps to 0xffffffff: passes
+    if (comps && l >= 9.094947017729282e-13f && l <= 1.099511627776e12f) {
+        const float y0 = __builtin_amdgcn_rcpf(l);
+        const float y = fmaf(fmaf(-l, y0, 1.0f), y0, y0);          // RN(1/l), see ptm::rcp_exact
+        return F3(div_pre(a.x, l, y), div_pre(a.y, l, y), div_pre(a.z, l, y));
+    }
     return F3(a.x / l, a.y / l, a.z / l);
 }
 // pinned: mix(a, b, t) = a * (1 - t) + b * t
@@ -125,24 +140,6 @@ struct RayPre {
     float ix, iy, iz;        // RN(1/d) per axis
     uint32_t flags;          // bit3: this ray takes the plain-division test
 };
-
-PT_DEV float div_pre(float n, float d, float y)
-{
-    const float q0 = n * y;
-    return fmaf(fmaf(-d, q0, n), y, q0);
-}
-
-// RN(1/d) without the 11-instruction division expansion: one Newton step on the hardware
-// reciprocal.  profiles/div_proof.hip (mode "rcp") checks ALL 2^32 inputs on gfx950: the result
-// equals the IEEE quotient 1.0f/d for every |d| in [2^-64, 2^64] (v_rcp_f32 alone is off for
-// 5e8 of them); outside that range, and for NaN, the plain division is used.
-PT_DEV float rcp_exact(float d)
-{
-    const float a = fabsf(d);
-    if (!(a >= 5.421010862427522e-20f && a <= 1.8446744073709552e19f)) return 1.0f / d;
-    const float y0 = __builtin_amdgcn_rcpf(d);
-    return fmaf(fmaf(-d, y0, 1.0f), y0, y0);
-}
 
 PT_DEV bool safe_magnitude(float v)
 {
@@ -399,7 +396,7 @@ PT_DEV float rand1(uint32_t &seed)
 PT_DEV float rand_normal(uint32_t &seed)
 {
     const float theta = PT_TWOPI * rand1(seed);
-    const float rho = sqrtf(-2.0f * ptm::log1(rand1(seed)));
+    const float rho = ptm::sqrt_exact(-2.0f * ptm::log1(rand1(seed)));
     return rho * ptm::cos1(theta);
 }
 
@@ -416,7 +413,7 @@ PT_DEV f3 rand_direction(uint32_t &seed)
 PT_DEV void rand_point_in_circle(uint32_t &seed, float &px, float &py)
 {
     const float theta = PT_TWOPI * rand1(seed);
-    const float rho = sqrtf(rand1(seed));
+    const float rho = ptm::sqrt_exact(rand1(seed));
     float s, c;
     ptm::sincos(theta, s, c);
     px = rho * c;
@@ -921,6 +918,16 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     if (sc.nnodes != 0) { root0 = sc.nodes[0]; root1 = sc.nodes[1]; }
     root0 = make_float4(uni(root0.x), uni(root0.y), uni(root0.z), uni(root0.w));
     root1 = make_float4(uni(root1.x), uni(root1.y), uni(root1.z), uni(root1.w));
+    // per-pixel divisions by launch-invariant divisors: 1 / resolution once, and pixel / resolution
+    // as an exact quotient from that reciprocal (ptm::div_pre; pixel indices are 0 or >= 1, so the
+    // only proviso is a resolution of ordinary magnitude -- otherwise the plain division runs)
+    const float inv_res_x = uni(1.0f / un.res_x), inv_res_y = uni(1.0f / un.res_y);
+    const bool res_ordinary = un.res_x >= 9.5367431640625e-07f && un.res_x <= 1.099511627776e12f &&
+                              un.res_y >= 9.5367431640625e-07f && un.res_y <= 1.099511627776e12f;
+    const float spf_f = (float)un.samples_per_frame;
+    auto per_sample = [&](const f3 &sum) {     // incomingLight / f32(samplesPerFrame), raytrace.wgsl:455 (x / 1 == x)
+        return un.samples_per_frame == 1 ? sum : F3(sum.x / spf_f, sum.y / spf_f, sum.z / spf_f);
+    };
 
     // diagnostic stamps (only when a buffer is bound): wall clock (100 MHz) and shader clock
     const uint64_t t_begin_rt = L.wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1165,8 +1172,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 sample++;
                 if (sample >= un.samples_per_frame) {
                     // pixel finished (:455, :477): the slot is free for the refill below
-                    const float n = (float)un.samples_per_frame;
-                    write_pixel<FUSE>(L, gx, gy, ly, F3(incoming.x / n, incoming.y / n, incoming.z / n), slot);
+                    write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
                 } else {
                     need_path = true;
                 }
@@ -1219,15 +1225,16 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             // raytrace.wgsl:441-455: next sample's camera path, or the pixel is finished
             for (;;) {
                 if (sample >= un.samples_per_frame) {
-                    const float n = (float)un.samples_per_frame;
-                    write_pixel<FUSE>(L, gx, gy, ly, F3(incoming.x / n, incoming.y / n, incoming.z / n), slot);
+                    write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
                     break;
                 }
-                const float uvx = (float)gx / un.res_x, uvy = (float)gy / un.res_y;
+                float uvx, uvy;
+                if (res_ordinary) { uvx = div_pre((float)gx, un.res_x, inv_res_x); uvy = div_pre((float)gy, un.res_y, inv_res_y); }
+                else { uvx = (float)gx / un.res_x; uvy = (float)gy / un.res_y; }
                 const f3 dir0 = camera_direction(cf, un.aspect, uvx, uvy);
                 float jx, jy, kx, ky;
                 rand_point_in_circle(seed, jx, jy);
-                const f3 jitter = F3(jx * (1.0f / un.res_x), jy * (1.0f / un.res_y), 0.0f);
+                const f3 jitter = F3(jx * inv_res_x, jy * inv_res_y, 0.0f);
                 rand_point_in_circle(seed, kx, ky);
                 const f3 jitter2 = F3(kx * un.aperture, ky * un.aperture, 0.0f);
                 const f3 focal = (cam_pos + dir0 * un.focal_distance) + jitter;
@@ -1674,6 +1681,11 @@ __global__ void __launch_bounds__(256) k_debug_math(int fn, const float *__restr
     case 7: r = ptm::pow1(x, y); break;
     case 8: r = ptm::round_f16(x); break;
     case 9: r = sqrtf(x); break;
+    case 11: r = ptm::sqrt_exact(x); break;
+    case 12: r = ptm::rcp_exact(x); break;
+    case 13: r = normalize(F3(x, y, x - y)).x; break;
+    case 14: r = normalize(F3(x, y, x - y)).y; break;
+    case 15: r = normalize(F3(x, y, x - y)).z; break;
     default: r = x / y; break;
     }
     out[i] = r;
