@@ -1308,7 +1308,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
 int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu)
 {
     const int ntiles = raytrace_grid_blocks(tile);
-    if (waves_per_cu <= 0 || waves_per_cu > 16) waves_per_cu = 16;   // VGPR-limited: 4 waves per SIMD
+    if (waves_per_cu <= 0 || waves_per_cu > 24) waves_per_cu = 16;   // default 16: VGPR-limited, 4 waves per SIMD
     const int resident = 256 * waves_per_cu;                          // <= PT_MAX_RESIDENT_WAVES
     return ntiles < resident ? ntiles : resident;
 }
