@@ -231,7 +231,7 @@ def main():
 
     # ---- the dominant kernel's launches inside the timed region: the library brackets every
     # batched raytrace launch with a HIP event pair on the stream it runs on; this is the
-    # per-launch duration rocprofv3 --kernel-trace reports for k_raytrace_sm<false>.
+    # per-launch duration rocprofv3 --kernel-trace reports for k_raytrace_sm<false,false,true>.
     launch_ms_total, launches, launch_frames = ctx.raytrace_launch_stats()
     kernel_ms = launch_ms_total / max(launches, 1)
 
@@ -269,7 +269,8 @@ def main():
                                      "accumulate per batch on the main stream"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_raytrace_sm<false> (persistent raytrace, batched frames)",
+                         "kernel": "k_raytrace_sm<false,false,true> (persistent raytrace, deferred-leaf walk, batched frames)"
+                                   if args.variant in (0, 7) else f"raytrace kernel variant {args.variant}",
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": int(launches),
                          "frames_in_timed_launches": int(launch_frames),
                          "algorithmic_bytes_per_launch": int(per_launch_bytes),
