@@ -58,6 +58,8 @@ struct mi3pt_ctx {
     bool output_is_accum = false;
     uint64_t *d_block_counters = nullptr;
     uint32_t *d_tile_counter = nullptr;
+    uint32_t *d_drain_flag = nullptr;     // signal memory: sequence number of the last batched launch that started draining
+    uint32_t launch_seq = 0;              // sequence number of the last batched launch
     uint32_t *d_stack_overflow = nullptr; // [2 parities][PT_MAX_RESIDENT_WAVES][32][64] overflow stack entries
     uint64_t *d_wave_times = nullptr;     // diagnostic stamps, allocated by mi3pt_debug_wave_times(enable)
     int wave_times_slots = 0;
@@ -191,6 +193,12 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
         return pt_set_error(MI3PT_ERR_HIP, "hipMalloc(environment) failed");
     }
     (void)hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream);     // self-cleaning afterwards
+    // a word the command processor can poll (hipStreamWaitValue32) and a running kernel can write
+    const char *gate = std::getenv("MI3PT_GATE");                      // experiment knob: 0 = launches queue behind each other
+    if (!(gate && gate[0] == '0') && hipExtMallocWithFlags((void **)&ctx->d_drain_flag, 8, hipMallocSignalMemory) == hipSuccess)
+        (void)hipMemsetAsync(ctx->d_drain_flag, 0, 8, ctx->stream);
+    else
+        ctx->d_drain_flag = nullptr;                                     // launches then simply queue behind each other
     (void)hipMemsetAsync(ctx->d_env, 0, env_bytes, ctx->stream);
     (void)hipMemsetAsync(ctx->d_cdf, 0, env_bytes, ctx->stream);
     std::memset(ctx->u_rt, 0, sizeof ctx->u_rt);
@@ -226,7 +234,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     free_textures(ctx);
     for (void *p : { ctx->d_tris, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
-                     (void *)ctx->d_tile_counter, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow })
+                     (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
         for (int k = 0; k < 2; k++)
@@ -656,6 +664,8 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.store_f16 = ctx->storage == MI3PT_STORAGE_F16;
     L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
     L.leaf_min = ctx->leaf_min;
+    L.drain_flag = nullptr;
+    L.drain_seq = 0;
     L.waves_per_cu = ctx->waves_per_cu;
     L.top_packets = ctx->top_packets;
     return L;
@@ -709,10 +719,19 @@ static int flush_pending(mi3pt_ctx *ctx)
     L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
     L.tile_counter = ctx->d_tile_counter + par * 32;
     L.stack_overflow = ctx->d_stack_overflow + (size_t)par * pt::PT_MAX_RESIDENT_WAVES * 32 * 64;
-    if (ctx->timing) {
+    if (ctx->timing)
         if (int rc = collect_rt_time(ctx, par)) return rc;      // the launch of two batches ago
-        HIP_TRY(hipEventRecord(ctx->ev_rt[par][0], rs));
+    // Hold this launch until the previous one (on the other stream) has handed out its last job:
+    // its persistent waves then start to exit, and this launch's workgroups take the slots they
+    // free.  Enqueued earlier, the kernel would sit in the dispatcher for the previous launch's
+    // whole run -- same throughput, but event / profiler durations twice the execution time.
+    if (ctx->d_drain_flag && pt::raytrace_grid_blocks(L.tile) > 0) {      // (an empty tile launches nothing)
+        if (ctx->launch_seq != 0)
+            HIP_TRY(hipStreamWaitValue32(rs, ctx->d_drain_flag, ctx->launch_seq, hipStreamWaitValueGte, 0xffffffffu));
+        L.drain_flag = ctx->d_drain_flag;
+        L.drain_seq = ++ctx->launch_seq;
     }
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev_rt[par][0], rs));
     pt::launch_raytrace(L, false, pick_variant(ctx), rs);
     HIP_TRY(hipGetLastError());
     if (ctx->timing) {

@@ -98,6 +98,8 @@ struct RtLaunch {
     int32_t store_f16;
     int32_t walk_min;            // state-machine kernel: walk while at least this many lanes are walking
     int32_t leaf_min;            // deferred-leaf walk: run a triangle step once this many lanes have a leaf parked
+    uint32_t *drain_flag;        // signal word (or null): receives drain_seq when the last job has been handed out
+    uint32_t drain_seq;
     int32_t top_packets;         // node packets to stage in LDS per wave (0..64)
     int32_t waves_per_cu;        // persistent kernels: resident one-wave workgroups per CU
 };

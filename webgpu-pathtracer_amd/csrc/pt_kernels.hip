@@ -951,9 +951,19 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     pre.ix = pre.iy = pre.iz = 0.0f;
     pre.flags = 8u;
 
+    const int drain_mark = max(ntiles - (int)(gridDim.x >> 1), 0);
     auto fetch_tile = [&]() -> int {
         int t = 0;
-        if (lane == 0) t = (int)atomicAdd(L.tile_counter, 1u);
+        if (lane == 0) {
+            t = (int)atomicAdd(L.tile_counter, 1u);
+            // When the queue is about to run dry (half a grid of jobs left: a lead of some tens of
+            // microseconds over the first exiting wave, which covers the command processor's wake-up
+            // and the dispatch) this launch announces its drain.  The host holds the next launch
+            // back (a stream wait on this word) until then, so that launches run back to back with
+            // only their tails overlapping instead of queueing for slots behind each other.
+            if (t == drain_mark && L.drain_flag)
+                __hip_atomic_store(L.drain_flag, L.drain_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return __builtin_amdgcn_readfirstlane(t);
     };
     int cur_tile = 0, cur_used = 64;
