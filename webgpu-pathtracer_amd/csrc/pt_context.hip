@@ -469,7 +469,7 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
         // The 64-entry abort (raytrace.wgsl:167-171) counts leaves too: it cannot fire while the
         // worst case stays below 64.  LDS holds 32 entries per lane: the node stack (internal
         // nodes only in the deferred walk) from the bottom, parked leaves from the top.
-        if (proper && worst < 64 && worst_internal <= 28) leaf_cap = 32 - (int)worst_internal;
+        if (proper && worst < 64 && (int)worst_internal <= pt::SM_LDS_DEPTH - 4) leaf_cap = pt::SM_LDS_DEPTH - (int)worst_internal;
         (void)visited;      // nodes the root does not reach are never walked by the reference either
     }
     if (int rc = replace_buffer(ctx, &ctx->d_nodes, bytes, nbytes)) return rc;

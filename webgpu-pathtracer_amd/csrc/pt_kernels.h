@@ -9,6 +9,13 @@ namespace pt {
 // overflow-stack slices and diagnostic slots.
 constexpr int PT_MAX_RESIDENT_WAVES = 256 * 24;
 
+// Stack entries per lane that the state-machine kernels keep in LDS ([depth][lane], 256 B per
+// entry and wave).  16 one-wave workgroups per CU x SM_LDS_DEPTH x 256 B must fit the 160 KB of LDS.
+#ifndef PT_SM_LDS_DEPTH_VALUE
+#define PT_SM_LDS_DEPTH_VALUE 32
+#endif
+constexpr int SM_LDS_DEPTH = PT_SM_LDS_DEPTH_VALUE;
+
 
 // per-pass counters, see mi3pt_counter in include/mi3pt.h
 enum { CNT_RAYS, CNT_BOX, CNT_TRI, CNT_HIT, CNT_MISS, CNT_OVERFLOW, CNT_PIXELS, CNT_RESERVED, CNT_COUNT };

@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
 // ---------------------------------------------------------------------------------
 enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
 
-#define PT_SM_LDS_DEPTH 32
+#define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
 #define PT_SM_TOP_PACKETS 64       // node packets staged in LDS per wave: the top 6 levels of the tree
 #ifndef PT_SM_MIN_WAVES
 #define PT_SM_MIN_WAVES 4
@@ -886,7 +886,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     // outstanding memory operation): the LDS access is unconditional, the overflow access a
     // rare branch kept apart by the opaque asm.
     auto st_load = [&](int i) -> uint32_t {
-        uint32_t v = stack[(i & (PT_SM_LDS_DEPTH - 1)) * 64];
+        uint32_t v = stack[(i < PT_SM_LDS_DEPTH ? i : 0) * 64];
         asm volatile("" : "+v"(v));          // keep this a ds_read of its own
         if (i >= PT_SM_LDS_DEPTH) v = ovf[(i - PT_SM_LDS_DEPTH) * 64];
         return v;
