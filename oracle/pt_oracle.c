@@ -565,7 +565,11 @@ static void aces_tonemap(const float c[3], float out[3])
     }
     for (int i = 0; i < 3; i++) {
         float m = (m2[0][i] * r[0] + m2[1][i] * r[1]) + m2[2][i] * r[2];
-        out[i] = om_pow(clampf(m, 0.0f, 1.0f), 1.0f / 2.2f);
+        /* vec3f(1.0 / 2.2), fullscreen.wgsl:102: both operands are AbstractFloat, so the quotient
+         * is a const-expression evaluated in double and THEN rounded to f32 (0x3EE8BA2F; the f32
+         * division 1.0f / 2.2f gives 0x3EE8BA2E).  Found by running the shader text itself
+         * (tests/test_wgsl_vectors.py). */
+        out[i] = om_pow(clampf(m, 0.0f, 1.0f), (float)(1.0 / 2.2));
     }
 }
 

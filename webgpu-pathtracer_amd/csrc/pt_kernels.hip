@@ -1589,7 +1589,8 @@ PT_DEV f3 aces_tonemap(f3 c)
     const float mx = (1.60475f * r.x + -0.53108f * r.y) + -0.07367f * r.z;
     const float my = (-0.10208f * r.x + 1.10813f * r.y) + -0.00605f * r.z;
     const float mz = (-0.00327f * r.x + -0.07276f * r.y) + 1.07602f * r.z;
-    const float g = 1.0f / 2.2f;
+    // vec3f(1.0 / 2.2): an AbstractFloat const-expression, evaluated in double, then rounded (fullscreen.wgsl:102)
+    const float g = (float)(1.0 / 2.2);
     return F3(ptm::pow1(clamp1(mx, 0.0f, 1.0f), g), ptm::pow1(clamp1(my, 0.0f, 1.0f), g),
               ptm::pow1(clamp1(mz, 0.0f, 1.0f), g));
 }
