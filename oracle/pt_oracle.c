@@ -9,10 +9,16 @@
  * cpu_baseline leg and __graft_entry__.smoke() may load this library; the product
  * (webgpu-pathtracer_amd/) never does.
  *
- * PARITY UNPINNED: the reference ships no tests, golden images or known-answer
- * vectors and cannot be executed here (no tsc / node_modules / Dawn).
- * This restatement is therefore pinned only by the hand-derived known-answer tests
- * in tests/ and by the arithmetic interpretation fixed in pt_oracle_math.h.
+ * PINNING: the reference ships no tests, golden images or known-answer vectors and its
+ * application cannot be built here (no tsc / node_modules / Dawn).  The three
+ * shader files, however, are executed as they stand by oracle/wgsl_interp.py, and
+ * tests/test_wgsl_vectors.py holds every function below to those outputs bit for bit
+ * (tests/golden/wgsl_vectors.npz; implementation-defined builtins per pt_oracle_math.h).
+ * The reference's BVH builder and environment-CDF code are likewise executed (under Node,
+ * tests/golden/run_reference_host.js) and the native builder held to their bytes.  What remains
+ * PARITY UNPINNED is the rest of the TypeScript host glue (scene flattening and uniform
+ * packing through three.js / webgpu-utils) and the browser's own choices for the
+ * implementation-defined arithmetic.
  *
  * Buffers use the reference's byte layouts (webgpu-utils offsets):
  *   Triangle 112 B, BVHNode 48 B, Material 64 B, raytrace Uniforms 96 B,
