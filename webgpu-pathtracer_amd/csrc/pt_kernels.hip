@@ -11,7 +11,15 @@
 //       VARIANT 1 walks the uploaded 48-B node records exactly like the WGSL,
 //       VARIANT 2 walks 64-B node packets (both child boxes in one line) and 48-B
 //       triangle packets -- same tests in the same order, a third of the loads.
-//   k_accumulate               accumulate.wgsl computeMain
+//       Kept as the on-device references of the parity tests (kernel variants 1 and 2).
+//   k_raytrace_persistent      variant 3: persistent waves with lane refill only
+//   k_raytrace_sm<FUSE, TOPLDS, DEFER>
+//       the shipped kernel: persistent one-wave workgroups, per-lane state machine with node /
+//       triangle / service steps, (frame slot, tile) jobs from a self-cleaning queue;
+//       DEFER = leaves parked and tested in steps of their own (variant 7, the default when
+//       the tree allows it), !DEFER = in-order walk (variant 4; 5 = other walk threshold),
+//       TOPLDS = top of the tree staged in LDS (variant 6, measured slower)
+//   k_accumulate[_batch]       accumulate.wgsl computeMain (one frame / an ordered batch of frames)
 //   k_fullscreen               fullscreen.wgsl fragmentMain (de-noise + tone-map)
 //   k_debug_intersect/_math    component probes for the parity tests
 #include "pt_kernels.h"
