@@ -228,6 +228,26 @@ def main():
         out[f"frame{fi}_uniforms"], out[f"frame{fi}_image"] = np.frombuffer(u.tobytes(), np.uint8), img
         print(f"frame {fi} ({w}x{h}) done, {time.time() - t0:.1f} s", flush=True)
 
+    # the same geometry with a polished metal and an emissive material: reflect / mix / emission
+    mats = layout.pack_materials([
+        dict(color=(0.9, 0.85, 0.8), roughness=0.15, metalness=0.9, specularColor=(0.95, 0.8, 0.6)),
+        dict(color=(1.0, 0.05, 0.05), roughness=0.6, metalness=0.3, specularColor=(1.0, 1.0, 1.0),
+             emissive=(2.0, 1.0, 0.5), emissiveIntensity=1.5)])
+    rt.res["materialBuffer"] = buffer(rt, "Material", np.frombuffer(mats.tobytes(), layout.MATERIAL))
+    cfg = dict(w=20, h=14, frame=4, bounces=5)
+    u = set_uniforms(**cfg)
+    tex = wi.Texture(np.zeros((cfg["h"], cfg["w"], 4), F32))
+    rt.res["outputTexture"] = tex
+    for y in range(cfg["h"]):
+        for x in range(cfg["w"]):
+            rt.invoke("computeMain", [vec((x, y, 0), "u")])
+    img = np.zeros((cfg["h"], cfg["w"], 4), F32)
+    for (x, y), v in tex.stores.items():
+        img[y, x] = v
+    out["metal_materials"] = np.frombuffer(mats.tobytes(), np.uint8).copy()
+    out["metal_uniforms"], out["metal_image"] = np.frombuffer(u.tobytes(), np.uint8), img
+    print(f"metal / emissive frame done, {time.time() - t0:.1f} s", flush=True)
+
     # ------------------------------------------------------------------ accumulate.wgsl
     acc = wi.Interpreter(src["accumulate"], math_fns)
     w, h = 9, 6

@@ -103,6 +103,17 @@ def test_whole_frames_match_the_executed_shader(orc, demo, env, vec):
         assert bits_equal(got, want), f"frame {i}: " + first_diff(got, want)
 
 
+def test_metal_and_emissive_materials(orc, demo, env, vec):
+    """reflect(), the un-normalised mix() direction, specularColor and emission (raytrace.wgsl:380-395)."""
+    mats = np.frombuffer(vec["metal_materials"].tobytes(), layout.MATERIAL)
+    sc = orc.OracleScene(demo.triangles, mats, demo.nodes, env)
+    want = vec["metal_image"]
+    h, w = want.shape[:2]
+    got, cnt = orc.raytrace(sc, vec["metal_uniforms"].tobytes(), w, h)
+    assert bits_equal(got, want), first_diff(got, want)
+    assert cnt["hits"] > 200 and want[..., :3].max() > 2.0             # emission reached the image
+
+
 # ---------------------------------------------------------------- accumulate.wgsl
 
 def test_accumulate_pass(orc, vec):
@@ -163,6 +174,14 @@ def test_device_frames_match_the_executed_shader(gpu_ctx, demo, env, vec):
         ctx.submit(capi.SUBMIT_RAYTRACE)
         got = ctx.read_texture(capi.TEX_OUTPUT)
         assert bits_equal(got, want), f"frame {i}: " + first_diff(got, want)
+    ctx.upload_materials(np.frombuffer(vec["metal_materials"].tobytes(), layout.MATERIAL))
+    want = vec["metal_image"]
+    h, w = want.shape[:2]
+    ctx.resize(w, h)
+    ctx.set_uniforms(capi.PASS_RAYTRACE, vec["metal_uniforms"].tobytes())
+    ctx.submit(capi.SUBMIT_RAYTRACE)
+    got = ctx.read_texture(capi.TEX_OUTPUT)
+    assert bits_equal(got, want), "metal / emissive frame: " + first_diff(got, want)
     tex = vec["fs_input"]
     h, w = tex.shape[:2]
     ctx.resize(w, h)
