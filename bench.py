@@ -37,6 +37,7 @@ for p in (os.path.join(ROOT, "webgpu-pathtracer_amd", "py"), os.path.join(ROOT, 
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0     # same guide: what a streaming kernel reaches
 BLOCK_ROWS = 8
 
 
@@ -276,7 +277,12 @@ def main():
                          "algorithmic_bytes_per_launch": int(per_launch_bytes),
                          "bytes_per_ray": round(algorithmic_bytes(total) / max(rays, 1), 1),
                          "pipelined_job_GBps": round(effective, 1),
-                         "pipelined_job_frac": round(effective / HBM_PEAK_GBS, 4)},
+                         "pipelined_job_frac": round(effective / HBM_PEAK_GBS, 4),
+                         # SURVEY.md 8d asks for both the 8.0 TB/s spec and the ~6.29 TB/s a streaming
+                         # kernel reaches (MI355X_MICROARCH.md); the bytes are algorithmic, served mostly
+                         # from L1/L2, so neither bounds this kernel
+                         "peak_achievable": HBM_ACHIEVABLE_GBS,
+                         "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, env, rt_uniforms, width, height)
