@@ -2,7 +2,8 @@
 # Collects PMC counters for the dominant kernel in separate passes (never combined with
 # trace domains other than --kernel-trace).  STEPS / WARMUP (env) set the bench length, PASSES
 # (env, e.g. "4 5") restricts the counter groups.  TA_* and GRBM_* passes are left out: on this
-# pool a TA_* pass aborted rocprofv3 (signal 6) and the following pass hung (round 1).  usage: pmc_passes.sh <outdir> [bench args...]
+# pool a TA_* pass aborted rocprofv3 (signal 6) and the following pass hung, and a TCP_* pass
+# (TCP_TOTAL_CACHE_ACCESSES_sum, TCP_TCC_READ_REQ_sum, TCP_GATE_EN1/2_sum) hung the run until its timeout (round 1).  usage: pmc_passes.sh <outdir> [bench args...]
 set -u
 OUT=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
