@@ -209,6 +209,13 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
  * worst-case stack stays below 29 entries (checked at upload), otherwise 4 runs.  auto = 7
  * when the scene allows it, else 4.  All variants produce the same bits. */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
+/* The reference's environment importance sampling (raytrace.wgsl:315-367: getEnvironmentMapUV /
+ * ...MarginalCDF / ...ConditionalCDF / ...PDF over the CDF texture of renderer.ts:159-266) is dead
+ * code as shipped -- its call sites raytrace.wgsl:398 and :402-404 are commented out.  enabled = 1
+ * runs the frame as if those three lines were live (a miss takes its uv from the CDF and divides
+ * the path's light by the pdf); it needs the CDF texture and uses the per-pixel kernel (no
+ * batching).  Default 0 = the shipped behaviour. */
+int mi3pt_set_env_sampling(mi3pt_ctx *ctx, int enabled);
 /* Frame pipelining (default on): RAYTRACE|ACCUMULATE submits are queued; up to 16 consecutive
  * frames whose uniforms differ only in `frame` run as one raytrace launch plus one ordered
  * multi-frame running mean, and launches alternate between two internal streams so the next

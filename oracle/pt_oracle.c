@@ -95,6 +95,8 @@ typedef struct {
     const uint8_t *mats;  uint32_t nmats;
     const uint8_t *nodes; uint32_t nnodes;
     const float *env;     int32_t env_w, env_h;   /* rgba32float, row 0 first */
+    const float *cdf;                              /* CDF texture (same size), or NULL */
+    int32_t env_sampling;                          /* 1 = the dormant importance-sampling lines enabled */
 } orc_scene;
 
 /* raytrace.wgsl:66-75 (+ Camera :10-16), offsets per SURVEY.md 8a */
@@ -340,6 +342,44 @@ static v3 sample_env_bilinear_clamp(const orc_scene *sc, float u, float v)
     return V3(r[0], r[1], r[2]);
 }
 
+/* textureSampleLevel(environmentCDFTexture, nearest sampler): renderer.ts:82-85.  Pinned: texel =
+ * floor(u * W), clamp-to-edge. */
+static const float *cdf_texel(const orc_scene *sc, float u, float v)
+{
+    int W = sc->env_w, H = sc->env_h;
+    float xf = floorf(u * (float)W), yf = floorf(v * (float)H);
+    xf = fminf(fmaxf(xf, 0.0f), (float)(W - 1));
+    yf = fminf(fmaxf(yf, 0.0f), (float)(H - 1));
+    if (xf != xf) xf = 0.0f;
+    if (yf != yf) yf = 0.0f;
+    return sc->cdf + 4 * ((size_t)(int)yf * W + (int)xf);
+}
+
+/* raytrace.wgsl:315-367 -- the environment importance-sampling functions.  DEAD CODE in the
+ * reference as shipped (their call sites, :398 and :402-404, are commented out); evaluated only
+ * when the scene asks for it (orc_scene.env_sampling), which is what un-commenting those lines
+ * would do. */
+static void env_uv_sampled(const orc_scene *sc, uint32_t *seed, float *u_out, float *v_out)
+{
+    float r1 = rand_f(seed);
+    float r2 = rand_f(seed);
+    float v_min = 0.0f, v_max = 1.0f;
+    for (int i = 0; i < 8; i++) {
+        float v_mid = (v_min + v_max) / 2.0f;
+        float c = fmaxf(cdf_texel(sc, 0.5f, v_mid)[0], EPSILON);
+        if (c < r1) v_min = v_mid; else v_max = v_mid;
+    }
+    float v = (v_min + v_max) / 2.0f;
+    float u_min = 0.0f, u_max = 1.0f;
+    for (int i = 0; i < 8; i++) {
+        float u_mid = (u_min + u_max) / 2.0f;
+        float c = fmaxf(cdf_texel(sc, u_mid, v)[1], EPSILON);
+        if (c < r2) u_min = u_mid; else u_max = u_mid;
+    }
+    *u_out = (u_min + u_max) / 2.0f;
+    *v_out = v;
+}
+
 /* raytrace.wgsl:373-411 */
 static v3 trace(const orc_scene *sc, const rt_uniforms *un, uint32_t *seed, ray_t ray,
                 int32_t max_bounces, uint64_t *cnt)
@@ -372,8 +412,13 @@ static v3 trace(const orc_scene *sc, const rt_uniforms *un, uint32_t *seed, ray_
             cnt[C_MISS]++;
             float u, v;
             env_uv_from_ray(un, tr.direction, &u, &v);
+            if (sc->env_sampling && sc->cdf) env_uv_sampled(sc, seed, &u, &v);          /* :398 */
             v3 env = sample_env_bilinear_clamp(sc, u, v);
             incoming = vadd(incoming, vscale(vmul(ray_color, env), un->env_intensity));
+            if (sc->env_sampling && sc->cdf) {                                            /* :402-404 */
+                float pdf = fmaxf(cdf_texel(sc, u, v)[2], EPSILON);
+                incoming = V3(incoming.x / pdf, incoming.y / pdf, incoming.z / pdf);
+            }
             break;
         }
     }

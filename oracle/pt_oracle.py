@@ -18,7 +18,8 @@ class _Scene(ctypes.Structure):
     _fields_ = [("tris", ctypes.c_void_p), ("ntris", ctypes.c_uint32),
                 ("mats", ctypes.c_void_p), ("nmats", ctypes.c_uint32),
                 ("nodes", ctypes.c_void_p), ("nnodes", ctypes.c_uint32),
-                ("env", ctypes.c_void_p), ("env_w", ctypes.c_int32), ("env_h", ctypes.c_int32)]
+                ("env", ctypes.c_void_p), ("env_w", ctypes.c_int32), ("env_h", ctypes.c_int32),
+                ("cdf", ctypes.c_void_p), ("env_sampling", ctypes.c_int32)]
 
 
 _lib = None
@@ -66,7 +67,7 @@ COUNTER_NAMES = ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_over
 class OracleScene:
     """Holds the byte buffers (reference layouts) alive for the C side."""
 
-    def __init__(self, triangles, materials, nodes, env=None):
+    def __init__(self, triangles, materials, nodes, env=None, cdf=None, env_sampling=False):
         self.tris = np.ascontiguousarray(triangles)
         self.mats = np.ascontiguousarray(materials)
         self.nodes = np.ascontiguousarray(nodes) if nodes is not None else np.zeros(0, np.uint8)
@@ -75,7 +76,13 @@ class OracleScene:
         self.env = np.ascontiguousarray(env, np.float32)
         self.c = _Scene(_p(self.tris), self.tris.nbytes // 112, _p(self.mats), self.mats.nbytes // 64,
                         _p(self.nodes), self.nodes.nbytes // 48, _p(self.env),
-                        self.env.shape[1], self.env.shape[0])
+                        self.env.shape[1], self.env.shape[0], None, 0)
+        self.cdf = None
+        if cdf is not None:
+            self.cdf = np.ascontiguousarray(cdf, np.float32)
+            assert self.cdf.shape == self.env.shape
+            self.c.cdf = self.cdf.ctypes.data
+            self.c.env_sampling = 1 if env_sampling else 0
 
 
 def tile_local_rows(h, rank, nranks, block_rows):

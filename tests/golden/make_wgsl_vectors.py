@@ -248,6 +248,40 @@ def main():
     out["metal_uniforms"], out["metal_image"] = np.frombuffer(u.tobytes(), np.uint8), img
     print(f"metal / emissive frame done, {time.time() - t0:.1f} s", flush=True)
 
+    # the dormant environment importance sampling (raytrace.wgsl:315-367): its call sites are
+    # commented out in the shipped shader (:398, :402-404); the three markers are removed from the
+    # in-memory text, nothing else is touched
+    dormant = src["raytrace"]
+    for marker, live in (("// uv = getEnvironmentMapUV(seed);", "uv = getEnvironmentMapUV(seed);"),
+                         ("// let pdf = getEnvironmentMapPDF(uv);", "let pdf = getEnvironmentMapPDF(uv);"),
+                         ("// incomingLight /= pdf;", "incomingLight /= pdf;")):
+        assert dormant.count(marker) == 1, marker
+        dormant = dormant.replace(marker, live)
+    from mi3pt_host import capi
+    cdf = capi.host_env_cdf(env)
+    rt2 = wi.Interpreter(dormant, math_fns, dict(rt.res))
+    rt2.res["materialBuffer"] = buffer(rt2, "Material", np.frombuffer(demo.material_bytes.tobytes(), layout.MATERIAL))
+    rt2.res["environmentCDFTexture"] = wi.Texture(cdf, "nearest", "clamp")
+    cfg = dict(w=18, h=12, frame=6, bounces=3)
+    u = set_uniforms(**cfg)
+    rt2.res["uniforms"] = rt.res["uniforms"]
+    tex = wi.Texture(np.zeros((cfg["h"], cfg["w"], 4), F32))
+    rt2.res["outputTexture"] = tex
+    for y in range(cfg["h"]):
+        for x in range(cfg["w"]):
+            rt2.invoke("computeMain", [vec((x, y, 0), "u")])
+    img = np.zeros((cfg["h"], cfg["w"], 4), F32)
+    for (x, y), v in tex.stores.items():
+        img[y, x] = v
+    out["envsample_uniforms"], out["envsample_image"] = np.frombuffer(u.tobytes(), np.uint8), img
+    rows = []
+    for s in seeds:
+        cell = {"s": wi.U32(int(s))}
+        uv = rt2.invoke("getEnvironmentMapUV", [wi.Ref(cell, "s")])
+        rows.append(f32s(uv) + [float(rt2.invoke("getEnvironmentMapPDF", [uv])), float(int(cell["s"]) & 0xFFFFFF)])
+    out["envsample_uv_pdf"] = np.array(rows, F32)
+    print(f"dormant importance-sampling frame done, {time.time() - t0:.1f} s", flush=True)
+
     # ------------------------------------------------------------------ accumulate.wgsl
     acc = wi.Interpreter(src["accumulate"], math_fns)
     w, h = 9, 6

@@ -114,6 +114,20 @@ def test_metal_and_emissive_materials(orc, demo, env, vec):
     assert cnt["hits"] > 200 and want[..., :3].max() > 2.0             # emission reached the image
 
 
+def test_dormant_environment_importance_sampling(orc, demo, env, vec):
+    """raytrace.wgsl:315-367 with the commented-out call sites (:398, :402-404) enabled -- the
+    generator removes the three comment markers from the in-memory shader text.  The oracle's
+    optional mode (and the device's, mi3pt_set_env_sampling) reproduces it bit for bit."""
+    cdf = capi.host_env_cdf(env)
+    sc = orc.OracleScene(demo.triangles, demo.material_bytes, demo.nodes, env, cdf=cdf, env_sampling=True)
+    want = vec["envsample_image"]
+    h, w = want.shape[:2]
+    got, cnt = orc.raytrace(sc, vec["envsample_uniforms"].tobytes(), w, h)
+    assert bits_equal(got, want), first_diff(got, want)
+    plain, _ = orc.raytrace(pc.oracle_scene(orc, demo, env), vec["envsample_uniforms"].tobytes(), w, h)
+    assert not bits_equal(plain, want) and cnt["misses"] > 50          # the mode really changes the image
+
+
 # ---------------------------------------------------------------- accumulate.wgsl
 
 def test_accumulate_pass(orc, vec):
@@ -182,6 +196,20 @@ def test_device_frames_match_the_executed_shader(gpu_ctx, demo, env, vec):
     ctx.submit(capi.SUBMIT_RAYTRACE)
     got = ctx.read_texture(capi.TEX_OUTPUT)
     assert bits_equal(got, want), "metal / emissive frame: " + first_diff(got, want)
+    # the dormant environment importance sampling, enabled on the device
+    ctx.upload_materials(demo.material_bytes)
+    ctx.upload_environment_cdf(capi.host_env_cdf(env))
+    ctx.set_env_sampling(True)
+    want = vec["envsample_image"]
+    h, w = want.shape[:2]
+    ctx.resize(w, h)
+    ctx.set_uniforms(capi.PASS_RAYTRACE, vec["envsample_uniforms"].tobytes())
+    ctx.submit(capi.SUBMIT_RAYTRACE)
+    got = ctx.read_texture(capi.TEX_OUTPUT)
+    ctx.set_env_sampling(False)
+    assert bits_equal(got, want), "importance-sampling frame: " + first_diff(got, want)
+    ctx.submit(capi.SUBMIT_RAYTRACE)
+    assert not bits_equal(ctx.read_texture(capi.TEX_OUTPUT), want)      # and off again
     tex = vec["fs_input"]
     h, w = tex.shape[:2]
     ctx.resize(w, h)

@@ -71,6 +71,7 @@ struct mi3pt_ctx {
 
     int storage = MI3PT_STORAGE_F32;
     int variant = 0;
+    bool env_sampling = false;  // mi3pt_set_env_sampling: the reference's dormant importance-sampling lines
     int leaf_min = 32;          // deferred-leaf walk: lanes with a parked leaf that trigger a triangle step (MI3PT_LEAF_MIN)
     int walk_min = 32;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
     int waves_per_cu = 16;      // 8 KB of LDS per one-wave workgroup, 128 VGPRs
@@ -270,6 +271,15 @@ extern "C" int mi3pt_set_storage(mi3pt_ctx *ctx, int storage)
         return pt_set_error(MI3PT_ERR_INVALID, "storage must be MI3PT_STORAGE_F32 or MI3PT_STORAGE_F16");
     if (int rc = require_idle(ctx)) return rc;
     ctx->storage = storage;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_set_env_sampling(mi3pt_ctx *ctx, int enabled)
+{
+    if (int rc = require_idle(ctx)) return rc;
+    if (enabled && !ctx->d_cdf)
+        return pt_set_error(MI3PT_ERR_STATE, "environment CDF texture has not been uploaded (mi3pt_upload_environment_cdf)");
+    ctx->env_sampling = enabled != 0;
     return MI3PT_OK;
 }
 
@@ -601,6 +611,8 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.tripk = static_cast<const float4 *>(ctx->d_tripk);
     s.leaf_rank = static_cast<const uint32_t *>(ctx->d_leaf_rank);
     s.leaf_cap = ctx->leaf_cap;
+    s.cdf = static_cast<const float4 *>(ctx->d_cdf);
+    s.env_sampling = (ctx->env_sampling && ctx->d_cdf) ? 1 : 0;
     s.ntris = (uint32_t)ctx->ntris; s.nnodes = (uint32_t)ctx->nnodes; s.nmats = (uint32_t)ctx->nmats;
     s.npackets = (uint32_t)ctx->npackets;
     s.root_ref = ctx->root_ref;
@@ -625,6 +637,7 @@ static int check_scene(const mi3pt_ctx *ctx)
 // 0 = auto -> the persistent kernel; the probes only know the two per-ray walks.
 static int pick_variant(const mi3pt_ctx *ctx)
 {
+    if (ctx->env_sampling) return 2;               // the dormant path lives in the per-pixel kernel only
     const bool defer_ok = ctx->leaf_cap >= 4;      // see mi3pt_upload_bvh: leaves may be tested out of order
     if (ctx->variant == 0) return defer_ok ? 7 : 4;
     if (ctx->variant == 7 && !defer_ok) return 4;

@@ -56,6 +56,8 @@ struct SceneRefs {
     const float4 *tripk;    // TriPacket array, or null
     const uint32_t *leaf_rank;  // per triangle: rank of its leaf in the reference's visiting order
     int32_t leaf_cap;       // > 0: leaves may be tested out of order; LDS slots available for deferred leaves
+    const float4 *cdf;      // environment CDF texels (R marginal, G conditional, B sin-weighted luminance), or null
+    int32_t env_sampling;   // 1: the reference's dormant importance-sampling lines run (per-pixel kernels only)
     uint32_t ntris, nnodes, nmats, npackets;
     uint32_t root_ref;      // reference of node 0 in packet terms
     uint32_t flags;         // bit0: every ROOT box coordinate is 0 or within [2^-70, 2^60]

@@ -464,6 +464,40 @@ PT_DEV f3 sample_env(const float4 *env, int W, int H, float u, float v)
     return r;
 }
 
+// textureSampleLevel(environmentCDFTexture, nearest sampler, clamp-to-edge): renderer.ts:82-85
+PT_DEV float4 cdf_texel(const float4 *cdf, int W, int H, float u, float v)
+{
+    float xf = floorf(u * (float)W), yf = floorf(v * (float)H);
+    xf = fminf(fmaxf(xf, 0.0f), (float)(W - 1));
+    yf = fminf(fmaxf(yf, 0.0f), (float)(H - 1));
+    if (xf != xf) xf = 0.0f;
+    if (yf != yf) yf = 0.0f;
+    return cdf[(size_t)(int)yf * W + (int)xf];
+}
+
+// raytrace.wgsl:315-349 getEnvironmentMapUV -- DEAD CODE in the reference as shipped (its call
+// site :398 is commented out); runs only under mi3pt_set_env_sampling(ctx, 1).
+PT_DEV void env_uv_sampled(const float4 *cdf, int W, int H, uint32_t &seed, float &u_out, float &v_out)
+{
+    const float r1 = rand1(seed);
+    const float r2 = rand1(seed);
+    float v_min = 0.0f, v_max = 1.0f;
+    for (int i = 0; i < 8; i++) {
+        const float v_mid = (v_min + v_max) / 2.0f;
+        const float c = fmaxf(cdf_texel(cdf, W, H, 0.5f, v_mid).x, PT_EPSILON);
+        if (c < r1) v_min = v_mid; else v_max = v_mid;
+    }
+    const float v = (v_min + v_max) / 2.0f;
+    float u_min = 0.0f, u_max = 1.0f;
+    for (int i = 0; i < 8; i++) {
+        const float u_mid = (u_min + u_max) / 2.0f;
+        const float c = fmaxf(cdf_texel(cdf, W, H, u_mid, v).y, PT_EPSILON);
+        if (c < r2) u_min = u_mid; else u_max = u_mid;
+    }
+    u_out = (u_min + u_max) / 2.0f;
+    v_out = v;
+}
+
 struct CameraFrame {      // loop-invariant part of cameraToRay, raytrace.wgsl:217-236
     float t, r;
     f3 w, u_dir, v_dir;
@@ -564,8 +598,13 @@ PT_DEV f3 shade_pixel(const RtLaunch &L, uint32_t gx, uint32_t gy, uint32_t *sta
                 cnt.miss++;
                 float u, v;
                 env_uv_from_dir(d, sinr, cosr, u, v);
+                if (sc.env_sampling) env_uv_sampled(sc.cdf, sc.env_w, sc.env_h, seed, u, v);        // :398
                 const f3 env = sample_env(sc.env, sc.env_w, sc.env_h, u, v);
                 light = light + (ray_color * env) * un.env_intensity;
+                if (sc.env_sampling) {                                                                // :402-404
+                    const float pdf = fmaxf(cdf_texel(sc.cdf, sc.env_w, sc.env_h, u, v).z, PT_EPSILON);
+                    light = F3(light.x / pdf, light.y / pdf, light.z / pdf);
+                }
                 break;
             }
         }

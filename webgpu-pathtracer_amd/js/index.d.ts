@@ -109,6 +109,8 @@ export class Renderer {
   /** launch the sample frames render() has queued, without waiting for them */
   flush(): void;
   raytraceLaunchStats(reset?: boolean): { totalMs: number; launches: number; frames: number };
+  /** the reference's dormant environment importance sampling (raytrace.wgsl:398-404 un-commented); default off */
+  setEnvironmentSampling(enabled: boolean): void;
 }
 
 /** src/main.ts:251-266 -- .glb / .gltf (no Draco) to a node hierarchy of indexed meshes */

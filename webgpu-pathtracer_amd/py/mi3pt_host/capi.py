@@ -30,6 +30,7 @@ SYMBOLS = (
     "mi3pt_write_texture",
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
+    "mi3pt_set_env_sampling",
     "mi3pt_set_pipelining", "mi3pt_flush",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
@@ -64,6 +65,7 @@ def load_library(path=None):
     lib.mi3pt_set_storage.argtypes = [c_void_p, c_int]
     lib.mi3pt_set_tile.argtypes = [c_void_p, c_int, c_int, c_int]
     lib.mi3pt_set_kernel_variant.argtypes = [c_void_p, c_int]
+    lib.mi3pt_set_env_sampling.argtypes = [c_void_p, c_int]
     lib.mi3pt_set_pipelining.argtypes = [c_void_p, c_int]
     for name in ("mi3pt_upload_triangles", "mi3pt_upload_materials", "mi3pt_upload_bvh"):
         getattr(lib, name).argtypes = [c_void_p, c_void_p, c_size_t]
@@ -203,6 +205,10 @@ class Context:
 
     def set_kernel_variant(self, variant):
         self._c(self.lib.mi3pt_set_kernel_variant(self.handle, variant))
+
+    def set_env_sampling(self, enabled):
+        """Run the reference's dormant environment importance sampling (raytrace.wgsl:398-404 un-commented)."""
+        self._c(self.lib.mi3pt_set_env_sampling(self.handle, int(bool(enabled))))
 
     def set_pipelining(self, enabled):
         self._c(self.lib.mi3pt_set_pipelining(self.handle, int(enabled)))
