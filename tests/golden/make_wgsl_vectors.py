@@ -178,6 +178,55 @@ def main():
         rows.append(hit_row(rt.invoke("raySceneIntersect", [ray])))
     out["scene_o"], out["scene_d"], out["scene_hit"] = o, d, np.array(rows, F32)
 
+    # the 64-entry stack abort (raytrace.wgsl:167-171) on hand-made chain trees, and the strict '<' tie rule
+    # on coincident triangles: the scenes are stored with the vectors
+    def chain(depth):
+        ntri = depth + 1
+        pos = np.zeros((ntri, 3, 3))
+        for i in range(ntri):
+            pos[i] = [[-1, -1, -1.0 - i], [1, -1, -1.0 - i], [0, 1, -1.0 - i]]
+        tris = layout.pack_triangles(pos, np.tile(np.array([0.0, 0.0, 1.0]), (ntri, 3, 1)), np.arange(ntri) % 4)
+        nodes = np.zeros(2 * ntri - 1, layout.BVH_NODE)
+        box = lambda a, b: (pos[a:b + 1].reshape(-1, 3).min(0), pos[a:b + 1].reshape(-1, 3).max(0))
+        idx = 0
+        for k in range(depth):
+            nodes[idx]["min"], nodes[idx]["max"] = box(k, depth)
+            nodes[idx]["isLeaf"], nodes[idx]["left"], nodes[idx]["right"], nodes[idx]["triangleIndex"] = 0, idx + 1, idx + 2, -1
+            nodes[idx + 1]["min"], nodes[idx + 1]["max"] = box(k, k)
+            nodes[idx + 1]["isLeaf"], nodes[idx + 1]["left"], nodes[idx + 1]["right"], nodes[idx + 1]["triangleIndex"] = 1, -1, -1, k
+            idx += 2
+        nodes[idx]["min"], nodes[idx]["max"] = box(depth, depth)
+        nodes[idx]["isLeaf"], nodes[idx]["left"], nodes[idx]["right"], nodes[idx]["triangleIndex"] = 1, -1, -1, depth
+        return tris, nodes
+
+    saved = {k: rt.res[k] for k in ("triangleBuffer", "bvhBuffer")}
+    for depth in (10, 62, 63, 64, 70):
+        tris, nodes = chain(depth)
+        rt.res["triangleBuffer"], rt.res["bvhBuffer"] = buffer(rt, "Triangle", tris), buffer(rt, "BVHNode", nodes)
+        rows = []
+        for ox, oy in ((0.0, 0.0), (0.3, -0.2), (5.0, 5.0)):
+            ray = wi.Struct("Ray", {"origin": vec((ox, oy, 5.0)), "direction": vec((0.0, 0.0, -1.0))})
+            rows.append([ox, oy] + hit_row(rt.invoke("raySceneIntersect", [ray])))
+        out[f"chain{depth}_tris"] = tris.view(np.uint8).reshape(-1, 112).copy()
+        out[f"chain{depth}_nodes"] = nodes.view(np.uint8).reshape(-1, 48).copy()
+        out[f"chain{depth}_hits"] = np.array(rows, F32)
+    # two coincident triangles with different materials under one root: equal t, first visited wins
+    pos = np.array([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]]] * 2, np.float64)
+    for order in (0, 1):
+        tris = layout.pack_triangles(pos, np.tile(np.array([0.0, 0.0, 1.0]), (2, 3, 1)), np.array([1 + order, 2 - order]))
+        nodes = np.zeros(3, layout.BVH_NODE)
+        for k in range(3):
+            nodes[k]["min"], nodes[k]["max"] = pos.reshape(-1, 3).min(0), pos.reshape(-1, 3).max(0)
+        nodes[0]["isLeaf"], nodes[0]["left"], nodes[0]["right"], nodes[0]["triangleIndex"] = 0, 1, 2, -1
+        for k in (1, 2):
+            nodes[k]["isLeaf"], nodes[k]["left"], nodes[k]["right"], nodes[k]["triangleIndex"] = 1, -1, -1, k - 1
+        rt.res["triangleBuffer"], rt.res["bvhBuffer"] = buffer(rt, "Triangle", tris), buffer(rt, "BVHNode", nodes)
+        ray = wi.Struct("Ray", {"origin": vec((0.0, 0.0, 2.0)), "direction": vec((0.0, 0.0, -1.0))})
+        out[f"tie{order}_tris"] = tris.view(np.uint8).reshape(-1, 112).copy()
+        out[f"tie{order}_nodes"] = nodes.view(np.uint8).reshape(-1, 48).copy()
+        out[f"tie{order}_hit"] = np.array(hit_row(rt.invoke("raySceneIntersect", [ray])), F32)
+    rt.res.update(saved)
+
     # camera
     cams = [dict(position=(0.0, 1.0, 4.0), direction=demo.camera_direction(), fov=45.0),
             dict(position=(1.0, 2.0, -3.0), direction=(0.0, -1.0, 0.0), fov=60.0),           # the |w.up| > 0.99999 branch

@@ -71,6 +71,28 @@ def test_scene_traversal(orc, demo, vec):
     assert bits_equal(rows[hit], want[hit]), first_diff(rows[hit], want[hit])
 
 
+def test_stack_abort_and_tie_rule(orc, vec):
+    """The 64-entry abort (raytrace.wgsl:167-171: best-so-far is returned when the stack holds 64
+    entries at the top of the loop) on chain trees of depth 10..70, and the first-visited rule for
+    equal t, as the executed shader decides them."""
+    mats = layout.pack_materials([scenes.WHITE] * 4)
+    aborted = 0
+    for depth in (10, 62, 63, 64, 70):
+        tris = np.frombuffer(vec[f"chain{depth}_tris"].tobytes(), layout.TRIANGLE)
+        nodes = np.frombuffer(vec[f"chain{depth}_nodes"].tobytes(), layout.BVH_NODE)
+        sc = orc.OracleScene(tris, mats, nodes)
+        for row in vec[f"chain{depth}_hits"]:
+            got, cnt = orc.ray_scene(sc, (row[0], row[1], 5.0), (0.0, 0.0, -1.0))
+            assert bits_equal(got, row[2:]), (depth, row[:2], got, row[2:])
+            aborted += cnt["stack_overflows"]
+    assert aborted > 0                                        # the deep chains really hit the abort
+    for order in (0, 1):
+        tris = np.frombuffer(vec[f"tie{order}_tris"].tobytes(), layout.TRIANGLE)
+        nodes = np.frombuffer(vec[f"tie{order}_nodes"].tobytes(), layout.BVH_NODE)
+        got, _ = orc.ray_scene(orc.OracleScene(tris, mats, nodes), (0.0, 0.0, 2.0), (0.0, 0.0, -1.0))
+        assert bits_equal(got, vec[f"tie{order}_hit"]) and got[8] == (2 - order)      # the RIGHT leaf is visited first
+
+
 def test_camera_rays(orc, vec):
     for block, row in zip(vec["camera_uniforms"], vec["camera_uv_ray"]):
         got = orc.camera_ray(block.tobytes(), float(row[0]), float(row[1]))
