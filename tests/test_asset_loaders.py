@@ -284,3 +284,34 @@ def test_loaded_model_and_environment_render_like_the_oracle(gpu_ctx, orc, tmp_p
     assert pc.same_bits(got, want), pc.describe_diff(got, want)
     assert cnt["hits"] == ocnt["hits"] > 0 and cnt["tri_tests"] == ocnt["tri_tests"]
     ctx.resize(64, 64)
+
+
+def _decode_png(png):
+    import zlib
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(png):
+        n, = struct.unpack(">I", png[pos:pos + 4])
+        kind, data = png[pos + 4:pos + 8], png[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", png[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(kind + data) & 0xFFFFFFFF
+        chunks[kind] = data
+        pos += 12 + n
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    assert (depth, ctype) == (8, 6)
+    raw = np.frombuffer(zlib.decompress(chunks[b"IDAT"]), np.uint8).reshape(h, w * 4 + 1)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+def test_screenshot_png_writers(tmp_path):
+    """main.ts:351-356: the screenshot is the canvas as PNG; both hosts write a valid 8-bit RGBA file."""
+    from mi3pt_host import renderer
+    img = np.random.default_rng(3).integers(0, 256, (9, 13, 4)).astype(np.uint8)
+    assert np.array_equal(_decode_png(renderer.encode_png(img)), img)
+    if NODE is not None:
+        (tmp_path / "img.rgba8").write_bytes(img.tobytes())
+        js = ("const pt=require(process.argv[1]),fs=require('fs');const b=fs.readFileSync(process.argv[2]);"
+              "fs.writeFileSync(process.argv[3],pt.encodePNG(new Uint8Array(b.buffer,b.byteOffset,b.length),13,9));")
+        r = subprocess.run([NODE, "-e", js, JS, str(tmp_path / "img.rgba8"), str(tmp_path / "js.png")], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(_decode_png((tmp_path / "js.png").read_bytes()), img)

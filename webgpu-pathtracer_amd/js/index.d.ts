@@ -104,6 +104,8 @@ export class Renderer {
   /** the fullscreen pass's target, row 0 = top */
   readCanvasFloat(): Float32Array; readCanvas(): Uint8Array;
   counters(): { rays: number; boxTests: number; triTests: number; hits: number; misses: number; stackOverflows: number; pixels: number };
+  /** src/main.ts:351-356: the presented canvas as PNG bytes (written to `file` when given) */
+  screenshot(file?: string): Buffer;
   /** write the HDR accumulation image back (checkpoint / resume, gathered multi-GPU image) */
   writeAccumulation(data: Float32Array): void;
   /** launch the sample frames render() has queued, without waiting for them */
@@ -126,3 +128,4 @@ export function whiteMaterial(): RaytracingMaterial;
 /** src/main.ts:268-279: position (0, 0.5, 0), uniform scale 1 / max(bounds.max), one material */
 export function placeModel(model: Object3D, material?: RaytracingMaterial): Object3D;
 export function boundsOfObject(object: Object3D): { min: Vector3; max: Vector3 };
+export function encodePNG(rgba: Uint8Array, width: number, height: number): Buffer;

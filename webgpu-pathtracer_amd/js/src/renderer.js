@@ -180,6 +180,12 @@ class Renderer {
   readCanvasFloat() { return this.native.readTexture(this.handle, TEX_CANVAS, this._height * this._width * 4); }
   readCanvas() { return this.native.readCanvasRgba8(this.handle, this._height * this._width * 4); }
   counters() { return this.native.getCounters(this.handle); }
+  // main.ts:351-356 (canvas.toDataURL("image/png")): the presented canvas as a PNG file
+  screenshot(file) {
+    const png = encodePNG(this.readCanvas(), this._width, this._height);
+    if (file) require('fs').writeFileSync(file, png);
+    return png;
+  }
   // write the HDR accumulation image back (checkpoint/resume; a gathered multi-GPU image)
   writeAccumulation(data) { this.native.writeTexture(this.handle, TEX_ACCUMULATION, data); }
   // launch queued sample frames now without waiting for them (render() only queues them)
@@ -189,4 +195,39 @@ class Renderer {
   raytraceLaunchStats(reset) { return this.native.raytraceLaunchStats(this.handle, reset ? 1 : 0); }
 }
 
-module.exports = { Renderer, loadNative };
+// Minimal PNG writer (8-bit RGBA, one IDAT, zlib from Node): what canvas.toDataURL("image/png") holds
+function encodePNG(rgba, width, height) {
+  const zlib = require('zlib');
+  const crcTable = [];
+  for (let n = 0; n < 256; n++) {
+    let c = n;
+    for (let k = 0; k < 8; k++) c = c & 1 ? 0xedb88320 ^ (c >>> 1) : c >>> 1;
+    crcTable[n] = c >>> 0;
+  }
+  const crc32 = (buf) => {
+    let c = 0xffffffff;
+    for (let i = 0; i < buf.length; i++) c = crcTable[(c ^ buf[i]) & 0xff] ^ (c >>> 8);
+    return (c ^ 0xffffffff) >>> 0;
+  };
+  const chunk = (type, data) => {
+    const body = Buffer.concat([Buffer.from(type, 'ascii'), data]);
+    const out = Buffer.alloc(8 + data.length + 4);
+    out.writeUInt32BE(data.length, 0);
+    body.copy(out, 4);
+    out.writeUInt32BE(crc32(body), 8 + data.length);
+    return out;
+  };
+  const ihdr = Buffer.alloc(13);
+  ihdr.writeUInt32BE(width, 0);
+  ihdr.writeUInt32BE(height, 4);
+  ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+  const raw = Buffer.alloc((width * 4 + 1) * height);
+  for (let y = 0; y < height; y++) {
+    raw[y * (width * 4 + 1)] = 0;
+    Buffer.from(rgba.buffer, rgba.byteOffset + y * width * 4, width * 4).copy(raw, y * (width * 4 + 1) + 1);
+  }
+  return Buffer.concat([Buffer.from([0x89, 0x50, 0x4e, 0x47, 0x0d, 0x0a, 0x1a, 0x0a]), chunk('IHDR', ihdr),
+    chunk('IDAT', zlib.deflateSync(raw)), chunk('IEND', Buffer.alloc(0))]);
+}
+
+module.exports = { Renderer, loadNative, encodePNG };

@@ -52,6 +52,7 @@ async function main() {
   const canvas = renderer.readCanvas();
   fs.writeFileSync(out + '.acc.f32', Buffer.from(acc.buffer));
   fs.writeFileSync(out + '.canvas.rgba8', Buffer.from(canvas.buffer));
+  renderer.screenshot(out + '.png');
   const summary = {
     width, height, frames, status: renderer.status, frame: renderer.frame, events,
     counters: renderer.counters(), stats: renderer.passes.raytrace.stats, wall_ms: ms,

@@ -339,3 +339,30 @@ class Renderer:
 
     def readCanvas(self):
         return self.ctx.read_canvas_rgba8()
+
+    def screenshot(self, path=None):
+        """main.ts:351-356 (canvas.toDataURL("image/png")): the presented canvas as PNG bytes."""
+        png = encode_png(self.readCanvas())
+        if path:
+            with open(path, "wb") as f:
+                f.write(png)
+        return png
+
+
+def encode_png(rgba8):
+    """8-bit RGBA, one IDAT chunk."""
+    import struct
+    import zlib
+    import numpy as np
+    img = np.ascontiguousarray(rgba8, np.uint8)
+    h, w = img.shape[:2]
+    raw = np.zeros((h, w * 4 + 1), np.uint8)
+    raw[:, 1:] = img.reshape(h, w * 4)
+
+    def chunk(kind, data):
+        body = kind + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xFFFFFFFF)
+
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw.tobytes())) + chunk(b"IEND", b""))
+
