@@ -89,10 +89,11 @@ def main():
     rt.res["environmentCDFTexture"] = wi.Texture(np.zeros((2, 2, 4), F32), "nearest", "clamp")
     rt.res["environmentCDFTextureSampler"] = "sampler"
 
-    def set_uniforms(w, h, frame=2, bounces=3, spf=1, aperture=0.0, focal=1.0, rotation=0.0, intensity=1.0, cam=None):
+    def set_uniforms(w, h, frame=2, bounces=3, spf=1, aperture=0.0, focal=1.0, rotation=0.0, intensity=1.0, cam=None, scaling=1.0):
         u = layout.UniformBlock(layout.RAYTRACE_UNIFORMS)
         cam = cam or dict(position=demo.camera["position"], direction=demo.camera_direction(), fov=demo.camera["fov"])
-        u.set({"resolution": [w, h], "aspect": w / h, "frame": frame, "maxBounces": bounces, "samplesPerFrame": spf,
+        # raytrace.ts:371-378: resolution = scaledWidth x scaledHeight (may be fractional), aspect = width / height
+        u.set({"resolution": [w * scaling, h * scaling], "aspect": w / h, "frame": frame, "maxBounces": bounces, "samplesPerFrame": spf,
                "camera": {"position": cam["position"], "direction": cam["direction"], "fov": cam["fov"],
                           "focalDistance": focal, "aperture": aperture},
                "envMapIntensity": intensity, "envMapRotation": rotation})
@@ -261,7 +262,8 @@ def main():
     # whole frames: computeMain over every pixel of small images
     frames = [dict(w=24, h=16, frame=2, bounces=3), dict(w=24, h=16, frame=5, bounces=3, aperture=0.05, focal=4.1),
               dict(w=16, h=12, frame=3, bounces=2, spf=2, rotation=0.7, intensity=1.5), dict(w=8, h=8, frame=2, bounces=0),
-              dict(w=11, h=7, frame=9, bounces=4)]
+              dict(w=11, h=7, frame=9, bounces=4),
+              dict(w=24, h=16, frame=2, bounces=2, scaling=0.7)]     # scalingFactor < 1: fractional resolution, sub-rectangle
     for fi, cfg in enumerate(frames):
         w, h = cfg["w"], cfg["h"]
         u = set_uniforms(**cfg)
@@ -271,7 +273,8 @@ def main():
             for x in range(w + 1):
                 rt.invoke("computeMain", [vec((x, y, 0), "u")])
         img = np.zeros((h, w, 4), F32)
-        assert set(tex.stores) == {(x, y) for y in range(h) for x in range(w)}
+        sw, sh = int(w * cfg.get("scaling", 1.0)), int(h * cfg.get("scaling", 1.0))
+        assert set(tex.stores) == {(x, y) for y in range(sh) for x in range(sw)}
         for (x, y), v in tex.stores.items():
             img[y, x] = v
         out[f"frame{fi}_uniforms"], out[f"frame{fi}_image"] = np.frombuffer(u.tobytes(), np.uint8), img

@@ -117,7 +117,7 @@ def test_whole_frames_match_the_executed_shader(orc, demo, env, vec):
     env rotation / intensity, maxBounces 0, ragged sizes)."""
     sc = pc.oracle_scene(orc, demo, env)
     ids = _frame_ids(vec)
-    assert len(ids) >= 5
+    assert len(ids) >= 6                                    # incl. the scalingFactor 0.7 sub-rectangle
     for i in ids:
         want = vec[f"frame{i}_image"]
         h, w = want.shape[:2]
