@@ -238,7 +238,7 @@ int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, flo
  * (begin, work-queue-empty, end on the 100 MHz wall clock; shader cycles begin->end; then
  * packed step statistics: walk steps | walking lanes, service steps | leaf lanes,
  * shaded lanes | hit lanes, path starts | segment starts; [8] triangle steps of the
- * deferred-leaf walk; [9..15] reserved).
+ * deferred-leaf walk; [9..11] shader cycles spent in node / triangle / service steps; [12..15] reserved).
  * out == NULL: enable != 0 allocates the buffer, enable == 0 frees it. */
 int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out, size_t capacity_slots, size_t *slots_out);
 

@@ -79,3 +79,10 @@ if tri_steps:
     print(f"deferred-leaf walk: the walk steps above are node steps; triangle steps {tri_steps} "
           f"({tri_steps / nframes / 1e6:.3f} M per frame), lanes/triangle step {leaf_lanes / tri_steps:.1f}")
 print(f"steps per wave: walk {walk_steps / len(raw):.0f}  triangle {tri_steps / len(raw):.0f}  service {service_steps / len(raw):.0f}")
+if raw.shape[1] > 11 and raw[:, 9:12].any():
+    cyc = raw[:, 9:12].astype(np.float64).sum(0)
+    tot = cyc.sum()
+    print(f"shader cycles by kind of step (deferred-leaf walk): node {cyc[0] / tot:.1%}  triangle {cyc[1] / tot:.1%}  "
+          f"service (+ loop overhead) {cyc[2] / tot:.1%};  per step: node {cyc[0] / max(walk_steps, 1):.0f}  "
+          f"triangle {cyc[1] / max(tri_steps, 1):.0f}  service {cyc[2] / max(service_steps, 1):.0f} cycles")
+

@@ -983,6 +983,15 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     // diagnostic step statistics (wave-uniform; stored with the stamps)
     uint32_t st_walk_steps = 0, st_walk_lanes = 0, st_leaf_lanes = 0, st_service_steps = 0;
     uint32_t st_shade_lanes = 0, st_hit_lanes = 0, st_path_lanes = 0, st_segment_lanes = 0, st_tri_steps = 0;
+    uint64_t st_cyc_node = 0, st_cyc_tri = 0, st_cyc_service = 0, st_mark = t_begin_clk;     // shader cycles per kind of step
+    int st_kind = 2;
+    auto st_switch = [&](int kind) {     // diagnostic only: the time since the last switch belongs to the step that ran
+        const uint64_t now = __builtin_amdgcn_s_memtime();
+        const uint64_t dt = now - st_mark;
+        if (st_kind == 0) st_cyc_node += dt; else if (st_kind == 1) st_cyc_tri += dt; else st_cyc_service += dt;
+        st_mark = now;
+        st_kind = kind;
+    };
     const int lcap = L.scene.leaf_cap;      // DEFER: capacity of a lane's leaf list
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1043,7 +1052,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
             const bool full = __ballot(trav && nl > lcap - 2) != 0ull;      // a node step may park two more
             if (full || n_node == 0 || n_leaf >= L.leaf_min) {
-                if (L.wave_times) { st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; }
+                if (L.wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; }
                 if (has_leaf) {
                     nl--;
                     const uint32_t ti = stack[(PT_SM_LDS_DEPTH - 1 - nl) * 64];
@@ -1061,7 +1070,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                 }
             } else {
-                if (L.wave_times) { st_walk_steps++; st_walk_lanes += (uint32_t)n_node; }
+                if (L.wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; }
                 if (has_node) {
                     sp--;
                     const uint32_t ref = stack[sp * 64];
@@ -1187,6 +1196,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
 
         // ---- service step
         if (L.wave_times) {
+            st_switch(2);
             st_service_steps++;
             st_shade_lanes += (uint32_t)__popcll(__ballot(mode == M_SHADE));
             st_hit_lanes += (uint32_t)__popcll(__ballot(mode == M_SHADE && best.tri >= 0));
@@ -1331,7 +1341,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
 
     if (L.wave_times && lane == 0) {
         uint64_t *w = L.wave_times + (size_t)blockIdx.x * 16;
+        st_switch(2);
         w[8] = st_tri_steps;
+        w[9] = st_cyc_node; w[10] = st_cyc_tri; w[11] = st_cyc_service;
         w[0] = t_begin_rt;
         w[1] = t_empty_rt;
         w[2] = __builtin_amdgcn_s_memrealtime();
