@@ -524,6 +524,27 @@ def test_full_hd_properties(gpu_ctx, orc, demo, env):
     assert pc.max_rel_err(frame_img[480:496], part) <= REL_TOL
 
 
+def test_repeated_runs_are_bit_identical(gpu_ctx, demo, env):
+    """The persistent kernel hands out jobs dynamically (which wave renders which pixel, and with
+    which lane neighbours, changes from run to run); the image must not."""
+    w, h = 1280, 720
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    runs = []
+    for _ in range(3):
+        ctx.reset()
+        ctx.reset_counters()
+        for f in range(2, 22):                   # more than one 16-frame batch: both streams, launch gating
+            pc.gpu_frame(ctx, pc.rt_uniforms(demo, w, h, frame=f, bounces=8), pc.acc_uniforms(w, h, f),
+                         capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+        runs.append((ctx.read_texture(capi.TEX_ACCUMULATION).tobytes(), ctx.counters()))
+    assert runs[0][0] == runs[1][0] == runs[2][0]
+    assert runs[0][1] == runs[1][1] == runs[2][1]
+    ctx.resize(64, 64)
+
+
 def test_no_cpu_fallback_symbols(built):
     """The product library must not contain an oracle / CPU render path."""
     import subprocess
