@@ -204,10 +204,11 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
 /* Kernel variant: 0 = auto, 1 = per-pixel kernel walking the uploaded records,
  * 2 = per-pixel kernel walking node packets, 3 = persistent waves with lane refill,
  * 4 = persistent per-lane state machine (the default), 5 = 4 with a walk threshold of 48,
- * 6 = 4 with the top 64 node packets staged in LDS (measured: no gain),
+ * 6 = 4 with the top 32 node packets staged in LDS (measured: no gain),
  * 7 = 4 with leaf tests deferred into triangle steps of their own; needs a proper tree whose
- * worst-case stack stays below 29 entries (checked at upload), otherwise 4 runs.  auto = 7
- * when the scene allows it, else 4.  All variants produce the same bits. */
+ * worst-case stack stays below 29 entries (checked at upload), otherwise 4 runs; 8 = 7 with the
+ * LDS-staged top of the tree of 6 (measured: no gain).  auto = 7 when the scene allows it, else 4.
+ * All variants produce the same bits. */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
 /* The reference's environment importance sampling (raytrace.wgsl:315-367: getEnvironmentMapUV /
  * ...MarginalCDF / ...ConditionalCDF / ...PDF over the CDF texture of renderer.ts:159-266) is dead

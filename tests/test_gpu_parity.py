@@ -260,7 +260,7 @@ def test_equal_t_ties_keep_the_first_visited_leaf_in_every_kernel(gpu_ctx, orc, 
         want = orc.accumulate(pc.acc_uniforms(w, h, f).tobytes(), w, h, img, want)
         ocnt = c if ocnt is None else {k: ocnt[k] + c[k] for k in c}
     picked = set()
-    for variant in (2, 4, 7):
+    for variant in (2, 4, 7, 8):
         ctx.set_kernel_variant(variant)
         ctx.reset()
         ctx.reset_counters()
@@ -293,7 +293,7 @@ FRAME_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("case", FRAME_CASES, ids=[f"{c[0]}x{c[1]}-b{c[2]}-s{c[3]}-a{c[4]}" for c in FRAME_CASES])
 def test_raytrace_pass_bit_identical(gpu_ctx, orc, demo, env, case, variant):
     w, h, bounces, spf, aperture, focal, frame, rotation = case
@@ -493,15 +493,15 @@ def test_full_hd_properties(gpu_ctx, orc, demo, env):
     u = pc.rt_uniforms(demo, w, h, frame=2, bounces=8)
     a = pc.acc_uniforms(w, h, 2)
     images = {}
-    for variant in (1, 2, 3, 4, 5, 6, 7):
+    for variant in (1, 2, 3, 4, 5, 6, 7, 8):
         ctx.set_kernel_variant(variant)
         ctx.reset()
         ctx.reset_counters()
         pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
         images[variant] = (ctx.read_texture(capi.TEX_ACCUMULATION), ctx.counters())
-    assert all(pc.same_bits(images[v][0], images[2][0]) for v in (1, 3, 4, 5, 6, 7))
+    assert all(pc.same_bits(images[v][0], images[2][0]) for v in (1, 3, 4, 5, 6, 7, 8))
     strip = lambda c: {k: v for k, v in c.items() if k != "reserved"}   # (reserved = fallback-slab count)
-    assert all(strip(images[v][1]) == strip(images[2][1]) for v in (1, 3, 4, 5, 6, 7))
+    assert all(strip(images[v][1]) == strip(images[2][1]) for v in (1, 3, 4, 5, 6, 7, 8))
     cnt = images[2][1]
     # the prepared-reciprocal slab test is really in use: only a small share of segments falls back
     assert images[4][1]["reserved"] < 0.05 * cnt["rays"]

@@ -286,7 +286,7 @@ extern "C" int mi3pt_set_env_sampling(mi3pt_ctx *ctx, int enabled)
 extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
-    if (variant < 0 || variant > 7) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..7");
+    if (variant < 0 || variant > 8) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..8");
     if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
     return MI3PT_OK;
@@ -640,7 +640,7 @@ static int pick_variant(const mi3pt_ctx *ctx)
     if (ctx->env_sampling) return 2;               // the dormant path lives in the per-pixel kernel only
     const bool defer_ok = ctx->leaf_cap >= 4;      // see mi3pt_upload_bvh: leaves may be tested out of order
     if (ctx->variant == 0) return defer_ok ? 7 : 4;
-    if (ctx->variant == 7 && !defer_ok) return 4;
+    if (ctx->variant >= 7 && !defer_ok) return ctx->variant == 8 ? 6 : 4;
     return ctx->variant;
 }
 // the walk the probe runs: 1 = uploaded records, 2 = packets, 3 = packets + prepared-reciprocal slab test

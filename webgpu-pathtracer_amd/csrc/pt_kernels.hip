@@ -18,7 +18,7 @@
 //       triangle / service steps, (frame slot, tile) jobs from a self-cleaning queue;
 //       DEFER = leaves parked and tested in steps of their own (variant 7, the default when
 //       the tree allows it), !DEFER = in-order walk (variant 4; 5 = other walk threshold),
-//       TOPLDS = top of the tree staged in LDS (variant 6, measured slower)
+//       TOPLDS = top of the tree staged in LDS (variants 6 and 8, measured no faster)
 //   k_accumulate[_batch]       accumulate.wgsl computeMain (one frame / an ordered batch of frames)
 //   k_fullscreen               fullscreen.wgsl fragmentMain (de-noise + tone-map)
 //   k_debug_intersect/_math    component probes for the parity tests
@@ -896,7 +896,7 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
 enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
 
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
-#define PT_SM_TOP_PACKETS 64       // node packets staged in LDS per wave: the top 6 levels of the tree
+#define PT_SM_TOP_PACKETS 32       // node packets staged in LDS per wave (2 KB: 16 waves per CU still fit): the top 5 levels
 #ifndef PT_SM_MIN_WAVES
 #define PT_SM_MIN_WAVES 4
 #endif
@@ -1074,8 +1074,15 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (has_node) {
                     sp--;
                     const uint32_t ref = stack[sp * 64];
-                    const float4 p0 = sc.packets[(size_t)ref * 4 + 0], p1 = sc.packets[(size_t)ref * 4 + 1];
-                    const float4 p2 = sc.packets[(size_t)ref * 4 + 2], p3 = sc.packets[(size_t)ref * 4 + 3];
+                    float4 p0, p1, p2, p3;
+                    if (TOPLDS && ref < ntop) {       // top of the tree: this wave's LDS copy
+                        p0 = top_lds[ref * 4 + 0]; p1 = top_lds[ref * 4 + 1];
+                        p2 = top_lds[ref * 4 + 2]; p3 = top_lds[ref * 4 + 3];
+                        asm volatile("" : "+v"(p0.x), "+v"(p1.x), "+v"(p2.x), "+v"(p3.x));   // keep these ds_read_b128
+                    } else {
+                        p0 = sc.packets[(size_t)ref * 4 + 0]; p1 = sc.packets[(size_t)ref * 4 + 1];
+                        p2 = sc.packets[(size_t)ref * 4 + 2]; p3 = sc.packets[(size_t)ref * 4 + 3];
+                    }
                     const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
                     const uint32_t pf = __float_as_uint(p3.z);
                     cnt.box += 2;                  // proper tree: both children exist
@@ -1402,6 +1409,9 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
         } else if (variant == 6) {
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, true, false>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_sm<false, true, false>), grid, block, 0, s, L);
+        } else if (variant == 8) {                       // deferred leaves + top of the tree in LDS
+            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, true, true>), grid, block, 0, s, L);
+            else hipLaunchKernelGGL((k_raytrace_sm<false, true, true>), grid, block, 0, s, L);
         } else if (variant == 7) {
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_sm<false, false, true>), grid, block, 0, s, L);
