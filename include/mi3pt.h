@@ -230,6 +230,13 @@ int mi3pt_set_pipelining(mi3pt_ctx *ctx, int enabled);
  * (hit, t, position xyz, normal xyz, materialIndex, box tests, triangle tests,
  * stack overflows) = raySceneIntersect, raytrace.wgsl:205-211. */
 int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n, float *out);
+/* Design experiment, not part of the rendering path: walks `n` given rays (6 floats each) with the
+ * deferred-leaf walk ALONE (no shading) as a persistent kernel with 4, 5, 6 or 8 resident waves
+ * per SIMD, `passes` times over the list inside one launch (amortises the drain), and reports the
+ * best of `repeats` kernel times; out_tuvi (optional) receives (t, u, v, triangle as int bits) per
+ * ray = the hit raySceneIntersect would report. */
+int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t n, int waves_per_simd, int repeats, int passes,
+                           float *out_tuvi, float *ms_out);
 /* fn: 0 sin, 1 cos, 2 tan, 3 log, 4 exp, 5 atan2(a,b), 6 asin, 7 pow(a,b),
  * 8 fp16 round trip, 9 sqrt, 10 a/b; the kernels' reduced-instruction forms: 11 sqrt, 12 1/a,
  * 13..15 x/y/z of normalize(a, b, a - b).  b may be NULL for unary functions. */

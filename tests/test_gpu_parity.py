@@ -524,6 +524,23 @@ def test_full_hd_properties(gpu_ctx, orc, demo, env):
     assert pc.max_rel_err(frame_img[480:496], part) <= REL_TOL
 
 
+def test_walk_probe_reports_the_same_hits(gpu_ctx, demo, env):
+    """mi3pt_debug_walk_probe (the walk-only occupancy experiment of profiles/walk_probe.py) must
+    find the hits raySceneIntersect finds, at every occupancy it offers."""
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    rays = _random_rays(np.random.default_rng(21), 50000)
+    ref = ctx.debug_intersect(rays)
+    for waves in (4, 5, 6, 8):
+        ms, hits = ctx.walk_probe(rays, waves, repeats=1, want_hits=True, passes=2)
+        assert ms > 0
+        hit = hits[:, 3].view(np.int32) >= 0
+        assert np.array_equal(hit, ref[:, 0] == 1)
+        assert pc.same_bits(hits[hit, 0], ref[hit, 1])            # t of the closest hit
+    with pytest.raises(capi.Mi3ptError):
+        ctx.walk_probe(rays, 7)
+
+
 def test_repeated_runs_are_bit_identical(gpu_ctx, demo, env):
     """The persistent kernel hands out jobs dynamically (which wave renders which pixel, and with
     which lane neighbours, changes from run to run); the image must not."""

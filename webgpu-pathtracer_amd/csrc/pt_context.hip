@@ -1067,6 +1067,51 @@ extern "C" int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n
     return MI3PT_OK;
 }
 
+extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t n, int waves_per_simd, int repeats, int passes,
+                                      float *out_tuvi, float *ms_out)
+{
+    if (int rc = require_idle(ctx)) return rc;
+    if (passes < 1) passes = 1;
+    if (!rays || !ms_out || n == 0 || n * (size_t)passes > 0x7fffffffu) return pt_set_error(MI3PT_ERR_INVALID, "bad argument");
+    if (int rc = check_scene(ctx)) return rc;
+    const int lcap = ctx->leaf_cap - (pt::SM_LDS_DEPTH - 16);        // the probe keeps 16 stack entries per lane in LDS
+    if (ctx->nnodes == 0 || lcap < 4) return pt_set_error(MI3PT_ERR_STATE, "the scene's tree is too deep for the walk probe");
+    float *d_rays = nullptr;
+    float4 *d_out = nullptr;
+    uint32_t *d_counter = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void **)&d_rays, n * 24);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_counter, 4);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * 24, hipMemcpyHostToDevice, ctx->stream);
+    float best_ms = 0.0f;
+    for (int r = 0; e == hipSuccess && r < (repeats > 0 ? repeats : 1); r++) {
+        e = hipMemsetAsync(d_counter, 0, 4, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+        if (e == hipSuccess && !pt::launch_walk_probe(scene_refs(ctx), d_rays, (uint32_t)n, (uint32_t)(n * (size_t)passes), d_counter, d_out, waves_per_simd, lcap,
+                                                      ctx->leaf_min, ctx->stream)) {
+            pt_set_error(MI3PT_ERR_INVALID, "waves_per_simd must be 4, 5, 6 or 8");
+            e = hipErrorInvalidValue;
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && (r == 0 || ms < best_ms)) best_ms = ms;
+    }
+    if (e == hipSuccess && out_tuvi) e = hipMemcpy(out_tuvi, d_out, n * 16, hipMemcpyDeviceToHost);
+    for (void *p : { (void *)d_rays, (void *)d_out, (void *)d_counter })
+        if (p) (void)hipFree(p);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("debug_walk_probe: ") + hipGetErrorString(e));
+    *ms_out = best_ms;
+    return MI3PT_OK;
+}
+
 extern "C" int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n)
 {
     if (int rc = require_idle(ctx)) return rc;

@@ -123,6 +123,8 @@ void launch_fullscreen(const FsUniforms &fs, const float4 *tex, int tex_w, int t
 void launch_debug_intersect(const SceneRefs &scene, const float *rays, size_t n, float *out, int variant,
                             hipStream_t s);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s);
+int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, uint32_t total, uint32_t *counter, float4 *out, int waves_per_simd,
+                      int lcap, int leaf_min, hipStream_t s);
 int raytrace_grid_blocks(const Tile &tile);
 int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu);
 

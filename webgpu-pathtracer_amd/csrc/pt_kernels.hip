@@ -1771,6 +1771,133 @@ __global__ void __launch_bounds__(256) k_debug_math(int fn, const float *__restr
     out[i] = r;
 }
 
+// ---------------------------------------------------------------------------------
+// Experiment kernel: the deferred-leaf walk ALONE (no shading, no camera) over a given list of
+// rays, as a persistent kernel at a chosen occupancy.  It answers one design question -- how
+// much would a walk that needs few registers gain from 5..8 resident waves per SIMD -- and is
+// not part of the rendering path (mi3pt_debug_walk_probe).  LDS: DEPTH entries per lane; the
+// caller guarantees that the scene's stack bound fits (leaf_cap is recomputed for DEPTH).
+// ---------------------------------------------------------------------------------
+template <int MINW, int DEPTH>
+__global__ void __launch_bounds__(64, MINW) k_walk_probe(const SceneRefs sc, const float *__restrict__ rays, uint32_t nrays, uint32_t total,
+                                                         uint32_t *__restrict__ counter, float4 *__restrict__ out, int lcap, int leaf_min)
+{
+    __shared__ uint32_t stack_lds[DEPTH * 64];
+    const int lane = threadIdx.x;
+    uint32_t *stack = stack_lds + lane;
+    float4 root0 = sc.nodes[0], root1 = sc.nodes[1];
+    f3 o = F3(0.0f, 0.0f, 0.0f), d = o;
+    RayPre pre;
+    pre.ix = pre.iy = pre.iz = 0.0f; pre.flags = 8u;
+    Best best;
+    best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
+    int sp = 0, nl = 0;
+    uint32_t ray = 0xffffffffu;          // 0xffffffff: idle
+    bool exhausted = false;
+    uint32_t chunk_next = 0u, chunk_left = 0u;
+    for (;;) {
+        // refill: idle lanes take the next rays of this wave's chunk (one atomic per 2048 rays)
+        const unsigned long long idle = __ballot(ray == 0xffffffffu);
+        if (idle != 0ull && !exhausted) {
+            if (chunk_left == 0u) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(counter, 2048u);
+                chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                chunk_left = chunk_next < total ? min(2048u, total - chunk_next) : 0u;
+                if (chunk_left == 0u) exhausted = true;
+            }
+            const uint32_t take = min((uint32_t)__popcll(idle), chunk_left);
+            const uint32_t rank = (uint32_t)lane_rank(idle);
+            if (ray == 0xffffffffu && rank < take) {
+                uint32_t mine = chunk_next + rank;
+                {
+                    mine %= nrays;                 // the list is walked `total / nrays` times (amortises the drain)
+                    ray = mine;
+                    o = F3(rays[(size_t)mine * 6 + 0], rays[(size_t)mine * 6 + 1], rays[(size_t)mine * 6 + 2]);
+                    d = F3(rays[(size_t)mine * 6 + 3], rays[(size_t)mine * 6 + 4], rays[(size_t)mine * 6 + 5]);
+                    best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
+                    pre = ray_prepare(o, d, sc.flags);
+                    sp = nl = 0;
+                    if (ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
+                        if (sc.root_ref & PT_REF_LEAF) { stack[(DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu; nl = 1; }
+                        else { stack[0] = sc.root_ref; sp = 1; }
+                    }
+                }
+            }
+            chunk_next += take;
+            chunk_left -= take;
+        }
+        // retire finished rays
+        if (ray != 0xffffffffu && sp == 0 && nl == 0) {
+            out[ray] = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
+            ray = 0xffffffffu;
+        }
+        const bool trav = ray != 0xffffffffu;
+        const unsigned long long walking = __ballot(trav);
+        if (walking == 0ull) { if (exhausted) break; else continue; }
+        // a few walk steps between refills
+        for (int it = 0; it < 8; it++) {
+            const bool t2 = ray != 0xffffffffu && (sp > 0 || nl > 0);
+            const bool has_node = t2 && sp > 0, has_leaf = t2 && nl > 0;
+            const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
+            if (n_node == 0 && n_leaf == 0) break;
+            const bool full = __ballot(t2 && nl > lcap - 2) != 0ull;
+            if (full || n_node == 0 || n_leaf >= leaf_min) {
+                if (has_leaf) {
+                    nl--;
+                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64];
+                    const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
+                    const float4 pb = sc.tripk[(size_t)ti * 3 + 1];
+                    const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
+                    float t, u, v;
+                    if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v)) {
+                        bool take = t < best.t;
+                        if (t == best.t && best.tri >= 0) take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
+                        if (take) { best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti; }
+                    }
+                }
+            } else if (has_node) {
+                sp--;
+                const uint32_t ref = stack[sp * 64];
+                const float4 p0 = sc.packets[(size_t)ref * 4 + 0], p1 = sc.packets[(size_t)ref * 4 + 1];
+                const float4 p2 = sc.packets[(size_t)ref * 4 + 2], p3 = sc.packets[(size_t)ref * 4 + 3];
+                const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
+                const uint32_t pf = __float_as_uint(p3.z);
+                bool hl, hr;
+                if (((pre.flags & 8u) | pf) == 0u) {
+                    hl = ray_aabb_fast(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                    hr = ray_aabb_fast(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
+                } else {
+                    hl = ray_aabb_pre(o, d, pre, (pf & 1u) != 0u, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                    hr = ray_aabb_pre(o, d, pre, (pf & 2u) != 0u, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
+                }
+                const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
+                stack[(ll ? DEPTH - 1 - nl : sp) * 64] = ll ? (lref & 0x7fffffffu) : lref;
+                nl += (hl && ll) ? 1 : 0;
+                sp += (hl && !ll) ? 1 : 0;
+                stack[(rl ? DEPTH - 1 - nl : sp) * 64] = rl ? (rref & 0x7fffffffu) : rref;
+                nl += (hr && rl) ? 1 : 0;
+                sp += (hr && !rl) ? 1 : 0;
+            }
+        }
+    }
+}
+
+// returns 0 when the occupancy is not instantiated
+int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, uint32_t total, uint32_t *counter, float4 *out, int waves_per_simd,
+                      int lcap, int leaf_min, hipStream_t s)
+{
+    const dim3 block(64);
+    const dim3 grid(256 * 4 * waves_per_simd);
+    switch (waves_per_simd) {
+    case 4: hipLaunchKernelGGL((k_walk_probe<4, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
+    case 5: hipLaunchKernelGGL((k_walk_probe<5, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
+    case 6: hipLaunchKernelGGL((k_walk_probe<6, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
+    case 8: hipLaunchKernelGGL((k_walk_probe<8, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
+    default: return 0;
+    }
+}
+
 void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s)
 {
     if (n == 0) return;

@@ -30,7 +30,7 @@ SYMBOLS = (
     "mi3pt_write_texture",
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
-    "mi3pt_set_env_sampling",
+    "mi3pt_set_env_sampling", "mi3pt_debug_walk_probe",
     "mi3pt_set_pipelining", "mi3pt_flush",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
@@ -90,6 +90,7 @@ def load_library(path=None):
     lib.mi3pt_reset_counters.argtypes = [c_void_p]
     lib.mi3pt_debug_intersect.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.mi3pt_debug_math.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t]
+    lib.mi3pt_debug_walk_probe.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.mi3pt_debug_wave_times.argtypes = [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]
     lib.mi3pt_host_build_bvh.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
     lib.mi3pt_host_build_bvh_f64.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
@@ -319,6 +320,15 @@ class Context:
         n = ctypes.c_size_t()
         self._c(self.lib.mi3pt_debug_wave_times(self.handle, 1, _ptr(out), len(out), ctypes.byref(n)))
         return out[:n.value]
+
+    def walk_probe(self, rays, waves_per_simd, repeats=3, want_hits=False, passes=1):
+        """Walk-only occupancy experiment (mi3pt_debug_walk_probe): returns (ms, hits or None)."""
+        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros((len(r), 4), np.float32) if want_hits else None
+        ms = ctypes.c_float()
+        self._c(self.lib.mi3pt_debug_walk_probe(self.handle, _ptr(r), len(r), int(waves_per_simd), int(repeats), int(passes),
+                                                _ptr(out) if out is not None else None, ctypes.byref(ms)))
+        return ms.value, out
 
     def debug_math(self, fn, a, b=None):
         a = np.ascontiguousarray(a, np.float32)
