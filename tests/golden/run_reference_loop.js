@@ -1,0 +1,131 @@
+'use strict';
+// TEST INFRASTRUCTURE.  Runs a script of Renderer calls (resize / render / pause / start / reset / property
+// writes) against (a) the reference's own Renderer state machine -- the methods of src/renderer.ts
+// :283-468 cut out of the reference checkout at run time, TypeScript annotations stripped, running
+// on recording stubs -- and (b) this repository's Node Renderer on a recording native stub, and
+// prints one trace per implementation: for every call the events emitted, status, frame, progress
+// and the passes that were encoded.
+//   node run_reference_loop.js <script.json> [<reference-root>]     (without a root only (b) runs)
+const fs = require('fs');
+const path = require('path');
+
+const MEMBERS = ['resize', 'get scalingFactor', 'set scalingFactor', 'get width', 'get scaledWidth', 'get height',
+  'get scaledHeight', 'get aspect', 'get canvas', 'get hasFramesToSample', 'get progress', 'get frame', 'set frame',
+  'setUniforms', 'update', 'render', 'reset', 'start', 'pause', 'on', 'emit'];
+
+function extractMember(source, name) {
+  // first occurrence that has a body: overload declarations end in ';' before any '{'
+  const re = new RegExp('^[ \\t]*(?:private |public |protected |async )*' + name.replace(' ', '\\s+') + '\\s*\\(', 'gm');
+  let m;
+  while ((m = re.exec(source)) !== null) {
+    let depth = 0, k = source.indexOf('(', m.index);
+    for (; k < source.length; k++) { if (source[k] === '(') depth++; else if (source[k] === ')') { depth--; if (depth === 0) break; } }
+    let j = k + 1;
+    while (j < source.length && source[j] !== '{' && source[j] !== ';') j++;
+    if (source[j] !== '{') continue;                         // an overload signature
+    let d = 0, e = j;
+    for (; e < source.length; e++) { if (source[e] === '{') d++; else if (source[e] === '}') { d--; if (d === 0) break; } }
+    return source.slice(m.index, e + 1);
+  }
+  throw new Error('member ' + name + ' not found in the reference source');
+}
+
+function stripTypes(ts) {
+  let js = ts.replace(/\b(private|public|protected)\s+/g, '');
+  js = js.replace(/\b(const|let|var)\s+([A-Za-z_$][\w$]*)\s*:\s*[^=;\n]+?\s*=/g, '$1 $2 =');
+  js = js.replace(/((?:get |set )?[A-Za-z_$][\w$]*)\s*\(([^()]*(?:\([^()]*\)[^()]*)*)\)\s*(:\s*[A-Za-z_$][\w$.\[\]<>]*)?\s*\{/g, (all, fname, params, ret) => {
+    if (['if', 'for', 'while', 'switch', 'catch'].includes(fname)) return all;
+    if (!ret && !/:/.test(params)) return all;
+    // split on top-level commas only (callback types contain commas inside parentheses)
+    const parts = [];
+    let depth = 0, cur = '';
+    for (const c of params) {
+      if (c === '(' || c === '<' || c === '[') depth++;
+      if (c === ')' || c === '>' || c === ']') depth--;
+      if (c === ',' && depth === 0) { parts.push(cur); cur = ''; } else cur += c;
+    }
+    if (cur.trim().length) parts.push(cur);
+    const stripped = parts.map((p) => p.replace(/\s*:\s*[\s\S]*$/, '').trim()).filter((p) => p.length).join(', ');
+    return fname + '(' + stripped + ') {';
+  });
+  js = js.replace(/\(([A-Za-z_$][\w$]*)\s*:\s*[A-Za-z_$][\w$.\[\]<>]*\)\s*=>/g, '($1) =>');       // (callback: any) => ...
+  js = js.replace(/null!/g, 'null').replace(/\)!/g, ')');
+  js = js.replace(/this\.listeners\.get\(event\)\?\./g, '(this.listeners.get(event) || []).');       // Node 12 has no ?.
+  return js;
+}
+
+function passStub(log, name) {
+  return {
+    timingAverage: name, setUniforms: (v) => log.uniforms.push([name, v]), update: () => {}, updateScene: () => {},
+    render: () => log.encoded.push(name), updateTimings: () => {},
+  };
+}
+
+function makeReference(root) {
+  const src = fs.readFileSync(path.join(root, 'src', 'renderer.ts'), 'utf8');
+  const body = MEMBERS.map((n) => stripTypes(extractMember(src, n))).join('\n\n');
+  const Ref = new Function('return class RefRenderer {\n' + body + '\n};')();      // eslint-disable-line no-new-func
+  const r = new Ref();
+  const log = { encoded: [], uniforms: [] };
+  // field initialisers of renderer.ts:21-45
+  r._canvas = { width: 0, height: 0 };
+  r._frame = 1;
+  r.listeners = new Map();
+  r._scalingFactor = 0.25;
+  r.frames = 64;
+  r.samplesPerFrame = 1;
+  r.status = 'idle';
+  r.passes = { raytrace: passStub(log, 'raytrace'), accumulate: passStub(log, 'accumulate'), fullscreen: passStub(log, 'fullscreen') };
+  r.device = { createCommandEncoder: () => ({ finish: () => 'commands' }), queue: { submit: () => {} } };
+  r.createStorageTexture = () => 'texture';
+  return { r, takeEncoded: () => { const e = log.encoded.slice(); log.encoded.length = 0; return e; } };
+}
+
+function makeMine() {
+  const pt = require(path.join(__dirname, '..', '..', 'webgpu-pathtracer_amd', 'js'));
+  let lastMask = 0;
+  const native = new Proxy({}, { get: (t, name) => (...args) => {
+    if (name === 'submit') { lastMask |= args[1]; return undefined; }
+    if (name === 'tileLocalRows') return args[0];
+    if (name === 'passTimeUs') return null;
+    return undefined;
+  } });
+  const r = new pt.Renderer({ native, handle: 1, options: {}, tile: { rank: 0, nranks: 1, blockRows: 8 } });
+  return { r, takeEncoded: () => {
+    const e = [];
+    if (lastMask & 1) e.push('raytrace');
+    if (lastMask & 2) e.push('accumulate');
+    if (lastMask & 4) e.push('fullscreen');
+    lastMask = 0;
+    return e;
+  } };
+}
+
+function run(impl, script) {
+  const { r, takeEncoded } = impl;
+  const events = [];
+  for (const ev of ['start', 'pause', 'reset', 'progress', 'complete', 'resize']) {
+    r.on(ev, (...args) => events.push(args.length ? [ev, args[0]] : [ev]));
+  }
+  const scene = { needsUpdate: false, environment: null, traverse: () => {}, updateMatrixWorld: () => {} };
+  const camera = { getWorldPosition: (t) => t, getWorldDirection: (t) => t, fov: 45, focalDistance: 1, aperture: 0,
+    updateMatrixWorld: () => {}, matrixWorld: { elements: new Array(16).fill(0) } };
+  const trace = [];
+  for (const op of script) {
+    events.length = 0;
+    if (op[0] === 'resize') r.resize(op[1], op[2]);
+    else if (op[0] === 'render') r.render(scene, camera);
+    else if (op[0] === 'set') r[op[1]] = op[2];
+    else if (['pause', 'start', 'reset'].includes(op[0])) r[op[0]]();
+    else throw new Error('bad op ' + op[0]);
+    trace.push({ op, events: events.slice(), status: r.status, frame: r.frame, progress: r.progress,
+      hasFramesToSample: r.hasFramesToSample, encoded: takeEncoded(), size: [r.width, r.height, r.scaledWidth, r.scaledHeight] });
+  }
+  return trace;
+}
+
+const [scriptFile, root] = process.argv.slice(2);
+const script = JSON.parse(fs.readFileSync(scriptFile, 'utf8'));
+const out = { mine: run(makeMine(), script) };
+if (root) out.reference = run(makeReference(root), script);
+console.log(JSON.stringify(out));
