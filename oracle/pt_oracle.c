@@ -14,11 +14,11 @@
  * shader files, however, are executed as they stand by oracle/wgsl_interp.py, and
  * tests/test_wgsl_vectors.py holds every function below to those outputs bit for bit
  * (tests/golden/wgsl_vectors.npz; implementation-defined builtins per pt_oracle_math.h).
- * The reference's BVH builder and environment-CDF code are likewise executed (under Node,
- * tests/golden/run_reference_host.js) and the native builder held to their bytes.  What remains
- * PARITY UNPINNED is the rest of the TypeScript host glue (scene flattening and uniform
- * packing through three.js / webgpu-utils) and the browser's own choices for the
- * implementation-defined arithmetic.
+ * The reference's TypeScript host code (BVH builder, environment CDF, scene compile, frame state
+ * machine) is likewise executed under Node (tests/golden/run_reference_*.js) and the hosts held to
+ * its outputs.  What remains PARITY UNPINNED is third-party code outside the reference tree
+ * (three.js, webgpu-utils: restated from the published algorithms) and the browser's own choices
+ * for the implementation-defined arithmetic.
  *
  * Buffers use the reference's byte layouts (webgpu-utils offsets):
  *   Triangle 112 B, BVHNode 48 B, Material 64 B, raytrace Uniforms 96 B,

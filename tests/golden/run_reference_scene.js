@@ -1,0 +1,152 @@
+'use strict';
+// TEST INFRASTRUCTURE.  Executes the reference's scene compile as written --
+//   RaytracePass.updateScene (mesh traversal, world-space flattening, material de-duplication),
+//   updateTriangleBuffer / updateMaterialBuffer / updateBVHBuffer (the packing),
+//   buildBVH / buildBVHRecursive / flattenBVH            (src/passes/raytrace.ts:104-193, 380-694)
+// cut out of the reference checkout at run time with the TypeScript annotations stripped -- on a
+// scene graph made of this repository's three.js stand-ins, and compares the bytes it hands to
+// GPUQueue.writeBuffer with what this repository's RaytracePass + native builder produce for the
+// same scene.
+//   node run_reference_scene.js <reference-root> <demo|model> [model-file]
+const fs = require('fs');
+const path = require('path');
+const pt = require(path.join(__dirname, '..', '..', 'webgpu-pathtracer_amd', 'js'));
+
+function extractMethod(source, name) {
+  const re = new RegExp('^[ \\t]*(?:private |public |protected )?' + name + '\\s*\\(', 'm');
+  const m = re.exec(source);
+  if (!m) throw new Error('method ' + name + ' not found in the reference source');
+  let depth = 0, k = source.indexOf('(', m.index);
+  for (; k < source.length; k++) { if (source[k] === '(') depth++; else if (source[k] === ')') { depth--; if (depth === 0) break; } }
+  let j = source.indexOf('{', k);
+  let d = 0, e = j;
+  for (; e < source.length; e++) { if (source[e] === '{') d++; else if (source[e] === '}') { d--; if (d === 0) break; } }
+  return source.slice(m.index, e + 1);
+}
+
+// remove `: Type` after a declared name, up to the top-level '=' (types may span lines and nest <>)
+function stripDeclarationTypes(js) {
+  const re = /\b(const|let|var)\s+([A-Za-z_$][\w$]*)\s*:/g;
+  let out = '', last = 0, m;
+  while ((m = re.exec(js)) !== null) {
+    let i = re.lastIndex, depth = 0;
+    for (; i < js.length; i++) {
+      const c = js[i];
+      if (c === '<' || c === '(' || c === '[' || c === '{') depth++;
+      else if (c === '>' || c === ')' || c === ']' || c === '}') depth--;
+      else if ((c === '=' || c === ';') && depth === 0) break;
+    }
+    out += js.slice(last, m.index) + m[1] + ' ' + m[2] + ' ';
+    last = i;
+    re.lastIndex = i;
+  }
+  return out + js.slice(last);
+}
+
+function stripTypes(ts) {
+  let js = ts.replace(/\b(private|public|protected)\s+/g, '');
+  js = stripDeclarationTypes(js);
+  js = js.replace(/\s+as\s+[A-Za-z_$][\w$.]*(?:<[^>]*>)?(?:\[\])?/g, '');                       // casts
+  js = js.replace(/([A-Za-z_$][\w$]*)\s*\(([^()]*)\)\s*(:\s*[A-Za-z_$][\w$.\[\]<>]*)?\s*\{/g, (all, fname, params, ret) => {
+    if (['if', 'for', 'while', 'switch', 'catch'].includes(fname)) return all;
+    if (!ret && !/:/.test(params)) return all;
+    const stripped = params.split(',').map((p) => p.replace(/\s*:\s*[\s\S]*$/, '').trim()).filter((p) => p.length).join(', ');
+    return fname + '(' + stripped + ') {';
+  });
+  return js.replace(/null!/g, 'null').replace(/\)!/g, ')');
+}
+
+// THREE as the extracted code sees it: this repository's stand-ins + Box3 (three@0.171.0)
+class Box3 {
+  constructor() { this.min = new pt.Vector3(+Infinity, +Infinity, +Infinity); this.max = new pt.Vector3(-Infinity, -Infinity, -Infinity); }
+  makeEmpty() { this.min.set(+Infinity, +Infinity, +Infinity); this.max.set(-Infinity, -Infinity, -Infinity); return this; }
+  isEmpty() { return (this.max.x < this.min.x) || (this.max.y < this.min.y) || (this.max.z < this.min.z); }
+  setFromPoints(points) { this.makeEmpty(); for (const p of points) this.expandByPoint(p); return this; }
+  expandByPoint(p) {
+    this.min.set(Math.min(this.min.x, p.x), Math.min(this.min.y, p.y), Math.min(this.min.z, p.z));
+    this.max.set(Math.max(this.max.x, p.x), Math.max(this.max.y, p.y), Math.max(this.max.z, p.z));
+    return this;
+  }
+  getCenter(t) { return this.isEmpty() ? t.set(0, 0, 0) : t.set(this.min.x + this.max.x, this.min.y + this.max.y, this.min.z + this.max.z).multiplyScalar(0.5); }
+  getSize(t) { return this.isEmpty() ? t.set(0, 0, 0) : t.subVectors(this.max, this.min); }
+}
+const THREE = { Vector3: pt.Vector3, Matrix3: pt.Matrix3, Mesh: pt.Mesh, Box3 };
+
+// makeStructuredView(...) of webgpu-utils: views[i].<field>.set(array) on typed-array windows
+function structuredView(struct, count) {
+  const def = pt.STRUCTS ? pt.STRUCTS[struct] : null;
+  const layout = def || require(path.join(__dirname, '..', '..', 'webgpu-pathtracer_amd', 'js', 'src', 'layout.js')).STRUCTS[struct];
+  const arrayBuffer = new ArrayBuffer(layout.size * count);
+  const views = [];
+  for (let i = 0; i < count; i++) {
+    const v = {};
+    for (const [name, spec] of Object.entries(layout.fields)) {
+      const Ctor = spec[0] === 'f32' ? Float32Array : (spec[0] === 'u32' ? Uint32Array : Int32Array);
+      v[name] = new Ctor(arrayBuffer, i * layout.size + spec[1], spec[2]);
+    }
+    views.push(v);
+  }
+  return { arrayBuffer, views };
+}
+
+function runReference(root, scene, camera) {
+  const src = fs.readFileSync(path.join(root, 'src', 'passes', 'raytrace.ts'), 'utf8');
+  const names = ['updateScene', 'updateTriangleBuffer', 'updateMaterialBuffer', 'updateBVHBuffer', 'buildBVH', 'buildBVHRecursive', 'flattenBVH'];
+  const body = names.map((n) => stripTypes(extractMethod(src, n))).join('\n\n');
+  const Extracted = new Function('THREE', 'RaytracingMaterial', 'console', 'return class Extracted {\n' + body + '\n};')(   // eslint-disable-line no-new-func
+    THREE, pt.RaytracingMaterial, { warn: () => {}, table: () => {}, log: () => {} });
+  const pass = new Extracted();
+  const written = {}, uniforms = [];
+  pass.setUniforms = (v) => uniforms.push(v);
+  pass.renderer = { updateEnvironmentTexture: () => {}, device: { queue: { writeBuffer: (buffer, offset, data) => { written[buffer] = Buffer.from(data.slice(0)); } } } };
+  pass.createBindGroup = () => 'bind group';
+  pass.createBVHStructuredView = (n) => structuredView('BVHNode', n);
+  pass.createTriangleStructuredView = (n) => structuredView('Triangle', n);
+  pass.createMaterialStructuredView = (n) => structuredView('Material', n);
+  pass.createBVHBuffer = () => 'nodes';
+  pass.createTriangleBuffer = () => 'triangles';
+  pass.createMaterialBuffer = () => 'materials';
+  pass.updateScene(scene, camera);
+  return { written, camera: uniforms[0].camera, needsUpdate: scene.needsUpdate };
+}
+
+function runMine(scene, camera) {
+  const flat = pt.RaytracePass.flattenScene(scene);
+  const packed = pt.RaytracePass.packScene(flat);
+  const nodes = pt.loadNative().hostBuildBvhF64(packed.positions, 2);
+  return { triangles: Buffer.from(packed.triangleBytes), materials: Buffer.from(packed.materialBytes), nodes: Buffer.from(nodes),
+    camera: { position: camera.getWorldPosition(new pt.Vector3()).toArray(), direction: camera.getWorldDirection(new pt.Vector3()).toArray(),
+      fov: camera.fov, focalDistance: camera.focalDistance, aperture: camera.aperture } };
+}
+
+const [root, which, modelFile] = process.argv.slice(2);
+const { buildDefaultScene } = require(path.join(__dirname, '..', '..', 'webgpu-pathtracer_amd', 'js', 'examples', 'default_scene.js'));
+const made = buildDefaultScene(null);
+const scene = made.scene, camera = made.camera;
+if (which === 'model') {
+  const model = /\.obj$/i.test(modelFile) ? new pt.OBJLoader().load(modelFile) : new pt.GLTFLoader().load(modelFile).scene;
+  pt.placeModel(model);
+  scene.clear();
+  scene.add(model);
+  // a second material on one mesh, an invisible mesh and a mesh with a foreign material: the traversal's filters
+  let n = 0;
+  model.traverse((o) => {
+    if (!(o instanceof pt.Mesh)) return;
+    n++;
+    if (n === 2) { o.material = new pt.RaytracingMaterial(); o.material.color.set(0.2, 0.4, 0.6); o.material.emissiveIntensity = 3; }
+    if (n === 3) o.visible = false;
+  });
+  const foreign = new pt.Mesh(new pt.BoxGeometry(1, 1, 1), { color: 'not a RaytracingMaterial' });
+  scene.add(foreign);
+}
+scene.needsUpdate = true;
+const mine = runMine(scene, camera);
+scene.needsUpdate = true;
+const ref = runReference(root, scene, camera);
+const same = (a, b) => a.length === b.length && a.equals(b);
+console.log(JSON.stringify({
+  triangles: mine.triangles.length / 112, nodes: mine.nodes.length / 48, materials: mine.materials.length / 64,
+  trianglesEqual: same(mine.triangles, ref.written.triangles), materialsEqual: same(mine.materials, ref.written.materials),
+  nodesEqual: same(mine.nodes, ref.written.nodes), cameraEqual: JSON.stringify(mine.camera) === JSON.stringify(ref.camera),
+  needsUpdateCleared: ref.needsUpdate === false,
+}));
