@@ -230,6 +230,14 @@ int mi3pt_set_pipelining(mi3pt_ctx *ctx, int enabled);
  * (hit, t, position xyz, normal xyz, materialIndex, box tests, triangle tests,
  * stack overflows) = raySceneIntersect, raytrace.wgsl:205-211. */
 int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n, float *out);
+/* An ALTERNATIVE tree, built on the device from the uploaded triangles: a linear
+ * BVH (Morton codes, radix sort, Karras' parallel hierarchy, bottom-up fit) in the same 48-byte
+ * records, pre-order numbered so that a child follows its parent; nodes_out (host) receives
+ * (2*ntris - 1) x 48 B for mi3pt_upload_bvh.  It is NOT the reference's SAH tree
+ * (mi3pt_host_build_bvh_f64 is): box / triangle test counts differ, the image does not, except
+ * where two triangles are hit at exactly the same t.  build_ms (optional): device time. */
+int mi3pt_device_build_bvh(mi3pt_ctx *ctx, void *nodes_out, size_t nodes_capacity_bytes, size_t *nnodes_out, float *build_ms);
+
 /* Design experiment, not part of the rendering path: walks `n` given rays (6 floats each) with the
  * deferred-leaf walk ALONE (no shading) as a persistent kernel with 4, 5, 6 or 8 resident waves
  * per SIMD, `passes` times over the list inside one launch (amortises the drain), and reports the

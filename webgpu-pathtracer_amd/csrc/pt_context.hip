@@ -1067,6 +1067,21 @@ extern "C" int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n
     return MI3PT_OK;
 }
 
+extern "C" int mi3pt_device_build_bvh(mi3pt_ctx *ctx, void *nodes_out, size_t nodes_capacity_bytes, size_t *nnodes_out, float *build_ms)
+{
+    if (int rc = require_idle(ctx)) return rc;
+    if (!nodes_out || !nnodes_out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (!ctx->d_tris || ctx->ntris == 0) return pt_set_error(MI3PT_ERR_STATE, "no triangles uploaded (mi3pt_upload_triangles)");
+    const size_t nodes = 2 * ctx->ntris - 1;
+    if (nodes_capacity_bytes < nodes * MI3PT_BVHNODE_STRIDE) return pt_set_error(MI3PT_ERR_INVALID, "node buffer too small");
+    std::string err;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (pt::lbvh_build(ctx->d_tris, ctx->ntris, nodes_out, build_ms, ctx->stream, err) != 0)
+        return pt_set_error(MI3PT_ERR_HIP, "device BVH build: " + err);
+    *nnodes_out = nodes;
+    return MI3PT_OK;
+}
+
 extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t n, int waves_per_simd, int repeats, int passes,
                                       float *out_tuvi, float *ms_out)
 {

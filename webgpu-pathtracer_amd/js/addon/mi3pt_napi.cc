@@ -444,6 +444,22 @@ napi_value HostBuildBvhF64(napi_env env, napi_callback_info info)
     return buf;
 }
 
+// deviceBuildBvh(ctx, ntris) -> Buffer of (2*ntris - 1) 48-byte nodes: the linear BVH built on the device
+// from the uploaded triangles (an alternative to the reference's SAH tree, see mi3pt.h)
+napi_value DeviceBuildBvh(napi_env env, napi_callback_info info)
+{
+    Args a;
+    mi3pt_ctx *ctx;
+    int32_t ntris;
+    if (!get_args(env, info, a, 2) || !get_ctx(env, a.v[0], &ctx) || !get_i32(env, a.v[1], &ntris) || ntris <= 0) return nullptr;
+    void *out = nullptr;
+    napi_value buf = make_node_buffer(env, (size_t)ntris, &out);
+    if (!buf) return nullptr;
+    size_t count = 0;
+    MI3PT_TRY(mi3pt_device_build_bvh(ctx, out, (2 * (size_t)ntris - 1) * MI3PT_BVHNODE_STRIDE, &count, nullptr));
+    return buf;
+}
+
 napi_value HostBuildBvh(napi_env env, napi_callback_info info)
 {
     Args a;
@@ -499,7 +515,7 @@ napi_value Init(napi_env env, napi_value exports)
         { "sync", Sync }, { "flush", Flush }, { "readTexture", ReadTexture }, { "readCanvasRgba8", ReadCanvasRgba8 },
         { "enableTiming", EnableTiming }, { "passTimeUs", PassTimeUs }, { "getCounters", GetCounters },
         { "resetCounters", ResetCounters }, { "hostBuildBvhF64", HostBuildBvhF64 }, { "hostBuildBvh", HostBuildBvh },
-        { "hostEnvCdf", HostEnvCdf }, { "setPipelining", SetPipelining }, { "setEnvSampling", SetEnvSampling }, { "writeTexture", WriteTexture },
+        { "hostEnvCdf", HostEnvCdf }, { "setPipelining", SetPipelining }, { "setEnvSampling", SetEnvSampling }, { "deviceBuildBvh", DeviceBuildBvh }, { "writeTexture", WriteTexture },
         { "raytraceLaunchStats", RaytraceLaunchStats },
     };
     for (const auto &f : fns) {

@@ -79,6 +79,8 @@ export interface RendererOptions {
   presentEveryFrame?: boolean;
   verbose?: boolean;
   builderThreads?: number;
+  /** build a linear BVH on the GPU instead of the reference's SAH tree (fast on huge meshes, same closest hits) */
+  deviceBvh?: boolean;
   /** multi-GPU tile split: this process renders rows (y / blockRows) % nranks == rank */
   tile?: { rank: number; nranks: number; blockRows: number };
 }

@@ -30,7 +30,7 @@ SYMBOLS = (
     "mi3pt_write_texture",
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
-    "mi3pt_set_env_sampling", "mi3pt_debug_walk_probe",
+    "mi3pt_set_env_sampling", "mi3pt_debug_walk_probe", "mi3pt_device_build_bvh",
     "mi3pt_set_pipelining", "mi3pt_flush",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
@@ -90,6 +90,7 @@ def load_library(path=None):
     lib.mi3pt_reset_counters.argtypes = [c_void_p]
     lib.mi3pt_debug_intersect.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.mi3pt_debug_math.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t]
+    lib.mi3pt_device_build_bvh.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
     lib.mi3pt_debug_walk_probe.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.mi3pt_debug_wave_times.argtypes = [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]
     lib.mi3pt_host_build_bvh.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
@@ -221,6 +222,7 @@ class Context:
     def upload_triangles(self, tris):
         a = np.ascontiguousarray(tris)
         self._c(self.lib.mi3pt_upload_triangles(self.handle, _ptr(a), a.nbytes))
+        self._ntris_uploaded = a.nbytes // 112
 
     def upload_materials(self, mats):
         a = np.ascontiguousarray(mats)
@@ -320,6 +322,19 @@ class Context:
         n = ctypes.c_size_t()
         self._c(self.lib.mi3pt_debug_wave_times(self.handle, 1, _ptr(out), len(out), ctypes.byref(n)))
         return out[:n.value]
+
+    def device_build_bvh(self):
+        """Linear BVH over the uploaded triangles, built on the device: (nodes, build_ms).  An alternative
+        to the reference's SAH tree (host_build_bvh_f64), in the same 48-byte records."""
+        n = ctypes.c_size_t()
+        ms = ctypes.c_float()
+        from . import layout
+        ntris = getattr(self, "_ntris_uploaded", 0)
+        if ntris == 0:
+            raise Mi3ptError(4, "no triangles uploaded")
+        nodes = np.zeros(2 * ntris - 1, layout.BVH_NODE)
+        self._c(self.lib.mi3pt_device_build_bvh(self.handle, _ptr(nodes), nodes.nbytes, ctypes.byref(n), ctypes.byref(ms)))
+        return nodes[: n.value], ms.value
 
     def walk_probe(self, rays, waves_per_simd, repeats=3, want_hits=False, passes=1):
         """Walk-only occupancy experiment (mi3pt_debug_walk_probe): returns (ms, hits or None)."""
