@@ -13,7 +13,7 @@ python bench.py > $OUT/${TAG}_demo_1080p_bench.json 2> $OUT/${TAG}_demo_bench.er
 echo "demo bench done: $(cut -c1-100 $OUT/${TAG}_demo_1080p_bench.json)"
 python bench.py --no-cpu-baseline --workload dragon > $OUT/${TAG}_dragon_1080p_bench.json 2>/dev/null
 echo "dragon bench done: $(cut -c1-100 $OUT/${TAG}_dragon_1080p_bench.json)"
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 64 --warmup 16 --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py > $OUT/${TAG}_stats.log 2>&1)
 cp $(ls $OUT/${TAG}_stats/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_demo_1080p_kernel_stats.csv
 echo "rocprof stats done"
 PASSES="1 2 4 5" STEPS=64 WARMUP=16 bash profiles/pmc_passes.sh gpurun_out/${TAG}_pmc_demo
