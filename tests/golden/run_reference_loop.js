@@ -54,11 +54,20 @@ function stripTypes(ts) {
   return js;
 }
 
-function passStub(log, name) {
-  return {
-    timingAverage: name, setUniforms: (v) => log.uniforms.push([name, v]), update: () => {}, updateScene: () => {},
-    render: () => log.encoded.push(name), updateTimings: () => {},
-  };
+const PASS_FILES = { raytrace: 'raytrace.ts', accumulate: 'accumulate.ts', fullscreen: 'fullscreen.ts' };
+
+// a pass whose update() is the reference's own (src/passes/<name>.ts), everything else recording stubs
+function passStub(log, name, root, renderer) {
+  const src = fs.readFileSync(path.join(root, 'src', 'passes', PASS_FILES[name]), 'utf8');
+  const Pass = new Function('return class P {\n' + stripTypes(extractMember(src, 'update')) + '\n};')();   // eslint-disable-line no-new-func
+  const p = new Pass();
+  p.renderer = renderer;
+  p.timingAverage = name;
+  p.setUniforms = (v) => log.uniforms.push([name, v]);
+  p.updateScene = () => {};
+  p.render = () => log.encoded.push(name);
+  p.updateTimings = () => {};
+  return p;
 }
 
 function makeReference(root) {
@@ -75,10 +84,11 @@ function makeReference(root) {
   r.frames = 64;
   r.samplesPerFrame = 1;
   r.status = 'idle';
-  r.passes = { raytrace: passStub(log, 'raytrace'), accumulate: passStub(log, 'accumulate'), fullscreen: passStub(log, 'fullscreen') };
+  r.passes = { raytrace: passStub(log, 'raytrace', root, r), accumulate: passStub(log, 'accumulate', root, r), fullscreen: passStub(log, 'fullscreen', root, r) };
   r.device = { createCommandEncoder: () => ({ finish: () => 'commands' }), queue: { submit: () => {} } };
   r.createStorageTexture = () => 'texture';
-  return { r, takeEncoded: () => { const e = log.encoded.slice(); log.encoded.length = 0; return e; } };
+  return { r, takeEncoded: () => { const e = log.encoded.slice(); log.encoded.length = 0; return e; },
+    takeUniforms: () => { const u = log.uniforms.slice(); log.uniforms.length = 0; return u; } };
 }
 
 function makeMine() {
@@ -91,7 +101,13 @@ function makeMine() {
     return undefined;
   } });
   const r = new pt.Renderer({ native, handle: 1, options: {}, tile: { rank: 0, nranks: 1, blockRows: 8 } });
-  return { r, takeEncoded: () => {
+  const uniforms = [];
+  for (const name of ['raytrace', 'accumulate', 'fullscreen']) {
+    const pass = r.passes[name], original = pass.setUniforms.bind(pass);
+    pass.setUniforms = (v) => { uniforms.push([name, v]); original(v); };
+    pass.updateScene = () => {};                              // the scene compile is covered by run_reference_scene.js
+  }
+  return { r, takeUniforms: () => { const u = uniforms.slice(); uniforms.length = 0; return u; }, takeEncoded: () => {
     const e = [];
     if (lastMask & 1) e.push('raytrace');
     if (lastMask & 2) e.push('accumulate');
@@ -102,7 +118,7 @@ function makeMine() {
 }
 
 function run(impl, script) {
-  const { r, takeEncoded } = impl;
+  const { r, takeEncoded, takeUniforms } = impl;
   const events = [];
   for (const ev of ['start', 'pause', 'reset', 'progress', 'complete', 'resize']) {
     r.on(ev, (...args) => events.push(args.length ? [ev, args[0]] : [ev]));
@@ -119,7 +135,8 @@ function run(impl, script) {
     else if (['pause', 'start', 'reset'].includes(op[0])) r[op[0]]();
     else throw new Error('bad op ' + op[0]);
     trace.push({ op, events: events.slice(), status: r.status, frame: r.frame, progress: r.progress,
-      hasFramesToSample: r.hasFramesToSample, encoded: takeEncoded(), size: [r.width, r.height, r.scaledWidth, r.scaledHeight] });
+      hasFramesToSample: r.hasFramesToSample, encoded: takeEncoded(), uniforms: takeUniforms(),
+      size: [r.width, r.height, r.scaledWidth, r.scaledHeight] });
   }
   return trace;
 }

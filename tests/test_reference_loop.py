@@ -73,12 +73,19 @@ def test_python_renderer_follows_the_executed_reference():
     ctx = Ctx()
     r = R.Renderer(ctx)
     r.passes["raytrace"].updateScene = lambda scene, camera: None      # the scene compile is not under test here
+    pushed = []
+    for name in ("raytrace", "accumulate", "fullscreen"):
+        def recording(value, name=name, original=r.passes[name].setUniforms):
+            pushed.append([name, json.loads(json.dumps(value))])
+            original(value)
+        r.passes[name].setUniforms = recording
     events = []
     for ev in ("start", "pause", "reset", "progress", "complete", "resize"):
         r.on(ev, lambda *a, ev=ev: events.append([ev, a[0]] if a else [ev]))
     trace = []
     for op in SCRIPT:
         del events[:]
+        del pushed[:]
         if op[0] == "resize":
             r.resize(op[1], op[2])
         elif op[0] == "render":
@@ -90,7 +97,7 @@ def test_python_renderer_follows_the_executed_reference():
         encoded = [n for bit, n in ((1, "raytrace"), (2, "accumulate"), (4, "fullscreen")) if ctx.mask & bit]
         ctx.mask = 0
         trace.append({"op": op, "events": [list(e) for e in events], "status": r.status, "frame": r.frame, "progress": r.progress,
-                      "hasFramesToSample": r.hasFramesToSample, "encoded": encoded,
+                      "hasFramesToSample": r.hasFramesToSample, "encoded": encoded, "uniforms": list(pushed),
                       "size": [r.width, r.height, r.scaledWidth, r.scaledHeight]})
     want = _committed()
     for got, exp in zip(trace, want):
