@@ -146,3 +146,23 @@ const script = JSON.parse(fs.readFileSync(scriptFile, 'utf8'));
 const out = { mine: run(makeMine(), script) };
 if (root) out.reference = run(makeReference(root), script);
 console.log(JSON.stringify(out));
+
+// RollingAverage (src/timing.ts:1-20): the reference's class (private #fields rewritten to plain ones for
+// Node 12) against this repository's, on the same sample sequence
+if (root) {
+  const tsrc = fs.readFileSync(path.join(root, 'src', 'timing.ts'), 'utf8');
+  const start = tsrc.indexOf('export class RollingAverage');
+  let d = 0, e = tsrc.indexOf('{', start);
+  for (; e < tsrc.length; e++) { if (tsrc[e] === '{') d++; else if (tsrc[e] === '}') { d--; if (d === 0) break; } }
+  const cls = tsrc.slice(start, e + 1).replace('export class', 'return class').replace(/#(\w+)/g, '_$1')
+    .replace(/^\s*_(\w+)(?::\s*[^=;]+)?(\s*=\s*[^;]+)?;/gm, '').replace(/constructor\(numSamples = 30\) \{/, 'constructor(numSamples = 30) { this._total = 0; this._samples = []; this._cursor = 0;')
+    .replace(/\((\w+): number\)/g, '($1)');
+  const Ref = new Function(cls)();        // eslint-disable-line no-new-func
+  const Mine = require(path.join(__dirname, '..', '..', 'webgpu-pathtracer_amd', 'js', 'src', 'timing.js')).RollingAverage;
+  const a = new Ref(), b = new Mine(), c = new Ref(4), e2 = new Mine(4);
+  const seq = [];
+  seq.push([a.value, b.value]);
+  for (let i = 0; i < 70; i++) { const v = Math.sin(i) * 100 + 150; a.addSample(v); b.addSample(v); c.addSample(v); e2.addSample(v); seq.push([a.value, b.value, c.value, e2.value]); }
+  const same = seq.every((r) => Object.is(r[0], r[1]) && (r.length < 4 || Object.is(r[2], r[3])));
+  if (!same) { console.error('RollingAverage differs from the reference'); process.exit(3); }
+}

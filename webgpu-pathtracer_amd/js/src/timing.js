@@ -14,6 +14,6 @@ class RollingAverage {
     this.samples[this.cursor] = v;
     this.cursor = (this.cursor + 1) % this.numSamples;
   }
-  get value() { return this.samples.length ? this.total / this.samples.length : 0; }
+  get value() { return this.total / this.samples.length; }      // NaN before the first sample, like the reference
 }
 module.exports = { RollingAverage };

@@ -31,17 +31,17 @@ class RollingAverage:
         self.total = 0.0
 
     def addSample(self, v):
-        if len(self.samples) < self.num_samples:
-            self.samples.append(v)
-        else:
-            self.total -= self.samples[self.cursor]
+        old = self.samples[self.cursor] if self.cursor < len(self.samples) else 0.0
+        self.total += v - old                      # one rounding, like `total += v - (samples[cursor] || 0)`
+        if self.cursor < len(self.samples):
             self.samples[self.cursor] = v
+        else:
+            self.samples.append(v)
         self.cursor = (self.cursor + 1) % self.num_samples
-        self.total += v
 
     @property
     def value(self):
-        return self.total / len(self.samples) if self.samples else 0.0
+        return self.total / len(self.samples) if self.samples else float("nan")     # 0 / 0 before the first sample
 
 
 class RaytracingScene:
