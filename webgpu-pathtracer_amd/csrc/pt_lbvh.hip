@@ -10,9 +10,9 @@
 // at exactly the same t.
 //
 // Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees" (HPG 2012):
-// 30-bit Morton codes of the triangle centroids, made unique by the triangle index in the low word,
-// radix-sorted (hipCUB); one thread per internal node finds its range and split from the common
-// prefixes; boxes are fitted bottom-up; nodes are numbered in pre-order (index = 2 * first leaf of
+// 63-bit Morton codes of the triangle centroids (21 bits per axis; equal codes are told apart by their
+// position after the sort), radix-sorted with the triangle index as payload (hipCUB); one thread per
+// internal node finds its range and split from the common prefixes; boxes are fitted bottom-up; nodes are numbered in pre-order (index = 2 * first leaf of
 // the range + number of left turns on the path from the root), so that a child always follows its
 // parent -- the order mi3pt_upload_bvh validates.
 #include "pt_internal.h"
@@ -23,12 +23,14 @@
 
 namespace pt {
 
-__device__ __forceinline__ uint32_t expand10(uint32_t v)      // 10 bits -> every third bit
+__device__ __forceinline__ unsigned long long expand21(unsigned long long v)      // 21 bits -> every third bit
 {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x001f00000000ffffull;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
 }
 
@@ -64,27 +66,29 @@ __global__ void __launch_bounds__(256) k_lbvh_prims(const float4 *__restrict__ t
 }
 
 __global__ void __launch_bounds__(256) k_lbvh_keys(const float *__restrict__ centroid, uint32_t n, const int *__restrict__ bounds,
-                                                   unsigned long long *__restrict__ keys)
+                                                   unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    uint32_t q[3];
+    unsigned long long q[3];
     for (int k = 0; k < 3; k++) {
         const float lo = unorder_f(bounds[k]), hi = unorder_f(bounds[3 + k]);
         const float extent = hi - lo;
         float t = extent > 0.0f ? (centroid[(size_t)i * 3 + k] - lo) / extent : 0.0f;
         t = fminf(fmaxf(t, 0.0f), 1.0f);
         if (!(t == t)) t = 0.0f;
-        q[k] = (uint32_t)fminf(t * 1024.0f, 1023.0f);
+        q[k] = (unsigned long long)fminf(t * 2097152.0f, 2097151.0f);
     }
-    const uint32_t morton = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
-    keys[i] = ((unsigned long long)morton << 32) | i;
+    keys[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);       // 63-bit Morton code
+    vals[i] = i;
 }
 
+// length of the common prefix of the (code, position) pairs: equal codes are told apart by position
 __device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j)
 {
     if (j < 0 || j >= n) return -1;
-    return __clzll((long long)(keys[i] ^ keys[j]));          // keys are unique: never 64
+    const unsigned long long x = keys[i] ^ keys[j];
+    return x != 0ull ? __clzll((long long)x) : 64 + __clz(i ^ j);
 }
 
 // node ids while building: internal i in [0, n-2], leaf k as (n - 1 + k)
@@ -119,14 +123,14 @@ __global__ void __launch_bounds__(256) k_lbvh_hierarchy(const unsigned long long
 }
 
 // bottom-up fit: the second child to arrive at a node unions the two boxes and climbs on
-__global__ void __launch_bounds__(256) k_lbvh_fit(const unsigned long long *__restrict__ keys, int n, const Box *__restrict__ tri_box,
+__global__ void __launch_bounds__(256) k_lbvh_fit(const uint32_t *__restrict__ tri_of, int n, const Box *__restrict__ tri_box,
                                                   const int *__restrict__ left, const int *__restrict__ right,
                                                   const int *__restrict__ parent, Box *__restrict__ node_box, int *__restrict__ arrived)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     int node = n - 1 + k;
-    node_box[node] = tri_box[(uint32_t)(keys[k] & 0xffffffffull)];
+    node_box[node] = tri_box[tri_of[k]];
     __threadfence();
     int p = parent[node];
     while (p >= 0) {
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(256) k_lbvh_fit(const unsigned long long *__re
 }
 
 // pre-order position of every node and the 48-byte record the reference's buffer holds there
-__global__ void __launch_bounds__(256) k_lbvh_emit(const unsigned long long *__restrict__ keys, int n, const int *__restrict__ left,
+__global__ void __launch_bounds__(256) k_lbvh_emit(const uint32_t *__restrict__ tri_of, int n, const int *__restrict__ left,
                                                    const int *__restrict__ first, const int *__restrict__ last,
                                                    const int *__restrict__ parent, const uint8_t *__restrict__ is_left,
                                                    const Box *__restrict__ node_box, uint8_t *__restrict__ out)
@@ -160,7 +164,7 @@ __global__ void __launch_bounds__(256) k_lbvh_emit(const unsigned long long *__r
     f[0] = b.mn[0]; f[1] = b.mn[1]; f[2] = b.mn[2]; w[3] = 0;
     f[4] = b.mx[0]; f[5] = b.mx[1]; f[6] = b.mx[2];
     if (leaf) {
-        w[7] = 1; w[8] = -1; w[9] = -1; w[10] = (int)(uint32_t)(keys[a] & 0xffffffffull);
+        w[7] = 1; w[8] = -1; w[9] = -1; w[10] = (int)tri_of[a];
     } else {
         const int lc = left[node];
         const int left_leaves = lc >= n - 1 ? 1 : last[lc] - first[lc] + 1;
@@ -181,6 +185,7 @@ int lbvh_build(const void *d_tris, size_t n, void *nodes_out, float *build_ms, h
     int *bounds = nullptr, *left = nullptr, *right = nullptr, *first = nullptr, *last = nullptr, *parent = nullptr, *arrived = nullptr;
     uint8_t *is_left = nullptr, *d_out = nullptr;
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
+    uint32_t *vals = nullptr, *vals_sorted = nullptr;
     void *tmp = nullptr;
     size_t tmp_bytes = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -194,6 +199,8 @@ int lbvh_build(const void *d_tris, size_t n, void *nodes_out, float *build_ms, h
     LB_TRY(hipMalloc((void **)&bounds, 24));
     LB_TRY(hipMalloc((void **)&keys, n * 8));
     LB_TRY(hipMalloc((void **)&keys_sorted, n * 8));
+    LB_TRY(hipMalloc((void **)&vals, n * 4));
+    LB_TRY(hipMalloc((void **)&vals_sorted, n * 4));
     LB_TRY(hipMalloc((void **)&left, n * 4));
     LB_TRY(hipMalloc((void **)&right, n * 4));
     LB_TRY(hipMalloc((void **)&first, n * 4));
@@ -202,7 +209,7 @@ int lbvh_build(const void *d_tris, size_t n, void *nodes_out, float *build_ms, h
     LB_TRY(hipMalloc((void **)&arrived, n * 4));
     LB_TRY(hipMalloc((void **)&is_left, nodes));
     LB_TRY(hipMalloc((void **)&d_out, nodes * 48));
-    LB_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys, keys_sorted, N, 0, 64, stream));
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_sorted, vals, vals_sorted, N, 0, 63, stream));
     LB_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
     LB_TRY(hipEventCreate(&e0));
     LB_TRY(hipEventCreate(&e1));
@@ -212,12 +219,12 @@ int lbvh_build(const void *d_tris, size_t n, void *nodes_out, float *build_ms, h
     LB_TRY(hipMemsetAsync(is_left, 0, nodes, stream));
     LB_TRY(hipEventRecord(e0, stream));
     hipLaunchKernelGGL(k_lbvh_prims, dim3(blocks_n), dim3(256), 0, stream, static_cast<const float4 *>(d_tris), (uint32_t)n, tri_box, centroid, bounds);
-    hipLaunchKernelGGL(k_lbvh_keys, dim3(blocks_n), dim3(256), 0, stream, centroid, (uint32_t)n, bounds, keys);
-    LB_TRY(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys_sorted, N, 0, 64, stream));
+    hipLaunchKernelGGL(k_lbvh_keys, dim3(blocks_n), dim3(256), 0, stream, centroid, (uint32_t)n, bounds, keys, vals);
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_sorted, vals, vals_sorted, N, 0, 63, stream));
     if (n > 1)
         hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocks_n), dim3(256), 0, stream, keys_sorted, N, left, right, first, last, parent, is_left);
-    hipLaunchKernelGGL(k_lbvh_fit, dim3(blocks_n), dim3(256), 0, stream, keys_sorted, N, tri_box, left, right, parent, node_box, arrived);
-    hipLaunchKernelGGL(k_lbvh_emit, dim3(blocks_nodes), dim3(256), 0, stream, keys_sorted, N, left, first, last, parent, is_left, node_box, d_out);
+    hipLaunchKernelGGL(k_lbvh_fit, dim3(blocks_n), dim3(256), 0, stream, vals_sorted, N, tri_box, left, right, parent, node_box, arrived);
+    hipLaunchKernelGGL(k_lbvh_emit, dim3(blocks_nodes), dim3(256), 0, stream, vals_sorted, N, left, first, last, parent, is_left, node_box, d_out);
     LB_TRY(hipGetLastError());
     LB_TRY(hipEventRecord(e1, stream));
     LB_TRY(hipMemcpyAsync(nodes_out, d_out, nodes * 48, hipMemcpyDeviceToHost, stream));
@@ -225,7 +232,7 @@ int lbvh_build(const void *d_tris, size_t n, void *nodes_out, float *build_ms, h
     LB_TRY(hipEventElapsedTime(&ms, e0, e1));
     if (build_ms) *build_ms = ms;
 done:
-    for (void *p : { (void *)tri_box, (void *)node_box, (void *)centroid, (void *)bounds, (void *)keys, (void *)keys_sorted, (void *)left,
+    for (void *p : { (void *)tri_box, (void *)node_box, (void *)centroid, (void *)bounds, (void *)keys, (void *)keys_sorted, (void *)vals, (void *)vals_sorted, (void *)left,
                      (void *)right, (void *)first, (void *)last, (void *)parent, (void *)arrived, (void *)is_left, (void *)d_out, tmp })
         if (p) (void)hipFree(p);
     if (e0) (void)hipEventDestroy(e0);
