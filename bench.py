@@ -200,11 +200,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def exchange():
+        # the one exchange of the job: HDR accumulation buffers -> rank 0 over xGMI
+        with torch.cuda.stream(stream):
+            send[: ctx.local_rows].copy_(accum)
+            if rehearsal:
+                stream.synchronize()
+                host = send.cpu()
+                dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
+            else:
+                dist.gather(send, gathered, dst=0)
+
     frame = 2
     for _ in range(args.warmup):
         one_frame(frame)
         frame += 1
     ctx.sync()
+    if world > 1 and args.warmup > 0:
+        # warm-up of the exchange too: the first gather on a communicator sets up RCCL's
+        # point-to-point channels (tens of ms), which is not part of a steady-state job
+        exchange()
+        sync_all()
     ctx.reset_counters()
     ctx.raytrace_launch_stats(reset=True)
 
@@ -217,15 +233,7 @@ def main():
         frame += 1
     ctx.flush()      # launch the frames still queued for batching (no host wait)
     if world > 1:
-        # the one exchange of the job: HDR accumulation buffers -> rank 0 over xGMI
-        with torch.cuda.stream(stream):
-            send[: ctx.local_rows].copy_(accum)
-            if rehearsal:
-                stream.synchronize()
-                host = send.cpu()
-                dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
-            else:
-                dist.gather(send, gathered, dst=0)
+        exchange()
     sync_all()
     elapsed = time.perf_counter() - t0
     counters = ctx.counters()
