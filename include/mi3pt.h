@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MI3PT_ABI_VERSION 1
+#define MI3PT_ABI_VERSION 2
 
 typedef enum mi3pt_status {
     MI3PT_OK = 0,
@@ -87,6 +87,18 @@ typedef enum mi3pt_storage {
     MI3PT_STORAGE_F16 = 1        /* round every stored texel through binary16 = the reference's
                                     rgba16float textures (renderer.ts:102, accumulate.ts:52) */
 } mi3pt_storage;
+
+/* what a submit that includes MI3PT_SUBMIT_FULLSCREEN shows (mi3pt_set_present_mode) */
+typedef enum mi3pt_present_mode {
+    MI3PT_PRESENT_EXACT = 0,     /* the canvas is drawn from the running mean INCLUDING this submit's frame:
+                                    renderer.ts:379-390 as written.  The frame queue is launched first, so a
+                                    loop that presents every frame runs one raytrace launch per frame. */
+    MI3PT_PRESENT_LATEST = 1     /* headless hosts: the frame is queued like any other; the canvas is drawn
+                                    from the running mean of the batches launched so far, and only when that
+                                    mean or the fullscreen uniforms changed since the last draw.  A submit
+                                    with FULLSCREEN alone (render() after sampling has stopped,
+                                    renderer.ts:369-373) launches the queue and shows every frame. */
+} mi3pt_present_mode;
 
 /* counters accumulated by every raytrace pass since the last mi3pt_reset_counters() */
 typedef enum mi3pt_counter {
@@ -162,8 +174,11 @@ int mi3pt_set_uniforms(mi3pt_ctx *ctx, int pass /* mi3pt_pass */, const void *by
  * the two-pass result). ---- */
 int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask);
 int mi3pt_sync(mi3pt_ctx *ctx);   /* queue.onSubmittedWorkDone(), renderer.ts:420 */
+/* Default MI3PT_PRESENT_EXACT.  See mi3pt_present_mode. */
+int mi3pt_set_present_mode(mi3pt_ctx *ctx, int mode /* mi3pt_present_mode */);
 /* RAYTRACE|ACCUMULATE submits may be queued inside the library and launched together (up to
- * 8 consecutive frames whose uniforms differ only in `frame` run as one kernel + one ordered
+ * 16 consecutive frames whose uniforms differ only in `frame` -- 16 x nranks for a rank of a tile
+ * split, at most 128, less when memory is short -- run as one kernel + one ordered
  * accumulate).  Every call that observes or changes device state launches the queue first;
  * mi3pt_flush does only that, without waiting -- use it before synchronising the stream
  * yourself (e.g. torch.cuda.synchronize()). */
@@ -207,8 +222,14 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
  * 6 = 4 with the top 32 node packets staged in LDS (measured: no gain),
  * 7 = 4 with leaf tests deferred into triangle steps of their own; needs a proper tree whose
  * worst-case stack stays below 29 entries (checked at upload), otherwise 4 runs; 8 = 7 with the
- * LDS-staged top of the tree of 6 (measured: no gain).  auto = 7 when the scene allows it, else 4.
- * All variants produce the same bits. */
+ * LDS-staged top of the tree of 6 (measured: no gain); 9 = 7 with exact-image distance culling: a
+ * child box that starts farther away than the closest hit so far, by a margin PROVEN to cover the
+ * rounding of the reference's fp32 Moller-Trumbore code, is skipped, children are
+ * visited near first -- the image is bit-identical, the box / triangle-test COUNTERS are lower than
+ * the reference walk's (which has no such bound, raytrace.wgsl:118-203).
+ * auto = 9 when the scene allows it (else 7, else 4); MI3PT_CULL=0 in the environment makes auto
+ * stop at 7.  Variants 1-8 execute exactly the reference's tests (counters equal the oracle's);
+ * all variants produce the same bits. */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
 /* The reference's environment importance sampling (raytrace.wgsl:315-367: getEnvironmentMapUV /
  * ...MarginalCDF / ...ConditionalCDF / ...PDF over the CDF texture of renderer.ts:159-266) is dead

@@ -82,3 +82,23 @@ def gpu_frame(ctx, rt_u, acc_u=None, mask=capi.SUBMIT_RAYTRACE):
     if acc_u is not None:
         ctx.set_uniforms(capi.PASS_ACCUMULATE, acc_u.tobytes())
     ctx.submit(mask)
+
+
+PATH_COUNTERS = ("rays", "hits", "misses", "stack_overflows", "pixels")
+WALK_COUNTERS = ("box_tests", "tri_tests")
+
+
+def check_counters(cnt, want, culled=False, what=""):
+    """Counters of a raytrace run against the oracle's (or a reference kernel's).  Kernel variants
+    1-8 execute exactly the reference's tests, so everything is equal.  The distance-culling walk
+    (variant 9, the default when the scene allows it) traces the same paths -- rays, hits, misses,
+    pixels equal -- but skips boxes and triangles behind the closest hit: those two only have to
+    stay at or below the reference walk's."""
+    for k in PATH_COUNTERS:
+        if k in want:
+            assert cnt[k] == want[k], f"{what} counter {k}: gpu {cnt[k]} reference {want[k]}"
+    for k in WALK_COUNTERS:
+        if culled:
+            assert cnt[k] <= want[k], f"{what} counter {k}: gpu {cnt[k]} above the reference walk's {want[k]}"
+        else:
+            assert cnt[k] == want[k], f"{what} counter {k}: gpu {cnt[k]} reference {want[k]}"

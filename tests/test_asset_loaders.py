@@ -282,7 +282,7 @@ def test_loaded_model_and_environment_render_like_the_oracle(gpu_ctx, orc, tmp_p
     got, cnt = ctx.read_texture(capi.TEX_OUTPUT), ctx.counters()
     want, ocnt = orc.raytrace(pc.oracle_scene(orc, sc, env), u.tobytes(), w, h)
     assert pc.same_bits(got, want), pc.describe_diff(got, want)
-    assert cnt["hits"] == ocnt["hits"] > 0 and cnt["tri_tests"] == ocnt["tri_tests"]
+    assert cnt["hits"] == ocnt["hits"] > 0 and cnt["tri_tests"] <= ocnt["tri_tests"]      # (default walk culls by distance)
     ctx.resize(64, 64)
 
 

@@ -61,8 +61,11 @@ def test_config3_dragon_class_1080p(gpu_ctx, orc, dragon, env):
     ref, cref = _render(ctx, dragon, w, h, frames, variant=2)
     got, cgot = _render(ctx, dragon, w, h, frames, variant=0)
     assert pc.same_bits(got, ref), pc.describe_diff(got, ref)
-    for k in ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels"):
-        assert cgot[k] == cref[k]
+    pc.check_counters(cgot, cref, culled=True, what="shipped kernel vs per-pixel kernel")
+    same, csame = _render(ctx, dragon, w, h, frames, variant=7)        # the walk that runs exactly the reference's tests
+    assert pc.same_bits(same, ref)
+    pc.check_counters(csame, cref, culled=False, what="deferred-leaf kernel vs per-pixel kernel")
+    assert cgot["box_tests"] < 0.8 * cref["box_tests"]
     assert cgot["pixels"] == 3 * w * h and cgot["rays"] == cgot["hits"] + cgot["misses"]
     assert cgot["stack_overflows"] == 0 and cgot["reserved"] < 0.02 * cgot["rays"]
     assert np.isfinite(got).all()

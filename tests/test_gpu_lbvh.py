@@ -64,8 +64,7 @@ def test_demo_scene_renders_identically(gpu_ctx, orc, demo, env):
     img, cnt = render()
     want, ocnt = orc.raytrace(orc.OracleScene(demo.triangles, demo.material_bytes, nodes, env), u.tobytes(), w, h)
     assert pc.same_bits(img, want), pc.describe_diff(img, want)
-    for k in ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels"):
-        assert cnt[k] == ocnt[k], k
+    pc.check_counters(cnt, ocnt, culled=True, what="device-built tree")       # default walk: culls by distance
     # same closest hits as with the reference's tree: same rays, hits and image (no exact ties in this view)
     assert (cnt["rays"], cnt["hits"], cnt["misses"]) == (sah_cnt["rays"], sah_cnt["hits"], sah_cnt["misses"])
     assert pc.same_bits(img, sah_img), pc.describe_diff(img, sah_img)

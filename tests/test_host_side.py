@@ -69,7 +69,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"libmi3pt.so does not export {name}"
-    assert lib.mi3pt_abi_version() == 1
+    assert lib.mi3pt_abi_version() == 2
     out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (mi3pt_\w+)", out))
     assert exported == set(declared)

@@ -10,6 +10,7 @@
 #include "pt_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,19 +47,31 @@ struct mi3pt_ctx {
     uint32_t scene_flags = 0;
     int64_t max_tri_ref = -1;       // largest triangleIndex referenced by a leaf
     int64_t max_mat_ref = -1;       // largest materialIndex referenced by a triangle
+    // distance-culling walk (kernel variant 9): per-child |e1||e2| bounds in the packets' `cull` field
+    bool cull_enabled = true;       // MI3PT_CULL=0: variant 0 resolves to the reference-counter walk (7)
+    bool cull_dirty = true;         // triangles or tree changed since the last analysis
+    bool cull_ok = false;           // analysis done and the tree admits the walk
+    float cull_lmax = 0.0f;
+    int num_cus = 256;              // hipDeviceProp_t::multiProcessorCount
 
     // textures
     int width = 0, height = 0, local_rows = 0;
     int rank = 0, nranks = 1, block_rows = 8;                 // active tile
     int next_rank = 0, next_nranks = 1, next_block_rows = 8;  // applied at resize
     float4 *d_radiance = nullptr, *d_accum_own = nullptr, *d_accum = nullptr, *d_canvas = nullptr;
-    float4 *d_radiance_alt = nullptr;    // second frame-radiance image (frame pipelining)
+    // Batched frames write per-frame radiance slots, one set per launch parity.  Allocated on
+    // demand (an interactive host that presents every frame only ever needs one slot per
+    // parity; a batch of n > 1 frames allocates the full batch_cap once), see ensure_slots().
+    float4 *d_slots[2] = { nullptr, nullptr };
+    int slots_alloc[2] = { 0, 0 };       // frames each set can hold
+    int batch_cap = 1;                   // frames per launch at this size (batch limit, tile split, free memory)
     float4 *last_radiance = nullptr;     // the radiance image the most recent raytrace pass wrote
     uint32_t *d_canvas8 = nullptr;
     bool output_is_accum = false;
     uint64_t *d_block_counters = nullptr;
     uint32_t *d_tile_counter = nullptr;
     uint32_t *d_drain_flag = nullptr;     // signal memory: sequence number of the last batched launch that started draining
+    bool gate_enabled = false;            // launches wait on d_drain_flag (off when the memory or the wait is unavailable)
     uint32_t launch_seq = 0;              // sequence number of the last batched launch
     uint32_t *d_stack_overflow = nullptr; // [2 parities][PT_MAX_RESIDENT_WAVES][32][64] overflow stack entries
     uint64_t *d_wave_times = nullptr;     // diagnostic stamps, allocated by mi3pt_debug_wave_times(enable)
@@ -93,18 +106,35 @@ struct mi3pt_ctx {
     // Anything that observes or changes device state flushes the queue first.
     struct PendingFrame { uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE]; uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE]; };
     std::vector<PendingFrame> pending;
-    int batch_max = 16;                  // MI3PT_BATCH (1 = no batching)
+    int batch_max = 16;                  // MI3PT_BATCH (1 = no batching); x nranks for a tile split, see batch_limit()
     // per-launch GPU time of the batched raytrace kernel (HIP events on its own stream)
     hipEvent_t ev_rt[2][2] = {};
     bool ev_rt_pending[2] = { false, false };
     double rt_total_ms = 0.0, rt_last_ms = 0.0;
     uint64_t rt_launches = 0, rt_frames = 0;
     int ev_rt_frames[2] = { 0, 0 };
+    int ev_rt_newest = 0;                // parity of the most recent timed launch
+
+    // Presentation (mi3pt_set_present_mode).  EXACT: a submit that includes FULLSCREEN launches the
+    // queue first, so the canvas shows this very frame (the reference's renderer.ts:379-390).
+    // LATEST: the frame is queued like any other and the canvas is drawn from the running mean of
+    // the batches launched so far -- and only when that mean (or the fullscreen uniforms) changed
+    // since the last draw; a FULLSCREEN-only submit always launches the queue and shows everything.
+    int present_mode = MI3PT_PRESENT_EXACT;
+    uint64_t accum_version = 1;          // bumped whenever d_accum (or what `output` points at) changes
+    uint64_t presented_version = 0;      // accum_version the canvas was last drawn from
+    bool want_present = false;           // LATEST: a requested draw is still owed to the canvas (frames were queued)
+    uint8_t presented_fs[MI3PT_FULLSCREEN_UNIFORMS_SIZE] = {};
 
     bool timing = false;
     hipEvent_t ev[3][2] = {};
     bool ev_recorded[3] = { false, false, false };
 };
+
+// Most frames one launch may cover.  A single GPU batches 16 (the drain tail of a persistent
+// launch is then ~10 % of it); a rank of an N-way tile split renders 1/N of the image per frame,
+// so it batches N times as many frames for the same amount of work per launch.
+static const int BATCH_LIMIT = 128;
 
 static inline float ldf(const uint8_t *p, size_t off) { float f; std::memcpy(&f, p + off, 4); return f; }
 static inline int32_t ldi(const uint8_t *p, size_t off) { int32_t v; std::memcpy(&v, p + off, 4); return v; }
@@ -119,6 +149,8 @@ static int require_ctx(mi3pt_ctx *ctx)
 }
 
 static int require_idle(mi3pt_ctx *ctx);      // require_ctx + flush of the deferred frame queue (below)
+static int flush_pending(mi3pt_ctx *ctx);
+static int settle_canvas(mi3pt_ctx *ctx);
 
 extern "C" int mi3pt_abi_version(void) { return MI3PT_ABI_VERSION; }
 extern "C" const char *mi3pt_last_error(void) { return g_last_error.c_str(); }
@@ -155,72 +187,88 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     HIP_TRY(hipSetDevice(device));
     mi3pt_ctx *ctx = new mi3pt_ctx();
     ctx->device = device;
+    // every resource below is required: a failure tears the half-built context down and reports
+    // the call that failed (mi3pt_destroy copes with members that are still null)
+#define CREATE_TRY(expr)                                                                                \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            const std::string msg_ = std::string("mi3pt_create: " #expr ": ") + hipGetErrorString(e_);  \
+            (void)hipGetLastError();                                                                    \
+            mi3pt_destroy(ctx);                                                                         \
+            return pt_set_error(MI3PT_ERR_HIP, msg_);                                                   \
+        }                                                                                               \
+    } while (0)
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, device));
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    hipError_t e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio_greatest);
-    if (e != hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        delete ctx;
-        return pt_set_error(MI3PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    CREATE_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    if (hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     }
     ctx->stream = ctx->own_stream;
     if (const char *e = std::getenv("MI3PT_PIPELINE")) ctx->pipeline = std::atoi(e) != 0;
     for (int k = 0; k < 2; k++) {
         // lowest priority: the persistent raytrace waves must never starve the (tiny, ordered)
         // accumulate kernels on the main stream, which gate the batch after next
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&ctx->rt_stream[k], hipStreamNonBlocking, least) != hipSuccess)
-            (void)hipStreamCreateWithFlags(&ctx->rt_stream[k], hipStreamNonBlocking);
-        (void)hipEventCreateWithFlags(&ctx->rt_done[k], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&ctx->acc_done[k], hipEventDisableTiming);
+        if (hipStreamCreateWithPriority(&ctx->rt_stream[k], hipStreamNonBlocking, prio_least) != hipSuccess) {
+            (void)hipGetLastError();
+            CREATE_TRY(hipStreamCreateWithFlags(&ctx->rt_stream[k], hipStreamNonBlocking));
+        }
+        CREATE_TRY(hipEventCreateWithFlags(&ctx->rt_done[k], hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&ctx->acc_done[k], hipEventDisableTiming));
     }
-    (void)hipEventCreateWithFlags(&ctx->main_mark, hipEventDisableTiming);
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->main_mark, hipEventDisableTiming));
     for (int k = 0; k < 2; k++)
-        for (int j = 0; j < 2; j++) (void)hipEventCreate(&ctx->ev_rt[k][j]);
+        for (int j = 0; j < 2; j++) CREATE_TRY(hipEventCreate(&ctx->ev_rt[k][j]));
+    for (int p = 0; p < 3; p++)
+        for (int k = 0; k < 2; k++) CREATE_TRY(hipEventCreate(&ctx->ev[p][k]));
     if (const char *e = std::getenv("MI3PT_WALK_MIN")) ctx->walk_min = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_BATCH")) ctx->batch_max = std::atoi(e);
     if (ctx->batch_max < 1) ctx->batch_max = 1;
-    if (ctx->batch_max > 16) ctx->batch_max = 16;
+    if (ctx->batch_max > BATCH_LIMIT) ctx->batch_max = BATCH_LIMIT;
     if (const char *e = std::getenv("MI3PT_WAVES_PER_CU")) ctx->waves_per_cu = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_LEAF_MIN")) ctx->leaf_min = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_TOP_PACKETS")) ctx->top_packets = std::atoi(e);
+    if (const char *e = std::getenv("MI3PT_CULL")) ctx->cull_enabled = std::atoi(e) != 0;
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
-    if (hipMalloc(&ctx->d_env, env_bytes) != hipSuccess || hipMalloc(&ctx->d_cdf, env_bytes) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_tile_counter, 256) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * 32 * 64 * 4) != hipSuccess) {
-        mi3pt_destroy(ctx);
-        return pt_set_error(MI3PT_ERR_HIP, "hipMalloc(environment) failed");
+    CREATE_TRY(hipMalloc(&ctx->d_env, env_bytes));
+    CREATE_TRY(hipMalloc(&ctx->d_cdf, env_bytes));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_tile_counter, 256));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * 32 * 64 * 4));
+    CREATE_TRY(hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream));     // self-cleaning afterwards
+    // a word the command processor can poll (hipStreamWaitValue32) and a running kernel can write;
+    // optional: without it launches simply queue behind each other
+    const char *gate = std::getenv("MI3PT_GATE");                      // experiment knob: 0 = no gating
+    if (!(gate && gate[0] == '0') && hipExtMallocWithFlags((void **)&ctx->d_drain_flag, 8, hipMallocSignalMemory) == hipSuccess) {
+        CREATE_TRY(hipMemsetAsync(ctx->d_drain_flag, 0, 8, ctx->stream));
+        ctx->gate_enabled = true;
+    } else {
+        (void)hipGetLastError();
+        ctx->d_drain_flag = nullptr;
     }
-    (void)hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream);     // self-cleaning afterwards
-    // a word the command processor can poll (hipStreamWaitValue32) and a running kernel can write
-    const char *gate = std::getenv("MI3PT_GATE");                      // experiment knob: 0 = launches queue behind each other
-    if (!(gate && gate[0] == '0') && hipExtMallocWithFlags((void **)&ctx->d_drain_flag, 8, hipMallocSignalMemory) == hipSuccess)
-        (void)hipMemsetAsync(ctx->d_drain_flag, 0, 8, ctx->stream);
-    else
-        ctx->d_drain_flag = nullptr;                                     // launches then simply queue behind each other
-    (void)hipMemsetAsync(ctx->d_env, 0, env_bytes, ctx->stream);
-    (void)hipMemsetAsync(ctx->d_cdf, 0, env_bytes, ctx->stream);
+    CREATE_TRY(hipMemsetAsync(ctx->d_env, 0, env_bytes, ctx->stream));
+    CREATE_TRY(hipMemsetAsync(ctx->d_cdf, 0, env_bytes, ctx->stream));
+    CREATE_TRY(hipStreamSynchronize(ctx->stream));
+#undef CREATE_TRY
     std::memset(ctx->u_rt, 0, sizeof ctx->u_rt);
     std::memset(ctx->u_acc, 0, sizeof ctx->u_acc);
     std::memset(ctx->u_fs, 0, sizeof ctx->u_fs);
-    for (int p = 0; p < 3; p++)
-        for (int k = 0; k < 2; k++) (void)hipEventCreate(&ctx->ev[p][k]);
     *out_ctx = ctx;
     return MI3PT_OK;
 }
 
 static void free_textures(mi3pt_ctx *ctx)
 {
-    if (ctx->d_radiance) (void)hipFree(ctx->d_radiance);
-    if (ctx->d_radiance_alt) (void)hipFree(ctx->d_radiance_alt);
-    ctx->d_radiance_alt = ctx->last_radiance = nullptr;
-    if (ctx->d_accum_own) (void)hipFree(ctx->d_accum_own);
-    if (ctx->d_canvas) (void)hipFree(ctx->d_canvas);
-    if (ctx->d_canvas8) (void)hipFree(ctx->d_canvas8);
-    if (ctx->d_block_counters) (void)hipFree(ctx->d_block_counters);
-    ctx->d_radiance = ctx->d_accum_own = ctx->d_accum = ctx->d_canvas = nullptr;
+    for (void *p : { (void *)ctx->d_radiance, (void *)ctx->d_slots[0], (void *)ctx->d_slots[1], (void *)ctx->d_accum_own,
+                     (void *)ctx->d_canvas, (void *)ctx->d_canvas8, (void *)ctx->d_block_counters })
+        if (p) (void)hipFree(p);
+    ctx->d_radiance = ctx->d_slots[0] = ctx->d_slots[1] = ctx->last_radiance = nullptr;
+    ctx->slots_alloc[0] = ctx->slots_alloc[1] = 0;
+    ctx->d_accum_own = ctx->d_accum = ctx->d_canvas = nullptr;
     ctx->d_canvas8 = nullptr;
     ctx->d_block_counters = nullptr;
     ctx->nblocks = 0;
@@ -286,7 +334,7 @@ extern "C" int mi3pt_set_env_sampling(mi3pt_ctx *ctx, int enabled)
 extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
-    if (variant < 0 || variant > 8) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..8");
+    if (variant < 0 || variant > 9) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..9");
     if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
     return MI3PT_OK;
@@ -353,6 +401,7 @@ extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t 
     if (int rc = replace_buffer(ctx, &ctx->d_tripk, pk.data(), n * sizeof(pt::TriPacket))) return rc;
     ctx->ntris = n;
     ctx->max_mat_ref = max_mat;
+    ctx->cull_dirty = true;
     return MI3PT_OK;
 }
 
@@ -491,6 +540,7 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
     ctx->root_ref = ref_of(0);
     ctx->scene_flags = box_safe(0) ? 1u : 0u;
     ctx->max_tri_ref = max_tri;
+    ctx->cull_dirty = true;
     return MI3PT_OK;
 }
 
@@ -532,8 +582,8 @@ static int zero_textures(mi3pt_ctx *ctx)
     const size_t tex_bytes = (size_t)ctx->local_rows * ctx->width * 16;
     const size_t canvas_px = (size_t)ctx->width * ctx->height;
     if (tex_bytes) {
-        HIP_TRY(hipMemsetAsync(ctx->d_radiance, 0, tex_bytes * ctx->batch_max, ctx->stream));
-        HIP_TRY(hipMemsetAsync(ctx->d_radiance_alt, 0, tex_bytes * ctx->batch_max, ctx->stream));
+        // (the batch slots need no clearing: a launch writes every texel the ordered mean reads)
+        HIP_TRY(hipMemsetAsync(ctx->d_radiance, 0, tex_bytes, ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_accum, 0, tex_bytes, ctx->stream));
     }
     if (canvas_px) {
@@ -543,7 +593,18 @@ static int zero_textures(mi3pt_ctx *ctx)
     ctx->output_is_accum = false;
     ctx->last_radiance = ctx->d_radiance;
     ctx->main_dirty = true;
+    ctx->accum_version++;
+    ctx->presented_version = 0;       // the canvas was cleared
+    ctx->want_present = false;
     return MI3PT_OK;
+}
+
+// Frames one launch may cover for this context's tile (before the memory cap of mi3pt_resize).
+static int batch_limit(const mi3pt_ctx *ctx, int nranks)
+{
+    long b = (long)ctx->batch_max * (nranks > 1 ? nranks : 1);
+    if (ctx->batch_max <= 1) b = 1;
+    return (int)(b > BATCH_LIMIT ? BATCH_LIMIT : b);
 }
 
 extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
@@ -552,23 +613,52 @@ extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
     if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
         return pt_set_error(MI3PT_ERR_INVALID, "width/height must be in [1, 32768]");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(ctx->rt_stream[k]));
+    // Transactional: the new images are allocated into locals and the context only changes once
+    // every allocation has succeeded; a failure leaves it WITHOUT textures (width = height = 0,
+    // every later submit / read reports "before resize") instead of with dangling pointers.
     free_textures(ctx);
-    ctx->rank = ctx->next_rank; ctx->nranks = ctx->next_nranks; ctx->block_rows = ctx->next_block_rows;
-    ctx->width = width; ctx->height = height;
-    ctx->local_rows = mi3pt_tile_local_rows(height, ctx->rank, ctx->nranks, ctx->block_rows);
-    const size_t tex_bytes = (size_t)ctx->local_rows * width * 16;
+    ctx->width = ctx->height = ctx->local_rows = 0;
+    const int rank = ctx->next_rank, nranks = ctx->next_nranks, block_rows = ctx->next_block_rows;
+    const int local_rows = mi3pt_tile_local_rows(height, rank, nranks, block_rows);
+    const size_t tex_bytes = (size_t)local_rows * width * 16;
     const size_t canvas_px = (size_t)width * height;
-    HIP_TRY(hipMalloc((void **)&ctx->d_radiance, tex_bytes ? tex_bytes * ctx->batch_max : 16));
-    HIP_TRY(hipMalloc((void **)&ctx->d_radiance_alt, tex_bytes ? tex_bytes * ctx->batch_max : 16));
-    HIP_TRY(hipMalloc((void **)&ctx->d_accum_own, tex_bytes ? tex_bytes : 16));
-    ctx->d_accum = ctx->d_accum_own;
-    HIP_TRY(hipMalloc((void **)&ctx->d_canvas, canvas_px * 16));
-    HIP_TRY(hipMalloc((void **)&ctx->d_canvas8, canvas_px * 4));
-    ctx->nblocks = pt::raytrace_grid_blocks(tile_of(ctx));
+    pt::Tile t;
+    t.tex_w = width; t.tex_h = height; t.local_rows = local_rows; t.rank = rank; t.nranks = nranks; t.block_rows = block_rows;
+    const int nblocks = pt::raytrace_grid_blocks(t);
     // two counter sets: overlapping raytrace kernels of consecutive frames use alternate halves
-    const size_t cbytes = 2 * (size_t)(ctx->nblocks ? ctx->nblocks : 1) * pt::CNT_COUNT * sizeof(uint64_t);
-    HIP_TRY(hipMalloc((void **)&ctx->d_block_counters, cbytes));
-    HIP_TRY(hipMemsetAsync(ctx->d_block_counters, 0, cbytes, ctx->stream));
+    const size_t cbytes = 2 * (size_t)(nblocks ? nblocks : 1) * pt::CNT_COUNT * sizeof(uint64_t);
+    float4 *radiance = nullptr, *accum = nullptr, *canvas = nullptr;
+    uint32_t *canvas8 = nullptr;
+    uint64_t *counters = nullptr;
+    hipError_t e = hipMalloc((void **)&radiance, tex_bytes ? tex_bytes : 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&accum, tex_bytes ? tex_bytes : 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&canvas, canvas_px * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&canvas8, canvas_px * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&counters, cbytes);
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, cbytes, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        for (void *p : { (void *)radiance, (void *)accum, (void *)canvas, (void *)canvas8, (void *)counters })
+            if (p) (void)hipFree(p);
+        return pt_set_error(MI3PT_ERR_HIP, std::string("mi3pt_resize: allocating the textures failed: ") + hipGetErrorString(e));
+    }
+    ctx->rank = rank; ctx->nranks = nranks; ctx->block_rows = block_rows;
+    ctx->width = width; ctx->height = height; ctx->local_rows = local_rows;
+    ctx->d_radiance = radiance; ctx->d_accum_own = accum; ctx->d_accum = accum;
+    ctx->d_canvas = canvas; ctx->d_canvas8 = canvas8; ctx->d_block_counters = counters;
+    ctx->nblocks = nblocks;
+    // batch depth: the limit for this tile split, capped so that the two slot sets together take
+    // at most a quarter of the memory that is free now (slots are allocated when first needed)
+    ctx->batch_cap = batch_limit(ctx, nranks);
+    size_t free_b = 0, total_b = 0;
+    if (tex_bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t per_frame = 2 * tex_bytes;
+        const size_t fit = (free_b / 4) / per_frame;
+        if ((size_t)ctx->batch_cap > fit) ctx->batch_cap = fit < 1 ? 1 : (int)fit;
+    } else {
+        (void)hipGetLastError();
+    }
     return zero_textures(ctx);
 }
 
@@ -617,6 +707,7 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.npackets = (uint32_t)ctx->npackets;
     s.root_ref = ctx->root_ref;
     s.flags = ctx->scene_flags;
+    s.cull_lmax = ctx->cull_lmax;
     if (std::getenv("MI3PT_FORCE_SLOW_SLAB")) s.flags = 0;     // experiment knob: plain IEEE divisions
     s.env_w = MI3PT_ENV_WIDTH; s.env_h = MI3PT_ENV_HEIGHT;
     return s;
@@ -634,12 +725,159 @@ static int check_scene(const mi3pt_ctx *ctx)
     return MI3PT_OK;
 }
 
+// Analysis for the distance-culling walk (kernel variant 9; pt_kernels.hip k_raytrace_sm<.., CULL>,
+// proof in DESIGN.md section 3a).  Per child of every internal node it bounds E = |e1| * |e2|
+// over the triangles below that child -- the quantity the rounding error of the reference's
+// Moller-Trumbore code scales with -- and writes the two bounds, rounded up to 16 bits each, into
+// the node packet.  A child gets +infinity (never skipped) when something below it is outside
+// the analysis: a triangle with E > 2^-5 or with |e1| + |e2| above 16 x the scene's mean (such
+// triangles would loosen the bound for every other one), a non-finite coordinate, or a box that
+// does not contain what is below it (the walk bounds distances by boxes; the reference does not
+// care whether its boxes bound anything).  Runs when the triangles or the tree changed, on the
+// host, from the device's own copies of both.
+static inline uint32_t round_up_16(float f)
+{
+    uint32_t b;
+    std::memcpy(&b, &f, 4);
+    if (!(f == f) || (b & 0x7f800000u) == 0x7f800000u || (b >> 31)) return 0x7f80u;   // NaN / inf / negative: never skip
+    const uint32_t r = (b + 0xffffu) >> 16;
+    return r > 0x7f80u ? 0x7f80u : r;
+}
+
+static int prepare_cull(mi3pt_ctx *ctx)
+{
+    if (!ctx->cull_dirty) return MI3PT_OK;
+    const bool wanted = ctx->variant == 9 || (ctx->variant == 0 && ctx->cull_enabled);
+    if (!wanted || ctx->leaf_cap < 4 || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
+        return MI3PT_OK;       // stays dirty: pick_variant falls back to the reference-counter walk
+    if (int rc = flush_pending(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(ctx->rt_stream[k]));
+    const size_t n = ctx->nnodes, nt = ctx->ntris;
+    std::vector<uint8_t> nodes(n * MI3PT_BVHNODE_STRIDE);
+    std::vector<pt::TriPacket> tris(nt);
+    HIP_TRY(hipMemcpy(nodes.data(), ctx->d_nodes, nodes.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tris.data(), ctx->d_tripk, nt * sizeof(pt::TriPacket), hipMemcpyDeviceToHost));
+    const uint8_t *src = nodes.data();
+    auto is_leaf = [&](size_t i) { return ldi(src + i * MI3PT_BVHNODE_STRIDE, 28) == 1; };
+
+    // per triangle: E and L in double from the fp32 vertices
+    auto tri_el = [&](size_t ti, double &E, double &Lsum) {
+        const pt::TriPacket &t = tris[ti];
+        double e1 = 0, e2 = 0;
+        for (int k = 0; k < 3; k++) {
+            const double u = (double)t.b[k] - (double)t.a[k], v = (double)t.c[k] - (double)t.a[k];
+            e1 += u * u; e2 += v * v;
+        }
+        e1 = std::sqrt(e1); e2 = std::sqrt(e2);
+        E = e1 * e2; Lsum = e1 + e2;
+    };
+    double mean_l = 0.0;
+    size_t counted = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!is_leaf(i)) continue;
+        const int32_t ti = ldi(src + i * MI3PT_BVHNODE_STRIDE, 40);
+        if (ti < 0 || (size_t)ti >= nt) return MI3PT_OK;      // check_scene reports it; no analysis
+        double E, Ls;
+        tri_el((size_t)ti, E, Ls);
+        if (Ls == Ls && Ls < 1e30) { mean_l += Ls; counted++; }
+    }
+    mean_l = counted ? mean_l / (double)counted : 0.0;
+    const double lcap = 16.0 * mean_l, ecap = 0.03125;
+
+    std::vector<float> emax(n, 0.0f);       // +inf = never skip
+    const float inf = __builtin_inff();
+    double lmax = 0.0;
+    auto inside = [&](const uint8_t *outer, const float mn[3], const float mx[3]) {
+        for (int k = 0; k < 3; k++)
+            if (!(ldf(outer, 4 * k) <= mn[k] && ldf(outer, 16 + 4 * k) >= mx[k])) return false;     // false for NaNs too
+        return true;
+    };
+    for (size_t i = n; i-- > 0;) {          // children come after their parent (checked at upload)
+        const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+        if (is_leaf(i)) {
+            const pt::TriPacket &t = tris[(size_t)ldi(r, 40)];
+            float mn[3], mx[3];
+            for (int k = 0; k < 3; k++) {
+                mn[k] = std::fmin(std::fmin(t.a[k], t.b[k]), t.c[k]);
+                mx[k] = std::fmax(std::fmax(t.a[k], t.b[k]), t.c[k]);
+            }
+            double E, Ls;
+            tri_el((size_t)ldi(r, 40), E, Ls);
+            const bool ok = E == E && Ls == Ls && E <= ecap && Ls <= lcap && inside(r, mn, mx);
+            if (ok) {
+                emax[i] = (float)(E * (1.0 + 1e-6));
+                if ((double)emax[i] < E) emax[i] = std::nextafter(emax[i], inf);
+                if (Ls > lmax) lmax = Ls;
+            } else {
+                emax[i] = inf;
+            }
+        } else {
+            const int32_t left = ldi(r, 32), right = ldi(r, 36);
+            float e = 0.0f;
+            for (int32_t c : { left, right }) {
+                if (c < 0 || (size_t)c >= n) { e = inf; continue; }
+                const uint8_t *cr = src + (size_t)c * MI3PT_BVHNODE_STRIDE;
+                float mn[3], mx[3];
+                for (int k = 0; k < 3; k++) { mn[k] = ldf(cr, 4 * k); mx[k] = ldf(cr, 16 + 4 * k); }
+                if (!inside(r, mn, mx)) e = inf;
+                if (emax[(size_t)c] > e) e = emax[(size_t)c];
+            }
+            emax[i] = e;
+        }
+    }
+    // packet numbering of mi3pt_upload_bvh: internal nodes in index order
+    std::vector<uint32_t> cull(ctx->npackets, 0x7f807f80u);
+    size_t pk = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (is_leaf(i)) continue;
+        const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+        const int32_t left = ldi(r, 32), right = ldi(r, 36);
+        const uint32_t hl = left >= 0 ? round_up_16(emax[(size_t)left]) : 0x7f80u;
+        const uint32_t hr = right >= 0 ? round_up_16(emax[(size_t)right]) : 0x7f80u;
+        if (pk < cull.size()) cull[pk] = (hl << 16) | hr;
+        pk++;
+    }
+    if (pk != ctx->npackets) return pt_set_error(MI3PT_ERR_STATE, "cull analysis: packet count mismatch");
+    uint32_t *d_cull = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_cull, cull.size() * 4));
+    hipError_t e = hipMemcpyAsync(d_cull, cull.data(), cull.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        pt::launch_patch_cull(static_cast<float4 *>(ctx->d_packets), d_cull, (uint32_t)ctx->npackets, ctx->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_cull);
+    if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("cull analysis: ") + hipGetErrorString(e));
+    float lm = (float)(lmax * (1.0 + 1e-6));
+    if ((double)lm < lmax) lm = std::nextafter(lm, inf);
+    ctx->cull_lmax = lm;
+    ctx->cull_ok = true;
+    ctx->cull_dirty = false;
+    ctx->main_dirty = true;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_set_present_mode(mi3pt_ctx *ctx, int mode)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    if (mode != MI3PT_PRESENT_EXACT && mode != MI3PT_PRESENT_LATEST)
+        return pt_set_error(MI3PT_ERR_INVALID, "mode must be MI3PT_PRESENT_EXACT or MI3PT_PRESENT_LATEST");
+    if (int rc = require_idle(ctx)) return rc;
+    ctx->present_mode = mode;
+    ctx->presented_version = 0;
+    ctx->want_present = false;
+    return MI3PT_OK;
+}
+
 // 0 = auto -> the persistent kernel; the probes only know the two per-ray walks.
 static int pick_variant(const mi3pt_ctx *ctx)
 {
     if (ctx->env_sampling) return 2;               // the dormant path lives in the per-pixel kernel only
     const bool defer_ok = ctx->leaf_cap >= 4;      // see mi3pt_upload_bvh: leaves may be tested out of order
-    if (ctx->variant == 0) return defer_ok ? 7 : 4;
+    const bool cull_ok = defer_ok && ctx->cull_ok && !ctx->cull_dirty;     // see prepare_cull
+    if (ctx->variant == 0) return cull_ok && ctx->cull_enabled ? 9 : (defer_ok ? 7 : 4);
+    if (ctx->variant == 9 && !cull_ok) return defer_ok ? 7 : 4;
     if (ctx->variant >= 7 && !defer_ok) return ctx->variant == 8 ? 6 : 4;
     return ctx->variant;
 }
@@ -680,6 +918,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.drain_flag = nullptr;
     L.drain_seq = 0;
     L.waves_per_cu = ctx->waves_per_cu;
+    L.num_cus = ctx->num_cus;
     L.top_packets = ctx->top_packets;
     return L;
 }
@@ -706,18 +945,48 @@ static int collect_rt_time(mi3pt_ctx *ctx, int par)
     return MI3PT_OK;
 }
 
-// Launches the queued frames: one raytrace kernel over (frame slot, tile) jobs on this
-// parity's side stream, then the ordered multi-frame running mean on the main stream.
-static int flush_pending(mi3pt_ctx *ctx)
+// Makes sure parity `par`'s slot set can hold n frames.  One frame: a single slot (the interactive
+// hosts never need more).  More: the full batch_cap at once, so a batching caller allocates once.
+// Growing frees the old set (hipFree waits for the device, so nothing still reads it).
+static int ensure_slots(mi3pt_ctx *ctx, int par, int n)
 {
-    if (ctx->pending.empty()) return MI3PT_OK;
-    const int n = (int)ctx->pending.size();
-    const mi3pt_ctx::PendingFrame first = ctx->pending.front();
-    ctx->pending.clear();
+    if (ctx->slots_alloc[par] >= n) return MI3PT_OK;
+    const size_t tex_bytes = (size_t)ctx->local_rows * ctx->width * 16;
+    int want = n > 1 ? ctx->batch_cap : 1;
+    if (want < n) want = n;
+    float4 *fresh = nullptr;
+    hipError_t e = hipMalloc((void **)&fresh, tex_bytes ? tex_bytes * (size_t)want : 16);
+    if (e != hipSuccess && want > n) {          // not enough memory for the full depth: take what this batch needs
+        (void)hipGetLastError();
+        want = n;
+        e = hipMalloc((void **)&fresh, tex_bytes ? tex_bytes * (size_t)want : 16);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return pt_set_error(MI3PT_ERR_HIP, std::string("radiance slots: ") + hipGetErrorString(e));
+    }
+    if (ctx->d_slots[par]) (void)hipFree(ctx->d_slots[par]);
+    ctx->d_slots[par] = fresh;
+    ctx->slots_alloc[par] = want;
+    return MI3PT_OK;
+}
+
+// One launch: frames [first, first + n) of the queue as one raytrace kernel over (frame slot,
+// tile) jobs on this parity's side stream, then the ordered multi-frame running mean on the
+// main stream.
+static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame &first, int n)
+{
     const pt::AccUniforms acc = acc_from(first.u_acc);
     pt::RtLaunch L = build_launch(ctx, first.u_rt, acc);
     const bool f16 = ctx->storage == MI3PT_STORAGE_F16;
-    const int par = (int)(ctx->seq++ & 1u);
+    const int par = (int)(ctx->seq & 1u);
+    if (int rc = ensure_slots(ctx, par, n)) {
+        // a single slot always fits where the textures did; fall back to it before giving up
+        if (n == 1 || ensure_slots(ctx, par, 1) != MI3PT_OK) return rc;
+        ctx->batch_cap = 1;
+        return MI3PT_ERR_STATE;      // caller re-chunks with the smaller cap
+    }
+    ctx->seq++;
     hipStream_t rs = ctx->rt_stream[par];
     if (ctx->main_dirty) {      // resets / rebinds queued on the main stream come first
         HIP_TRY(hipEventRecord(ctx->main_mark, ctx->stream));
@@ -727,7 +996,7 @@ static int flush_pending(mi3pt_ctx *ctx)
     }
     // the accumulate of two batches ago must have consumed this parity's radiance slots
     if (ctx->acc_done_valid[par]) HIP_TRY(hipStreamWaitEvent(rs, ctx->acc_done[par], 0));
-    L.radiance = par ? ctx->d_radiance_alt : ctx->d_radiance;
+    L.radiance = ctx->d_slots[par];
     L.nframes = n;
     L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
     L.tile_counter = ctx->d_tile_counter + par * 32;
@@ -738,19 +1007,36 @@ static int flush_pending(mi3pt_ctx *ctx)
     // its persistent waves then start to exit, and this launch's workgroups take the slots they
     // free.  Enqueued earlier, the kernel would sit in the dispatcher for the previous launch's
     // whole run -- same throughput, but event / profiler durations twice the execution time.
-    if (ctx->d_drain_flag && pt::raytrace_grid_blocks(L.tile) > 0) {      // (an empty tile launches nothing)
-        if (ctx->launch_seq != 0)
-            HIP_TRY(hipStreamWaitValue32(rs, ctx->d_drain_flag, ctx->launch_seq, hipStreamWaitValueGte, 0xffffffffu));
-        L.drain_flag = ctx->d_drain_flag;
-        L.drain_seq = ++ctx->launch_seq;
+    const uint32_t seq_before = ctx->launch_seq;
+    const bool launches = pt::raytrace_grid_blocks(L.tile) > 0;       // (an empty tile launches nothing)
+    if (ctx->gate_enabled && launches) {
+        if (ctx->launch_seq != 0 &&
+            hipStreamWaitValue32(rs, ctx->d_drain_flag, ctx->launch_seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
+            // no stream memory operations here: launches simply queue behind each other from now on
+            (void)hipGetLastError();
+            ctx->gate_enabled = false;
+        } else {
+            L.drain_flag = ctx->d_drain_flag;
+            L.drain_seq = ++ctx->launch_seq;
+        }
     }
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev_rt[par][0], rs));
     pt::launch_raytrace(L, false, pick_variant(ctx), rs);
-    HIP_TRY(hipGetLastError());
+    if (hipError_t e = hipGetLastError()) {
+        // The kernel that would have published drain_seq never ran: publish it from the host side
+        // of the stream instead, so that neither a later launch nor mi3pt_destroy waits for it.
+        if (L.drain_flag && hipStreamWriteValue32(rs, ctx->d_drain_flag, L.drain_seq, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->launch_seq = seq_before;
+            ctx->gate_enabled = false;
+        }
+        return pt_set_error(MI3PT_ERR_HIP, std::string("raytrace launch: ") + hipGetErrorString(e));
+    }
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev_rt[par][1], rs));
         ctx->ev_rt_pending[par] = true;
         ctx->ev_rt_frames[par] = n;
+        ctx->ev_rt_newest = par;
     }
     HIP_TRY(hipEventRecord(ctx->rt_done[par], rs));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->rt_done[par], 0));
@@ -762,6 +1048,26 @@ static int flush_pending(mi3pt_ctx *ctx)
     ctx->acc_done_valid[par] = true;
     ctx->last_radiance = L.radiance + (size_t)(n - 1) * L.slot_pixels;
     ctx->output_is_accum = true;
+    ctx->accum_version++;
+    return MI3PT_OK;
+}
+
+// Launches everything that is queued, batch_cap frames at a time.  The queue is emptied even on
+// failure (the frames are lost with the error; the context stays usable).
+static int flush_pending(mi3pt_ctx *ctx)
+{
+    if (ctx->pending.empty()) return MI3PT_OK;
+    std::vector<mi3pt_ctx::PendingFrame> q;
+    q.swap(ctx->pending);
+    size_t at = 0;
+    while (at < q.size()) {
+        int n = (int)(q.size() - at);
+        if (n > ctx->batch_cap) n = ctx->batch_cap;
+        const int rc = launch_batch(ctx, q[at], n);
+        if (rc == MI3PT_ERR_STATE && n > 1) continue;       // the slot memory shrank batch_cap: retry smaller
+        if (rc != MI3PT_OK) return rc;
+        at += (size_t)n;
+    }
     return MI3PT_OK;
 }
 
@@ -780,6 +1086,22 @@ static bool batch_compatible(const mi3pt_ctx::PendingFrame &last, const mi3pt_ct
     return ldu(next.u_rt, 12) == ldu(last.u_rt, 12) + 1u && ldu(next.u_acc, 8) == ldu(last.u_acc, 8) + 1u;
 }
 
+static int run_fullscreen(mi3pt_ctx *ctx)
+{
+    pt::FsUniforms fs;
+    fs.res_x = ldf(ctx->u_fs, 0); fs.res_y = ldf(ctx->u_fs, 4); fs.aspect = ldf(ctx->u_fs, 8);
+    fs.scaling = ldf(ctx->u_fs, 12); fs.denoise = ldu(ctx->u_fs, 16); fs.tonemapping = ldu(ctx->u_fs, 20);
+    const float4 *tex = ctx->output_is_accum ? ctx->d_accum : ctx->last_radiance;
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2][0], ctx->stream));
+    pt::launch_fullscreen(fs, tex, ctx->width, ctx->height, ctx->width, ctx->height, ctx->d_canvas,
+                          ctx->d_canvas8, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[2][1], ctx->stream)); ctx->ev_recorded[2] = true; }
+    ctx->presented_version = ctx->accum_version;
+    std::memcpy(ctx->presented_fs, ctx->u_fs, sizeof ctx->presented_fs);
+    return MI3PT_OK;
+}
+
 extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
 {
     if (int rc = require_ctx(ctx)) return rc;
@@ -788,16 +1110,23 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
         return pt_set_error(MI3PT_ERR_INVALID, "unknown bits in pass_mask");
     const bool do_rt = pass_mask & MI3PT_SUBMIT_RAYTRACE, do_acc = pass_mask & MI3PT_SUBMIT_ACCUMULATE;
     const bool do_fs = pass_mask & MI3PT_SUBMIT_FULLSCREEN;
+    if (do_fs && ctx->nranks != 1)
+        return pt_set_error(MI3PT_ERR_STATE,
+                            "the fullscreen pass needs the whole image: gather the tiles into a 1-rank context");
+    if (do_rt) {
+        if (int rc = check_scene(ctx)) return rc;
+        if (int rc = prepare_cull(ctx)) return rc;      // (no-op unless the scene changed)
+    }
     const pt::Tile tile = tile_of(ctx);
     const pt::AccUniforms acc = acc_uniforms(ctx);
     const bool f16 = ctx->storage == MI3PT_STORAGE_F16;
     const int variant = pick_variant(ctx);
     const bool same_region = acc.res_w == (uint32_t)ldf(ctx->u_rt, 0) && acc.res_h == (uint32_t)ldf(ctx->u_rt, 4);
+    const bool lazy_present = ctx->present_mode == MI3PT_PRESENT_LATEST;
     bool acc_done = false;
 
     if (do_rt && do_acc && same_region && ctx->pipeline && variant >= 4) {
         // queued: runs with its neighbours as one batch (see flush_pending)
-        if (int rc = check_scene(ctx)) return rc;
         mi3pt_ctx::PendingFrame f;
         std::memcpy(f.u_rt, ctx->u_rt, sizeof f.u_rt);
         std::memcpy(f.u_acc, ctx->u_acc, sizeof f.u_acc);
@@ -805,14 +1134,13 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
             if (int rc = flush_pending(ctx)) return rc;
         if (ctx->pending.empty()) for (bool &r : ctx->ev_recorded) r = false;
         ctx->pending.push_back(f);
-        if ((int)ctx->pending.size() >= ctx->batch_max || do_fs)
+        if ((int)ctx->pending.size() >= ctx->batch_cap || (do_fs && !lazy_present))
             if (int rc = flush_pending(ctx)) return rc;
         acc_done = true;
     } else {
-        if (int rc = flush_pending(ctx)) return rc;
+        if (int rc = flush_pending(ctx)) return rc;      // anything but a queued frame runs after the queue
         for (bool &r : ctx->ev_recorded) r = false;
         if (do_rt) {
-            if (int rc = check_scene(ctx)) return rc;
             const pt::RtLaunch L = build_launch(ctx, ctx->u_rt, acc);
             // Fuse when the accumulate pass covers exactly the pixels the raytrace pass writes.
             const bool fused = do_acc && same_region;
@@ -823,6 +1151,7 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
             ctx->last_radiance = ctx->d_radiance;
             ctx->output_is_accum = fused;
             ctx->main_dirty = true;     // a later batch must not overtake this kernel
+            ctx->accum_version++;
             acc_done = fused;
         }
     }
@@ -833,22 +1162,30 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
         if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[1][1], ctx->stream)); ctx->ev_recorded[1] = true; }
         ctx->output_is_accum = true;   // accumulate.ts:171-175 copies the mean into outputTexture
         ctx->main_dirty = true;
+        ctx->accum_version++;
     }
     if (do_fs) {
-        if (ctx->nranks != 1)
-            return pt_set_error(MI3PT_ERR_STATE,
-                                "the fullscreen pass needs the whole image: gather the tiles into a 1-rank context");
-        pt::FsUniforms fs;
-        fs.res_x = ldf(ctx->u_fs, 0); fs.res_y = ldf(ctx->u_fs, 4); fs.aspect = ldf(ctx->u_fs, 8);
-        fs.scaling = ldf(ctx->u_fs, 12); fs.denoise = ldu(ctx->u_fs, 16); fs.tonemapping = ldu(ctx->u_fs, 20);
-        const float4 *tex = ctx->output_is_accum ? ctx->d_accum : ctx->last_radiance;
-        if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2][0], ctx->stream));
-        pt::launch_fullscreen(fs, tex, ctx->width, ctx->height, ctx->width, ctx->height, ctx->d_canvas,
-                              ctx->d_canvas8, ctx->stream);
-        HIP_TRY(hipGetLastError());
-        if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[2][1], ctx->stream)); ctx->ev_recorded[2] = true; }
+        // LATEST: frames may still be queued; the canvas is drawn from what has been launched, and
+        // only if that (or the pass's uniforms) changed since the last draw.  What is still queued
+        // is owed: a canvas read-back (or a FULLSCREEN-only submit) draws it.
+        const bool current = ctx->presented_version == ctx->accum_version &&
+                             std::memcmp(ctx->presented_fs, ctx->u_fs, sizeof ctx->u_fs) == 0;
+        if (lazy_present && current) {
+            if (!ctx->pending.empty()) ctx->want_present = true;
+            return MI3PT_OK;
+        }
+        if (int rc = run_fullscreen(ctx)) return rc;
+        ctx->want_present = lazy_present && !ctx->pending.empty();
     }
     return MI3PT_OK;
+}
+
+// LATEST presentation: the draw a queued frame asked for happens before the canvas is looked at.
+static int settle_canvas(mi3pt_ctx *ctx)
+{
+    if (ctx->present_mode != MI3PT_PRESENT_LATEST || !ctx->want_present || ctx->width == 0 || ctx->nranks != 1) return MI3PT_OK;
+    ctx->want_present = false;
+    return run_fullscreen(ctx);
 }
 
 extern "C" int mi3pt_flush(mi3pt_ctx *ctx) { return require_idle(ctx); }
@@ -877,6 +1214,7 @@ extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t 
         need = (size_t)ctx->local_rows * ctx->width * 4;
         break;
     case MI3PT_TEX_CANVAS:
+        if (int rc = settle_canvas(ctx)) return rc;
         src = ctx->d_canvas;
         need = (size_t)ctx->height * ctx->width * 4;
         break;
@@ -908,6 +1246,7 @@ extern "C" int mi3pt_write_texture(mi3pt_ctx *ctx, int which, const float *src, 
     }
     ctx->output_is_accum = true;      // like the copy-back of accumulate.ts:171-175
     ctx->main_dirty = true;
+    ctx->accum_version++;
     return MI3PT_OK;
 }
 
@@ -918,6 +1257,7 @@ extern "C" int mi3pt_read_canvas_rgba8(mi3pt_ctx *ctx, uint8_t *dst, size_t nbyt
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "read before resize");
     const size_t need = (size_t)ctx->width * ctx->height * 4;
     if (nbytes != need) return pt_set_error(MI3PT_ERR_INVALID, "destination size does not match the canvas");
+    if (int rc = settle_canvas(ctx)) return rc;
     HIP_TRY(hipMemcpyAsync(dst, ctx->d_canvas8, need, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MI3PT_OK;
@@ -939,6 +1279,7 @@ extern "C" int mi3pt_bind_accumulation(mi3pt_ctx *ctx, void *dev_ptr, size_t nby
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "bind before resize");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->main_dirty = true;
+    ctx->accum_version++;
     if (!dev_ptr) {
         ctx->d_accum = ctx->d_accum_own;
         return MI3PT_OK;
@@ -963,11 +1304,12 @@ extern "C" int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds)
     if (int rc = require_idle(ctx)) return rc;
     if (!microseconds || pass < 0 || pass > 2) return pt_set_error(MI3PT_ERR_INVALID, "bad argument");
     if (pass == MI3PT_PASS_RAYTRACE && !ctx->ev_recorded[0] && (ctx->ev_rt_pending[0] || ctx->ev_rt_pending[1] || ctx->rt_launches)) {
-        // batched launch: the most recent batch's kernel time divided by its frames
-        const uint64_t before = ctx->rt_launches;
-        for (int par = 0; par < 2; par++) if (int rc = collect_rt_time(ctx, par)) return rc;
-        (void)before;
-        const int frames = ctx->ev_rt_frames[(int)((ctx->seq + 1u) & 1u)];
+        // batched launch: the most recent batch's kernel time divided by its frames (the older
+        // parity is folded in first, so rt_last_ms ends up holding the newest launch)
+        const int newest = ctx->ev_rt_newest;
+        if (int rc = collect_rt_time(ctx, newest ^ 1)) return rc;
+        if (int rc = collect_rt_time(ctx, newest)) return rc;
+        const int frames = ctx->ev_rt_frames[newest];
         *microseconds = (float)(ctx->rt_last_ms * 1000.0 / (frames > 0 ? frames : 1));
         return MI3PT_OK;
     }
@@ -983,7 +1325,8 @@ extern "C" int mi3pt_raytrace_launch_stats(mi3pt_ctx *ctx, int reset, double *to
                                            uint64_t *frames)
 {
     if (int rc = require_idle(ctx)) return rc;
-    for (int par = 0; par < 2; par++) if (int rc = collect_rt_time(ctx, par)) return rc;
+    if (int rc = collect_rt_time(ctx, ctx->ev_rt_newest ^ 1)) return rc;
+    if (int rc = collect_rt_time(ctx, ctx->ev_rt_newest)) return rc;
     if (total_ms) *total_ms = ctx->rt_total_ms;
     if (launches) *launches = ctx->rt_launches;
     if (frames) *frames = ctx->rt_frames;
@@ -1106,7 +1449,7 @@ extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t 
         e = hipMemsetAsync(d_counter, 0, 4, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
         if (e == hipSuccess && !pt::launch_walk_probe(scene_refs(ctx), d_rays, (uint32_t)n, (uint32_t)(n * (size_t)passes), d_counter, d_out, waves_per_simd, lcap,
-                                                      ctx->leaf_min, ctx->stream)) {
+                                                      ctx->leaf_min, ctx->num_cus, ctx->stream)) {
             pt_set_error(MI3PT_ERR_INVALID, "waves_per_simd must be 4, 5, 6 or 8");
             e = hipErrorInvalidValue;
         }

@@ -5,8 +5,8 @@
 
 namespace pt {
 
-// Upper bound on the persistent kernels' grid (256 CUs x 24 waves); sizes the per-wave
-// overflow-stack slices and diagnostic slots.
+// Upper bound on the persistent kernels' grid (CUs x waves per CU, clamped to this); sizes the
+// per-wave overflow-stack slices and diagnostic slots.  MI355X: 256 CUs x at most 24 waves.
 constexpr int PT_MAX_RESIDENT_WAVES = 256 * 24;
 
 // Stack entries per lane that the state-machine kernels keep in LDS ([depth][lane], 256 B per
@@ -33,7 +33,9 @@ struct NodePacket {
     float rmin[3], rmax[3];
     uint32_t lref, rref;     // child reference: leaf -> 0x80000000 | triangleIndex, else packet index
     uint32_t flags;          // bit0 / bit1: left / right box has a non-zero coordinate outside [2^-70, 2^60]
-    uint32_t pad;
+    uint32_t cull;           // CULL walk: upper bounds of |e1|*|e2| over the triangles below the left (high 16
+                             // bits) / right (low 16 bits) child, as the top halves of binary32 values rounded
+                             // up; 0x7f80 = +infinity = never skip.  Written by the context's cull analysis.
 };
 static_assert(sizeof(NodePacket) == 64, "packet is one 64-B line");
 
@@ -61,6 +63,7 @@ struct SceneRefs {
     uint32_t ntris, nnodes, nmats, npackets;
     uint32_t root_ref;      // reference of node 0 in packet terms
     uint32_t flags;         // bit0: every ROOT box coordinate is 0 or within [2^-70, 2^60]
+    float cull_lmax;        // CULL walk: max |e1| + |e2| over the triangles a packet's `cull` field admits
     int32_t env_w, env_h;
 };
 
@@ -111,6 +114,7 @@ struct RtLaunch {
     uint32_t drain_seq;
     int32_t top_packets;         // node packets to stage in LDS per wave (0..64)
     int32_t waves_per_cu;        // persistent kernels: resident one-wave workgroups per CU
+    int32_t num_cus;             // compute units of the device (hipDeviceProp_t::multiProcessorCount)
 };
 
 void launch_raytrace(const RtLaunch &L, bool fuse_accumulate, int variant, hipStream_t s);
@@ -124,8 +128,10 @@ void launch_debug_intersect(const SceneRefs &scene, const float *rays, size_t n,
                             hipStream_t s);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s);
 int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, uint32_t total, uint32_t *counter, float4 *out, int waves_per_simd,
-                      int lcap, int leaf_min, hipStream_t s);
+                      int lcap, int leaf_min, int num_cus, hipStream_t s);
 int raytrace_grid_blocks(const Tile &tile);
-int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu);
+int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu, int num_cus);
+// writes NodePacket::cull of `npackets` packets from a dense array (the context's cull analysis)
+void launch_patch_cull(float4 *packets, const uint32_t *cull, uint32_t npackets, hipStream_t s);
 
 }  // namespace pt

@@ -197,6 +197,20 @@ PT_DEV bool ray_aabb_fast(const f3 &o, const f3 &d, const RayPre &p, float mnx, 
     return !(tmin > tmax) && (tmax >= fmaxf(0.0f, tmin));
 }
 
+// ray_aabb_fast() that also hands out the entry distance tmin (CULL walk: ordering and the
+// distance bound; the hit predicate is the same expression)
+PT_DEV bool ray_aabb_fast_t(const f3 &o, const f3 &d, const RayPre &p, float mnx, float mny, float mnz,
+                            float mxx, float mxy, float mxz, float &tmin_out)
+{
+    const float ax = div_pre(mnx - o.x, d.x, p.ix), bx = div_pre(mxx - o.x, d.x, p.ix);
+    const float ay = div_pre(mny - o.y, d.y, p.iy), by = div_pre(mxy - o.y, d.y, p.iy);
+    const float az = div_pre(mnz - o.z, d.z, p.iz), bz = div_pre(mxz - o.z, d.z, p.iz);
+    const float tmin = fmaxf(fmaxf(fmaxf(-PT_INF, fminf(ax, bx)), fminf(ay, by)), fminf(az, bz));
+    const float tmax = fminf(fminf(fminf(PT_INF, fmaxf(ax, bx)), fmaxf(ay, by)), fmaxf(az, bz));
+    tmin_out = tmin;
+    return !(tmin > tmax) && (tmax >= fmaxf(0.0f, tmin));
+}
+
 // raytrace.wgsl:78-116 -- Moller-Trumbore, two-sided.  Returns hit and (t, u, v);
 // position and normal are formed once, for the closest hit, by finish_hit().
 PT_DEV bool ray_triangle(const f3 &o, const f3 &d, const f3 &a, const f3 &b, const f3 &c,
@@ -895,6 +909,26 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
 // ---------------------------------------------------------------------------------
 enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
 
+// Per-segment constants of the CULL walk's distance bound.  For a triangle with
+// E = |e1| |e2| <= 2^-5 and L = |e1| + |e2| <= lmax that the reference's Moller-Trumbore code
+// accepts with t <= best.t, the point o + t d lies within
+//     delta = 2^-24 * kappa * (32 best.t |d| + 52 L),   kappa = E |d| / |det| <= E |d| / EPSILON
+// of the triangle, hence of every box that holds it; along the ray that is at most
+// delta * max_i |1 / d_i|.  With dn = |dx| + |dy| + |dz| >= |d|:
+//     margin(E, best.t) = E * (Ka * best.t + Kb),  Ka = 32 u 1e6 dn^2 dinv,  Kb = 52 u 1e6 dn dinv lmax
+// (u = 2^-24; both rounded up by 1.001 for the handful of roundings in forming them).  Rays the
+// analysis does not cover (a plain-division ray, dn > 2, non-finite) get Ka = Kb = +infinity: no culling (a child that
+// must never be skipped carries E = +infinity).
+PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float lmax, float &ka, float &kb)
+{
+    const float dn = (fabsf(d.x) + fabsf(d.y)) + fabsf(d.z);
+    const float dinv = fmaxf(fmaxf(fabsf(pre.ix), fabsf(pre.iy)), fabsf(pre.iz));
+    const float g = dn * dinv;
+    const bool ok = (pre.flags & 8u) == 0u && dn <= 2.0f;
+    ka = ok ? 1.90926f * (dn * g) : __builtin_inff();
+    kb = ok ? 3.10254f * (g * lmax) : __builtin_inff();
+}
+
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
 #define PT_SM_TOP_PACKETS 32       // node packets staged in LDS per wave (2 KB: 16 waves per CU still fit): the top 5 levels
 #ifndef PT_SM_MIN_WAVES
@@ -906,7 +940,18 @@ enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
 // VALU-issue-bound and the top of the tree is L1-resident anyway, while the second load path
 // costs registers -- so the shipped default keeps TOPLDS = false.
 // (5 waves per SIMD = 96 VGPRs spills 53 registers and runs 28 % slower: profiles/r01_g_rejected_experiments.log)
-template <bool FUSE, bool TOPLDS, bool DEFER>
+//
+// CULL (kernel variant 9, needs DEFER): exact-image distance culling.  The reference walk has no
+// upper bound by the current hit (raytrace.wgsl:118-152, 154-203): it tests every box the ray
+// touches.  A child whose box the ray enters at tmin is skipped here when
+//     tmin * (1 - 2^-21)  -  E * (Ka * best.t + Kb)  >  best.t
+// where E (packet, 16 bits per child, rounded up) bounds |e1| * |e2| over the triangles below the
+// child and Ka, Kb are per-segment constants of the ray (cull_setup).  DESIGN.md section 3a proves
+// that every triangle below such a child, had it been tested, would have been rejected or have
+// returned t > best.t in the reference's own fp32 Moller-Trumbore arithmetic -- so the closest
+// hit, its (t, u, v) and the tie rule are untouched and images stay bit-identical, while the
+// box / triangle COUNTERS drop below the reference's.  Children are pushed far first, near last.
+template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false>
 __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
 {
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
@@ -1006,6 +1051,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     RayPre pre;
     pre.ix = pre.iy = pre.iz = 0.0f;
     pre.flags = 8u;
+    float cull_ka = __builtin_inff(), cull_kb = __builtin_inff();      // CULL: per-segment constants of the distance bound
 
     const int drain_mark = max(ntiles - (int)(gridDim.x >> 1), 0);
     auto fetch_tile = [&]() -> int {
@@ -1087,20 +1133,42 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     const uint32_t pf = __float_as_uint(p3.z);
                     cnt.box += 2;                  // proper tree: both children exist
                     bool hl, hr;
+                    float tl = -PT_INF, tr = -PT_INF;       // CULL: entry distances (-INF: never culled)
                     if (((pre.flags & 8u) | pf) == 0u) {
-                        hl = ray_aabb_fast(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-                        hr = ray_aabb_fast(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
+                        if (CULL) {
+                            hl = ray_aabb_fast_t(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, tl);
+                            hr = ray_aabb_fast_t(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w, tr);
+                        } else {
+                            hl = ray_aabb_fast(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                            hr = ray_aabb_fast(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
+                        }
                     } else {
                         hl = ray_aabb_pre(o, d, pre, (pf & 1u) != 0u, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
                         hr = ray_aabb_pre(o, d, pre, (pf & 2u) != 0u, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
                     }
+                    uint32_t r1 = lref, r2 = rref;
+                    if (CULL) {
+                        // distance bound (see the kernel's header comment and DESIGN.md 3a)
+                        const uint32_t pe = __float_as_uint(p3.w);
+                        const float rc = fmaf(cull_ka, best.t, cull_kb);
+                        const float el = __uint_as_float(pe & 0xffff0000u), er = __uint_as_float(pe << 16);
+                        const bool cl = fmaf(-el, rc, tl * 0.999999523162841796875f) > best.t;
+                        const bool cr = fmaf(-er, rc, tr * 0.999999523162841796875f) > best.t;
+                        hl = hl && !cl;
+                        hr = hr && !cr;
+                        // far child first, near child last (popped first); leaves go to the leaf list anyway
+                        if (tl < tr) {
+                            r1 = rref; r2 = lref;
+                            const bool h = hl; hl = hr; hr = h;
+                        }
+                    }
                     // sp + nl <= 30 here (leaf_cap = 32 - worst-case stack, nl <= leaf_cap - 2), so slot sp
                     // and slot 31 - nl are both free: the stores are unconditional, the counts select
-                    const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
-                    stack[(ll ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = ll ? (lref & 0x7fffffffu) : lref;
+                    const bool ll = (r1 & PT_REF_LEAF) != 0u, rl = (r2 & PT_REF_LEAF) != 0u;
+                    stack[(ll ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = ll ? (r1 & 0x7fffffffu) : r1;
                     nl += (hl && ll) ? 1 : 0;
                     sp += (hl && !ll) ? 1 : 0;
-                    stack[(rl ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = rl ? (rref & 0x7fffffffu) : rref;
+                    stack[(rl ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = rl ? (r2 & 0x7fffffffu) : r2;
                     nl += (hr && rl) ? 1 : 0;
                     sp += (hr && !rl) ? 1 : 0;
                     if (sp == 0 && nl == 0) mode = M_SHADE;
@@ -1331,6 +1399,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             if (sc.nnodes != 0) {
                 pre = ray_prepare(o, d, sc.flags);
                 if (pre.flags & 8u) cnt.slow++;
+                if (CULL) cull_setup(d, pre, sc.cull_lmax, cull_ka, cull_kb);
                 cnt.box++;
                 if (ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
                     if (DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
@@ -1381,11 +1450,13 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     }
 }
 
-int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu)
+int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu, int num_cus)
 {
     const int ntiles = raytrace_grid_blocks(tile);
     if (waves_per_cu <= 0 || waves_per_cu > 24) waves_per_cu = 16;   // default 16: VGPR-limited, 4 waves per SIMD
-    const int resident = 256 * waves_per_cu;                          // <= PT_MAX_RESIDENT_WAVES
+    if (num_cus <= 0) num_cus = 256;
+    int resident = num_cus * waves_per_cu;                            // the device's own CU count (hipDeviceProp_t)
+    if (resident > PT_MAX_RESIDENT_WAVES) resident = PT_MAX_RESIDENT_WAVES;
     return ntiles < resident ? ntiles : resident;
 }
 
@@ -1402,8 +1473,11 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
     if (blocks <= 0) return;
     const dim3 block(64);
     if (variant >= 3) {
-        const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu));
-        if (variant == 3) {
+        const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu, L.num_cus));
+        if (variant == 9) {                              // deferred leaves + exact-image distance culling
+            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true>), grid, block, 0, s, L);
+            else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true>), grid, block, 0, s, L);
+        } else if (variant == 3) {
             if (fuse) hipLaunchKernelGGL((k_raytrace_persistent<true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_persistent<false>), grid, block, 0, s, L);
         } else if (variant == 6) {
@@ -1885,10 +1959,10 @@ __global__ void __launch_bounds__(64, MINW) k_walk_probe(const SceneRefs sc, con
 
 // returns 0 when the occupancy is not instantiated
 int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, uint32_t total, uint32_t *counter, float4 *out, int waves_per_simd,
-                      int lcap, int leaf_min, hipStream_t s)
+                      int lcap, int leaf_min, int num_cus, hipStream_t s)
 {
     const dim3 block(64);
-    const dim3 grid(256 * 4 * waves_per_simd);
+    const dim3 grid((num_cus > 0 ? num_cus : 256) * 4 * waves_per_simd);
     switch (waves_per_simd) {
     case 4: hipLaunchKernelGGL((k_walk_probe<4, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
     case 5: hipLaunchKernelGGL((k_walk_probe<5, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
@@ -1896,6 +1970,18 @@ int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, ui
     case 8: hipLaunchKernelGGL((k_walk_probe<8, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
     default: return 0;
     }
+}
+
+__global__ void __launch_bounds__(256) k_patch_cull(float4 *__restrict__ packets, const uint32_t *__restrict__ cull, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) packets[(size_t)i * 4 + 3].w = __uint_as_float(cull[i]);
+}
+
+void launch_patch_cull(float4 *packets, const uint32_t *cull, uint32_t npackets, hipStream_t s)
+{
+    if (npackets == 0) return;
+    hipLaunchKernelGGL(k_patch_cull, dim3((npackets + 255u) / 256u), dim3(256), 0, s, packets, cull, npackets);
 }
 
 void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s)

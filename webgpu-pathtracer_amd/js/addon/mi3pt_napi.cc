@@ -229,6 +229,7 @@ CTX_INT_FN(SetStorage, mi3pt_set_storage)
 CTX_INT_FN(SetKernelVariant, mi3pt_set_kernel_variant)
 CTX_INT_FN(EnableTiming, mi3pt_enable_timing)
 CTX_INT_FN(SetPipelining, mi3pt_set_pipelining)
+CTX_INT_FN(SetPresentMode, mi3pt_set_present_mode)
 CTX_INT_FN(SetEnvSampling, mi3pt_set_env_sampling)
 CTX_VOID_FN(Reset, mi3pt_reset)
 CTX_VOID_FN(Sync, mi3pt_sync)
@@ -515,7 +516,7 @@ napi_value Init(napi_env env, napi_value exports)
         { "sync", Sync }, { "flush", Flush }, { "readTexture", ReadTexture }, { "readCanvasRgba8", ReadCanvasRgba8 },
         { "enableTiming", EnableTiming }, { "passTimeUs", PassTimeUs }, { "getCounters", GetCounters },
         { "resetCounters", ResetCounters }, { "hostBuildBvhF64", HostBuildBvhF64 }, { "hostBuildBvh", HostBuildBvh },
-        { "hostEnvCdf", HostEnvCdf }, { "setPipelining", SetPipelining }, { "setEnvSampling", SetEnvSampling }, { "deviceBuildBvh", DeviceBuildBvh }, { "writeTexture", WriteTexture },
+        { "hostEnvCdf", HostEnvCdf }, { "setPipelining", SetPipelining }, { "setPresentMode", SetPresentMode }, { "setEnvSampling", SetEnvSampling }, { "deviceBuildBvh", DeviceBuildBvh }, { "writeTexture", WriteTexture },
         { "raytraceLaunchStats", RaytraceLaunchStats },
     };
     for (const auto &f : fns) {

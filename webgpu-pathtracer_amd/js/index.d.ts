@@ -77,6 +77,8 @@ export interface RendererOptions {
   device?: number;
   enableTimestampQuery?: boolean;
   presentEveryFrame?: boolean;
+  /** default true: draw the canvas once per launched batch instead of once per render() (headless) */
+  presentLatest?: boolean;
   verbose?: boolean;
   builderThreads?: number;
   /** build a linear BVH on the GPU instead of the reference's SAH tree (fast on huge meshes, same closest hits) */

@@ -30,8 +30,14 @@ class Renderer {
   constructor(args) {                                   // renderer.ts:47-92
     this.native = args.native;
     this.handle = args.handle;
-    this.options = Object.assign({ enableTimestampQuery: false, verbose: false, presentEveryFrame: true },
-      args.options || {});
+    // presentEveryFrame: encode the fullscreen pass on every render() like renderer.ts:386 (false: never).
+    // presentLatest (headless default): a sample frame that also presents is queued like any other and
+    // the canvas is drawn once per launched batch (MI3PT_PRESENT_LATEST); reading the canvas, or a
+    // render() after sampling has stopped, shows every frame.  false = the canvas is redrawn from this
+    // very frame on every render(), which costs one kernel launch per frame.
+    this.options = Object.assign({ enableTimestampQuery: false, verbose: false, presentEveryFrame: true,
+      presentLatest: true }, args.options || {});
+    this.native.setPresentMode(this.handle, this.options.presentLatest ? 1 : 0);
     this._width = 0;
     this._height = 0;
     this._frame = 1;

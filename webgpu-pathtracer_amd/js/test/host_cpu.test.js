@@ -91,7 +91,7 @@ assert.throws(() => r.update(empty, camera), /Input nodes array is empty/);
 
 // --- the real addon: loads, fails loudly without a device, host-side builder works
 const native = pt.loadNative();
-assert.strictEqual(native.abiVersion(), 1);
+assert.strictEqual(native.abiVersion(), 2);
 assert.strictEqual(native.tileLocalRows(70, 1, 3, 5), 25);
 assert.throws(() => native.hostBuildBvhF64(new Float64Array(0)), /Input nodes array is empty/);
 const nodes = native.hostBuildBvhF64(new Float64Array([0, 0, 0, 1, 0, 0, 0, 1, 0, 5, 5, 5, 6, 5, 5, 5, 6, 5]), 1);

@@ -17,6 +17,7 @@ PASS_RAYTRACE, PASS_ACCUMULATE, PASS_FULLSCREEN = 0, 1, 2
 SUBMIT_RAYTRACE, SUBMIT_ACCUMULATE, SUBMIT_FULLSCREEN = 1, 2, 4
 TEX_OUTPUT, TEX_ACCUMULATION, TEX_CANVAS = 0, 1, 2
 STORAGE_F32, STORAGE_F16 = 0, 1
+PRESENT_EXACT, PRESENT_LATEST = 0, 1
 COUNTER_NAMES = ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels", "reserved")
 
 # every symbol include/mi3pt.h declares; tests/test_capi_symbols.py checks the header
@@ -31,7 +32,7 @@ SYMBOLS = (
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
     "mi3pt_set_env_sampling", "mi3pt_debug_walk_probe", "mi3pt_device_build_bvh",
-    "mi3pt_set_pipelining", "mi3pt_flush",
+    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
 )
@@ -67,6 +68,7 @@ def load_library(path=None):
     lib.mi3pt_set_kernel_variant.argtypes = [c_void_p, c_int]
     lib.mi3pt_set_env_sampling.argtypes = [c_void_p, c_int]
     lib.mi3pt_set_pipelining.argtypes = [c_void_p, c_int]
+    lib.mi3pt_set_present_mode.argtypes = [c_void_p, c_int]
     for name in ("mi3pt_upload_triangles", "mi3pt_upload_materials", "mi3pt_upload_bvh"):
         getattr(lib, name).argtypes = [c_void_p, c_void_p, c_size_t]
     for name in ("mi3pt_upload_environment", "mi3pt_upload_environment_cdf"):
@@ -214,6 +216,9 @@ class Context:
 
     def set_pipelining(self, enabled):
         self._c(self.lib.mi3pt_set_pipelining(self.handle, int(enabled)))
+
+    def set_present_mode(self, mode):
+        self._c(self.lib.mi3pt_set_present_mode(self.handle, int(mode)))
 
     def set_tile(self, rank, nranks, block_rows=8):
         self._c(self.lib.mi3pt_set_tile(self.handle, rank, nranks, block_rows))

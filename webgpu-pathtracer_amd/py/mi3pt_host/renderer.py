@@ -175,8 +175,11 @@ class Renderer:
 
     def __init__(self, ctx, options=None):
         self.ctx = ctx
-        self.options = {"enableTimestampQuery": False}
+        # presentLatest (headless default): the canvas is drawn once per launched batch instead of once
+        # per render(); reading it, or a render() after sampling stopped, shows every frame
+        self.options = {"enableTimestampQuery": False, "presentLatest": True}
         self.options.update(options or {})
+        ctx.set_present_mode(capi.PRESENT_LATEST if self.options["presentLatest"] else capi.PRESENT_EXACT)
         self._width = self._height = 0
         self._frame = 1
         self._scalingFactor = 0.25
