@@ -183,6 +183,9 @@ int mi3pt_set_present_mode(mi3pt_ctx *ctx, int mode /* mi3pt_present_mode */);
  * mi3pt_flush does only that, without waiting -- use it before synchronising the stream
  * yourself (e.g. torch.cuda.synchronize()). */
 int mi3pt_flush(mi3pt_ctx *ctx);
+/* Frames one launch covers at the current size and tile split (the queue is launched by itself when
+ * it holds this many).  A caller that wants launches of one shape flushes at a divisor of its job. */
+int mi3pt_batch_capacity(mi3pt_ctx *ctx, int *frames);
 
 /* ---- read-back (the capability a headless drop-in needs; the reference only has
  * canvas.toDataURL, main.ts:351-356).  Blocking.  dst holds rows x width x 4 floats
@@ -211,6 +214,9 @@ int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds);
  * reset (HIP event pairs on the stream each kernel ran on), their number, and the frames
  * they covered.  Waits for the launches in flight. */
 int mi3pt_raytrace_launch_stats(mi3pt_ctx *ctx, int reset, double *total_ms, uint64_t *launches, uint64_t *frames);
+/* GPU-clock span from the start of the first to the end of the last of those launches.  Launches
+ * overlap at their tails, so span / launches (not total_ms / launches) is what a launch costs. */
+int mi3pt_raytrace_launch_span(mi3pt_ctx *ctx, double *span_ms);
 
 /* ---- counters (roofline inputs) ---- */
 int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT]);

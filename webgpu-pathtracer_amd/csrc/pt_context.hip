@@ -51,7 +51,7 @@ struct mi3pt_ctx {
     bool cull_enabled = true;       // MI3PT_CULL=0: variant 0 resolves to the reference-counter walk (7)
     bool cull_dirty = true;         // triangles or tree changed since the last analysis
     bool cull_ok = false;           // analysis done and the tree admits the walk
-    float cull_lmax = 0.0f;
+    float cull_ka = 0.0f, cull_kb = 0.0f;   // scene constants of the distance bound
     int num_cus = 256;              // hipDeviceProp_t::multiProcessorCount
 
     // textures
@@ -114,6 +114,8 @@ struct mi3pt_ctx {
     uint64_t rt_launches = 0, rt_frames = 0;
     int ev_rt_frames[2] = { 0, 0 };
     int ev_rt_newest = 0;                // parity of the most recent timed launch
+    hipEvent_t ev_span_start = nullptr;  // start of the first timed launch since the statistics were reset
+    bool span_started = false;
 
     // Presentation (mi3pt_set_present_mode).  EXACT: a submit that includes FULLSCREEN launches the
     // queue first, so the canvas shows this very frame (the reference's renderer.ts:379-390).
@@ -225,6 +227,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
         for (int j = 0; j < 2; j++) CREATE_TRY(hipEventCreate(&ctx->ev_rt[k][j]));
     for (int p = 0; p < 3; p++)
         for (int k = 0; k < 2; k++) CREATE_TRY(hipEventCreate(&ctx->ev[p][k]));
+    CREATE_TRY(hipEventCreate(&ctx->ev_span_start));
     if (const char *e = std::getenv("MI3PT_WALK_MIN")) ctx->walk_min = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_BATCH")) ctx->batch_max = std::atoi(e);
     if (ctx->batch_max < 1) ctx->batch_max = 1;
@@ -294,6 +297,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
         if (ctx->acc_done[k]) (void)hipEventDestroy(ctx->acc_done[k]);
     }
     if (ctx->main_mark) (void)hipEventDestroy(ctx->main_mark);
+    if (ctx->ev_span_start) (void)hipEventDestroy(ctx->ev_span_start);
     for (int k = 0; k < 2; k++)
         for (int j = 0; j < 2; j++)
             if (ctx->ev_rt[k][j]) (void)hipEventDestroy(ctx->ev_rt[k][j]);
@@ -707,7 +711,7 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.npackets = (uint32_t)ctx->npackets;
     s.root_ref = ctx->root_ref;
     s.flags = ctx->scene_flags;
-    s.cull_lmax = ctx->cull_lmax;
+    s.cull_ka = ctx->cull_ka; s.cull_kb = ctx->cull_kb;
     if (std::getenv("MI3PT_FORCE_SLOW_SLAB")) s.flags = 0;     // experiment knob: plain IEEE divisions
     s.env_w = MI3PT_ENV_WIDTH; s.env_h = MI3PT_ENV_HEIGHT;
     return s;
@@ -730,7 +734,7 @@ static int check_scene(const mi3pt_ctx *ctx)
 // over the triangles below that child -- the quantity the rounding error of the reference's
 // Moller-Trumbore code scales with -- and writes the two bounds, rounded up to 16 bits each, into
 // the node packet.  A child gets +infinity (never skipped) when something below it is outside
-// the analysis: a triangle with E > 2^-5 or with |e1| + |e2| above 16 x the scene's mean (such
+// the analysis: a triangle with E > 2^-3 or with |e1| + |e2| above 16 x the scene's mean (such
 // triangles would loosen the bound for every other one), a non-finite coordinate, or a box that
 // does not contain what is below it (the walk bounds distances by boxes; the reference does not
 // care whether its boxes bound anything).  Runs when the triangles or the tree changed, on the
@@ -783,11 +787,11 @@ static int prepare_cull(mi3pt_ctx *ctx)
         if (Ls == Ls && Ls < 1e30) { mean_l += Ls; counted++; }
     }
     mean_l = counted ? mean_l / (double)counted : 0.0;
-    const double lcap = 16.0 * mean_l, ecap = 0.03125;
+    const double lcap = 16.0 * mean_l, ecap = 0.125;
 
     std::vector<float> emax(n, 0.0f);       // +inf = never skip
     const float inf = __builtin_inff();
-    double lmax = 0.0;
+    double lmax = 0.0, eglob = 0.0;
     auto inside = [&](const uint8_t *outer, const float mn[3], const float mx[3]) {
         for (int k = 0; k < 3; k++)
             if (!(ldf(outer, 4 * k) <= mn[k] && ldf(outer, 16 + 4 * k) >= mx[k])) return false;     // false for NaNs too
@@ -809,6 +813,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
                 emax[i] = (float)(E * (1.0 + 1e-6));
                 if ((double)emax[i] < E) emax[i] = std::nextafter(emax[i], inf);
                 if (Ls > lmax) lmax = Ls;
+                if (E > eglob) eglob = E;
             } else {
                 emax[i] = inf;
             }
@@ -849,9 +854,22 @@ static int prepare_cull(mi3pt_ctx *ctx)
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_cull);
     if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("cull analysis: ") + hipGetErrorString(e));
-    float lm = (float)(lmax * (1.0 + 1e-6));
-    if ((double)lm < lmax) lm = std::nextafter(lm, inf);
-    ctx->cull_lmax = lm;
+    // Constants of the bound, for the largest E and L the packets admit.  u = 2^-24;
+    // kappa_max = E_max |d|_max / EPSILON with |d| <= dn <= 2 (cull_setup) and EPSILON = fp32(1e-6).
+    {
+        const double u = std::ldexp(1.0, -24), inv_eps = 1.0 / (double)1e-6f;
+        const double kmax = eglob * 2.0 * inv_eps;
+        const double A = 5.85 * u * kmax;                       // relative error of one Cramer quotient
+        const double br = (1.0 + A) / (1.0 - A) + 1.0;
+        const double cs = 5.85 * 2.0 * br + 1.01;               // coefficient of |o - a|
+        const double cl = 5.85 * br + 2.2 * br + 2.0 + cs;      // coefficient of L
+        const double den = 1.0 - cs * u * kmax;
+        if (!(A < 0.25) || !(den > 0.5)) return pt_set_error(MI3PT_ERR_STATE, "cull analysis: E cap outside the analysis");
+        const double c1 = (cs + 2.01) / den, c2 = cl / den;
+        const double ka = c1 * u * inv_eps * 1.001, kb = c2 * u * inv_eps * lmax * 1.001;
+        ctx->cull_ka = std::nextafter((float)ka, inf);
+        ctx->cull_kb = std::nextafter((float)kb, inf);
+    }
     ctx->cull_ok = true;
     ctx->cull_dirty = false;
     ctx->main_dirty = true;
@@ -1020,7 +1038,10 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame &first, in
             L.drain_seq = ++ctx->launch_seq;
         }
     }
-    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev_rt[par][0], rs));
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev_rt[par][0], rs));
+        if (!ctx->span_started) { HIP_TRY(hipEventRecord(ctx->ev_span_start, rs)); ctx->span_started = true; }
+    }
     pt::launch_raytrace(L, false, pick_variant(ctx), rs);
     if (hipError_t e = hipGetLastError()) {
         // The kernel that would have published drain_seq never ran: publish it from the host side
@@ -1190,6 +1211,14 @@ static int settle_canvas(mi3pt_ctx *ctx)
 
 extern "C" int mi3pt_flush(mi3pt_ctx *ctx) { return require_idle(ctx); }
 
+extern "C" int mi3pt_batch_capacity(mi3pt_ctx *ctx, int *frames)
+{
+    if (!ctx || !frames) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "no textures before resize");
+    *frames = ctx->pipeline ? ctx->batch_cap : 1;
+    return MI3PT_OK;
+}
+
 extern "C" int mi3pt_sync(mi3pt_ctx *ctx)
 {
     if (int rc = require_idle(ctx)) return rc;
@@ -1330,7 +1359,28 @@ extern "C" int mi3pt_raytrace_launch_stats(mi3pt_ctx *ctx, int reset, double *to
     if (total_ms) *total_ms = ctx->rt_total_ms;
     if (launches) *launches = ctx->rt_launches;
     if (frames) *frames = ctx->rt_frames;
-    if (reset) { ctx->rt_total_ms = 0.0; ctx->rt_launches = 0; ctx->rt_frames = 0; }
+    if (reset) { ctx->rt_total_ms = 0.0; ctx->rt_launches = 0; ctx->rt_frames = 0; ctx->span_started = false; }
+    return MI3PT_OK;
+}
+
+// Wall-clock span of the batched raytrace launches since the last reset of the launch statistics:
+// from the start of the first to the end of the last, on the GPU's clock.  Consecutive launches
+// overlap at their tails (the next one starts while the last paths of this one drain), so the
+// sum of the per-launch durations exceeds this; span / launches is the non-overlapped time a
+// launch costs.
+extern "C" int mi3pt_raytrace_launch_span(mi3pt_ctx *ctx, double *span_ms)
+{
+    if (int rc = require_idle(ctx)) return rc;
+    if (!span_ms) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    *span_ms = 0.0;
+    if (!ctx->span_started) return MI3PT_OK;
+    for (int par = 0; par < 2; par++) {
+        if (!ctx->ev_rt_frames[par]) continue;              // this parity never ran a timed launch
+        HIP_TRY(hipEventSynchronize(ctx->ev_rt[par][1]));
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->ev_span_start, ctx->ev_rt[par][1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if ((double)ms > *span_ms) *span_ms = ms;
+    }
     return MI3PT_OK;
 }
 

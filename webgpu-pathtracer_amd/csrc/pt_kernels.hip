@@ -197,17 +197,17 @@ PT_DEV bool ray_aabb_fast(const f3 &o, const f3 &d, const RayPre &p, float mnx, 
     return !(tmin > tmax) && (tmax >= fmaxf(0.0f, tmin));
 }
 
-// ray_aabb_fast() that also hands out the entry distance tmin (CULL walk: ordering and the
-// distance bound; the hit predicate is the same expression)
+// ray_aabb_fast() that also hands out the per-axis entry distances min(t1, t2) (CULL walk: the
+// distance bound and the near-first ordering; the hit predicate is the same expression)
 PT_DEV bool ray_aabb_fast_t(const f3 &o, const f3 &d, const RayPre &p, float mnx, float mny, float mnz,
-                            float mxx, float mxy, float mxz, float &tmin_out)
+                            float mxx, float mxy, float mxz, f3 &tnear)
 {
     const float ax = div_pre(mnx - o.x, d.x, p.ix), bx = div_pre(mxx - o.x, d.x, p.ix);
     const float ay = div_pre(mny - o.y, d.y, p.iy), by = div_pre(mxy - o.y, d.y, p.iy);
     const float az = div_pre(mnz - o.z, d.z, p.iz), bz = div_pre(mxz - o.z, d.z, p.iz);
-    const float tmin = fmaxf(fmaxf(fmaxf(-PT_INF, fminf(ax, bx)), fminf(ay, by)), fminf(az, bz));
+    tnear = F3(fminf(ax, bx), fminf(ay, by), fminf(az, bz));
+    const float tmin = fmaxf(fmaxf(fmaxf(-PT_INF, tnear.x), tnear.y), tnear.z);
     const float tmax = fminf(fminf(fminf(PT_INF, fmaxf(ax, bx)), fmaxf(ay, by)), fmaxf(az, bz));
-    tmin_out = tmin;
     return !(tmin > tmax) && (tmax >= fmaxf(0.0f, tmin));
 }
 
@@ -910,23 +910,21 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
 enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
 
 // Per-segment constants of the CULL walk's distance bound.  For a triangle with
-// E = |e1| |e2| <= 2^-5 and L = |e1| + |e2| <= lmax that the reference's Moller-Trumbore code
-// accepts with t <= best.t, the point o + t d lies within
-//     delta = 2^-24 * kappa * (32 best.t |d| + 52 L),   kappa = E |d| / |det| <= E |d| / EPSILON
-// of the triangle, hence of every box that holds it; along the ray that is at most
-// delta * max_i |1 / d_i|.  With dn = |dx| + |dy| + |dz| >= |d|:
-//     margin(E, best.t) = E * (Ka * best.t + Kb),  Ka = 32 u 1e6 dn^2 dinv,  Kb = 52 u 1e6 dn dinv lmax
-// (u = 2^-24; both rounded up by 1.001 for the handful of roundings in forming them).  Rays the
-// analysis does not cover (a plain-division ray, dn > 2, non-finite) get Ka = Kb = +infinity: no culling (a child that
-// must never be skipped carries E = +infinity).
-PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float lmax, float &ka, float &kb)
+// E = |e1| |e2| and L = |e1| + |e2| that the reference's Moller-Trumbore code accepts with
+// t <= best.t, the point o + t d lies within
+//     delta = u kappa (c1 best.t |d| + c2 L),   kappa = E |d| / |det| <= E |d| / EPSILON,  u = 2^-24
+// of the triangle, hence of every box that holds it.  The context folds c1 u / EPSILON and
+// c2 u L_max / EPSILON (c1 ~ 26.4, c2 ~ 42.5 for small triangles, larger when the scene admits
+// bigger ones; both rounded up) into SceneRefs::cull_ka / cull_kb; with dn = |dx| + |dy| + |dz| >= |d|
+//     delta <= E * (Ka * best.t + Kb),   Ka = cull_ka dn^2,   Kb = cull_kb dn.
+// Rays the analysis does not cover (a plain-division ray, dn > 2, non-finite) get Ka = Kb =
+// +infinity: nothing is skipped (a child that must never be skipped carries E = +infinity).
+PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float scene_kb, float &ka, float &kb)
 {
     const float dn = (fabsf(d.x) + fabsf(d.y)) + fabsf(d.z);
-    const float dinv = fmaxf(fmaxf(fabsf(pre.ix), fabsf(pre.iy)), fabsf(pre.iz));
-    const float g = dn * dinv;
     const bool ok = (pre.flags & 8u) == 0u && dn <= 2.0f;
-    ka = ok ? 1.90926f * (dn * g) : __builtin_inff();
-    kb = ok ? 3.10254f * (g * lmax) : __builtin_inff();
+    ka = ok ? scene_ka * (dn * dn) : __builtin_inff();
+    kb = ok ? scene_kb * dn : __builtin_inff();
 }
 
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
@@ -943,8 +941,9 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float lmax, float &ka, fl
 //
 // CULL (kernel variant 9, needs DEFER): exact-image distance culling.  The reference walk has no
 // upper bound by the current hit (raytrace.wgsl:118-152, 154-203): it tests every box the ray
-// touches.  A child whose box the ray enters at tmin is skipped here when
-//     tmin * (1 - 2^-21)  -  E * (Ka * best.t + Kb)  >  best.t
+// touches.  A child whose box the ray enters at tmin is skipped here when, in essence,
+//     tmin  -  E * (Ka * best.t + Kb)  >  best.t
+// (on every axis i: tnear_i - E (Ka best.t + Kb) / |d_i| > best.t (1 + 2^-20) skips the child)
 // where E (packet, 16 bits per child, rounded up) bounds |e1| * |e2| over the triangles below the
 // child and Ka, Kb are per-segment constants of the ray (cull_setup).  DESIGN.md section 3a proves
 // that every triangle below such a child, had it been tested, would have been rejected or have
@@ -1133,11 +1132,11 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     const uint32_t pf = __float_as_uint(p3.z);
                     cnt.box += 2;                  // proper tree: both children exist
                     bool hl, hr;
-                    float tl = -PT_INF, tr = -PT_INF;       // CULL: entry distances (-INF: never culled)
+                    f3 nl3 = F3(-PT_INF, -PT_INF, -PT_INF), nr3 = nl3;       // CULL: per-axis entry distances (-INF: never skipped)
                     if (((pre.flags & 8u) | pf) == 0u) {
                         if (CULL) {
-                            hl = ray_aabb_fast_t(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, tl);
-                            hr = ray_aabb_fast_t(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w, tr);
+                            hl = ray_aabb_fast_t(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, nl3);
+                            hr = ray_aabb_fast_t(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w, nr3);
                         } else {
                             hl = ray_aabb_fast(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
                             hr = ray_aabb_fast(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
@@ -1148,16 +1147,19 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     }
                     uint32_t r1 = lref, r2 = rref;
                     if (CULL) {
-                        // distance bound (see the kernel's header comment and DESIGN.md 3a)
+                        // distance bound (see the kernel's header comment and DESIGN.md 3a): a hit below this
+                        // child lies within delta of its box, so on EVERY axis it is at least
+                        // tnear_i - delta / |d_i| away; skip when that exceeds the closest hit so far
                         const uint32_t pe = __float_as_uint(p3.w);
                         const float rc = fmaf(cull_ka, best.t, cull_kb);
-                        const float el = __uint_as_float(pe & 0xffff0000u), er = __uint_as_float(pe << 16);
-                        const bool cl = fmaf(-el, rc, tl * 0.999999523162841796875f) > best.t;
-                        const bool cr = fmaf(-er, rc, tr * 0.999999523162841796875f) > best.t;
-                        hl = hl && !cl;
-                        hr = hr && !cr;
+                        const float dl = __uint_as_float(pe & 0xffff0000u) * rc, dr = __uint_as_float(pe << 16) * rc;
+                        const float bt = best.t * 1.00000095367431640625f;       // 1 + 2^-20: the roundings of tnear and of the fma
+                        const float tl = fmaxf(fmaxf(fmaf(-dl, fabsf(pre.ix), nl3.x), fmaf(-dl, fabsf(pre.iy), nl3.y)), fmaf(-dl, fabsf(pre.iz), nl3.z));
+                        const float tr = fmaxf(fmaxf(fmaf(-dr, fabsf(pre.ix), nr3.x), fmaf(-dr, fabsf(pre.iy), nr3.y)), fmaf(-dr, fabsf(pre.iz), nr3.z));
+                        hl = hl && !(tl > bt);
+                        hr = hr && !(tr > bt);
                         // far child first, near child last (popped first); leaves go to the leaf list anyway
-                        if (tl < tr) {
+                        if (fmaxf(fmaxf(nl3.x, nl3.y), nl3.z) < fmaxf(fmaxf(nr3.x, nr3.y), nr3.z)) {
                             r1 = rref; r2 = lref;
                             const bool h = hl; hl = hr; hr = h;
                         }
@@ -1399,7 +1401,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             if (sc.nnodes != 0) {
                 pre = ray_prepare(o, d, sc.flags);
                 if (pre.flags & 8u) cnt.slow++;
-                if (CULL) cull_setup(d, pre, sc.cull_lmax, cull_ka, cull_kb);
+                if (CULL) cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
                 cnt.box++;
                 if (ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
                     if (DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene

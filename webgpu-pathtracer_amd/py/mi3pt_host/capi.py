@@ -32,7 +32,7 @@ SYMBOLS = (
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
     "mi3pt_set_env_sampling", "mi3pt_debug_walk_probe", "mi3pt_device_build_bvh",
-    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode",
+    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
 )
@@ -88,6 +88,8 @@ def load_library(path=None):
     lib.mi3pt_pass_time_us.argtypes = [c_void_p, c_int, ctypes.POINTER(ctypes.c_float)]
     lib.mi3pt_raytrace_launch_stats.argtypes = [c_void_p, c_int, ctypes.POINTER(ctypes.c_double),
                                                 ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.mi3pt_raytrace_launch_span.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
+    lib.mi3pt_batch_capacity.argtypes = [c_void_p, ctypes.POINTER(c_int)]
     lib.mi3pt_get_counters.argtypes = [c_void_p, c_void_p]
     lib.mi3pt_reset_counters.argtypes = [c_void_p]
     lib.mi3pt_debug_intersect.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
@@ -304,6 +306,17 @@ class Context:
         self._c(self.lib.mi3pt_raytrace_launch_stats(self.handle, int(reset), ctypes.byref(ms), ctypes.byref(n),
                                                      ctypes.byref(f)))
         return ms.value, n.value, f.value
+
+    def batch_capacity(self):
+        n = ctypes.c_int()
+        self._c(self.lib.mi3pt_batch_capacity(self.handle, ctypes.byref(n)))
+        return n.value
+
+    def raytrace_launch_span(self):
+        """GPU-clock ms from the start of the first to the end of the last batched launch since the reset."""
+        ms = ctypes.c_double()
+        self._c(self.lib.mi3pt_raytrace_launch_span(self.handle, ctypes.byref(ms)))
+        return ms.value
 
     def counters(self):
         out = np.zeros(8, np.uint64)
