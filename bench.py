@@ -1,34 +1,47 @@
 #!/usr/bin/env python3
 """Benchmark of the per-pixel ray-trace path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload demo|dragon]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dragon|demo] [--scaling strong|weak]
 
-One STEP = one Renderer.render() frame of the hot path (raytrace + accumulate passes, 1
-sample per pixel, whole image).  The library queues consecutive frames and launches them in
-batches (bit-identical results); the timed region ends with a flush + device sync.  Default workload = BASELINE.json
-configs[1]: default demo mesh + environment map, 1920x1080, 8 bounces, 64 frames
-(= 64 spp); `--workload dragon` is configs[2] (~870k triangles).
+One STEP = one Renderer.render() frame of the hot path (raytrace + accumulate passes, 1 sample
+per pixel, whole image, 8 bounces).  The library queues consecutive frames and launches them in
+batches (bit-identical results); the timed region ends with a flush + device sync.
 
-N > 1 (launched by torch.distributed.run, one process per GPU): image tiles are dealt to
-the ranks in 8-row blocks, the scene is replicated, there is NO per-frame communication,
-and the job ends with one RCCL gather of the HDR accumulation buffers to rank 0
-(inside the timed region).  Weak scaling: the image grows with N so every GPU always
-renders 1920x1080 pixels per frame (N=2: 1920x2160, N=4: 3840x2160, N=8: 3840x4320);
-`--scaling strong` keeps 1920x1080 and splits it instead.
+Headline workload (default) = the scene BASELINE.json's target is quoted on: the dragon-class
+~870k-triangle mesh + environment map at 1920x1080 (configs[2]); `--workload demo` is
+configs[1] (default demo mesh, 1,998 triangles) and is also measured, shorter, as `also.demo`.
 
-Prints ONE JSON line on rank 0: metric Mrays/s (rays = raySceneIntersect calls, counted
-exactly by the kernel), plus
-  roofline     : algorithmic bytes per launch / average launch duration of the dominant
-                 kernel (HIP event pairs on the stream each launch ran on, all launches of
-                 the timed region) against the 8 TB/s HBM peak,
-  cpu_baseline : the CPU oracle timed on a bounded sample of the same workload
-                 (rank 0, N = 1 only).
+N > 1 (launched by torch.distributed.run, one process per GPU): image tiles are dealt to the
+ranks in 8-row blocks, the scene is replicated, there is NO per-frame communication, and the job
+ends with one RCCL gather of the HDR accumulation buffers to rank 0 (inside the timed region).
+Default `--scaling strong`: the metric is Mrays/s AT 1920x1080, so the one 1080p image is split
+N ways.  `--scaling weak` grows the image with N instead (N=2: 1920x2160, N=4: 3840x2160,
+N=8: 3840x4320) so that every GPU always renders 1920x1080 pixels per frame.
+
+Prints ONE JSON line on rank 0: metric Mrays/s (rays = raySceneIntersect calls, counted exactly
+by the kernel), plus
+  roofline     : the dominant kernel (the persistent raytrace kernel) against the HBM peak --
+                 `traffic` = HBM-side bytes per launch from rocprofv3 PMC passes of THIS command
+                 line (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md), run
+                 as child processes after the timed job; `achieved` = traffic / the kernel's
+                 average launch duration (HIP event pairs on the stream each launch ran on);
+                 `frac` = achieved / 8 TB/s.  The kernel is NOT HBM-bound:
+                 `real_bound`, `valu_issue_frac` and `lane_utilisation` (SQ counters, one more
+                 pass) say what it is bound by; the algorithmic byte rate SURVEY.md 8(d) defines
+                 is kept beside it as `algorithmic_GBps` (it is served by L1/L2 and may exceed the
+                 HBM peak -- it is not a roofline fraction).
+  cpu_baseline : the CPU oracle timed on a bounded sample of the same workload (rank 0, N = 1).
 The oracle is only ever the baseline / checker here, never the thing measured as `value`.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -38,7 +51,14 @@ for p in (os.path.join(ROOT, "webgpu-pathtracer_amd", "py"), os.path.join(ROOT, 
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0     # same guide: what a streaming kernel reaches
+SHADER_CLOCK_HZ = 2.4e9         # peak engine clock used for the VALU issue rate
 BLOCK_ROWS = 8
+BOUNCES = 8
+KERNEL_NEEDLE = "k_raytrace_sm"
+# counter groups of the PMC passes: one rocprofv3 run each (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
+               "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"))
 
 
 def image_size(n_gpus, scaling):
@@ -50,49 +70,97 @@ def image_size(n_gpus, scaling):
 
 def build_scene(workload):
     from mi3pt_host import scenes
-    if workload == "dragon":
-        sc = scenes.dragon_class_scene()
-    else:
-        sc = scenes.demo_scene()
+    sc = scenes.dragon_class_scene() if workload == "dragon" else scenes.demo_scene()
     sc.build_bvh()
     return sc, scenes.synthetic_env()
 
 
+def workload_name(workload, sc):
+    return ("default demo mesh (1,998 triangles) + synthetic env map" if workload == "demo"
+            else f"dragon-class procedural mesh ({len(sc.triangles)} triangles) + synthetic env map")
+
+
 def algorithmic_bytes(c):
-    """SURVEY.md 8(d) / BASELINE.md: bytes in the reference's own layouts, each touched
-    record counted once: 48 B per box test, 112 B per triangle test, one 64-B material
-    per hit, four 16-B env texels per miss, 16+16 B accumulator read-modify-write."""
+    """SURVEY.md 8(d) / BASELINE.md: bytes in the reference's own layouts, each touched record
+    counted once: 48 B per box test, 112 B per triangle test, one 64-B material per hit, four
+    16-B env texels per miss, 16+16 B accumulator read-modify-write.  The counters are the
+    kernel's own: the shipped walk skips boxes behind the closest hit, so this is below what
+    the reference's walk would touch for the same image."""
     return 48 * c["box_tests"] + 112 * c["tri_tests"] + 64 * c["hits"] + 64 * c["misses"] + 32 * c["pixels"]
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (separate runs,
-    see profiles/pmc_passes.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    16-B-per-lane reads, WRITE_SIZE as is).  Collected offline and committed as
-    profiles/traffic.json; null when no measurement exists for the workload."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(path) as f:
-            entry = json.load(f).get(workload)
-        return int(entry["hbm_bytes_per_launch"]) if entry else None
-    except (OSError, ValueError, KeyError):
-        return None
+def frames_per_launch(steps, cap):
+    """Launches of ONE shape inside the timed region: the largest divisor-like split of the job
+    that fits the library's batch capacity (20 steps, capacity 16 -> 2 launches of 10)."""
+    if steps <= 0:
+        return 1
+    launches = -(-steps // max(cap, 1))
+    return -(-steps // launches)
 
 
-def cpu_baseline(sc, env, un_bytes_for_frame, width, height, budget_s=12.0):
-    """Time the CPU oracle on interleaved 1/32 shards of the same frames until the
-    budget is used.  kind = "port": the oracle is a restatement, not the reference."""
+class Job:
+    """Scene + context + the frame loop, shared by the timed run and the PMC child runs."""
+
+    def __init__(self, workload, width, height, rank=0, world=1, device=0, variant=0, stream_ptr=None):
+        from mi3pt_host import capi, layout
+        self.capi, self.layout = capi, layout
+        self.workload, self.width, self.height = workload, width, height
+        self.sc, self.env = build_scene(workload)
+        self.ctx = capi.Context(device)
+        if stream_ptr is not None:
+            self.ctx.set_stream(stream_ptr)
+        self.ctx.set_kernel_variant(variant)
+        self.ctx.enable_timing(True)            # one HIP event pair per batched raytrace launch
+        self.ctx.upload_bvh(self.sc.nodes)
+        self.ctx.upload_triangles(self.sc.triangles)
+        self.ctx.upload_materials(self.sc.material_bytes)
+        self.ctx.upload_environment(self.env)
+        self.ctx.set_tile(rank, world, BLOCK_ROWS)
+        self.ctx.resize(width, height)
+        self.frame = 2
+
+    def rt_uniforms(self, frame):
+        sc = self.sc
+        u = self.layout.UniformBlock(self.layout.RAYTRACE_UNIFORMS)
+        u.set({"resolution": [self.width, self.height], "aspect": self.width / self.height, "frame": frame,
+               "maxBounces": BOUNCES, "samplesPerFrame": 1,
+               "camera": {"position": sc.camera["position"], "direction": sc.camera_direction(),
+                          "fov": sc.camera["fov"], "focalDistance": sc.camera["focalDistance"],
+                          "aperture": sc.camera["aperture"]},
+               "envMapIntensity": 1.0, "envMapRotation": 0.0})
+        return u.tobytes()
+
+    def acc_uniforms(self, frame):
+        u = self.layout.UniformBlock(self.layout.ACCUMULATE_UNIFORMS)
+        u.set({"resolution": [self.width, self.height], "frame": frame, "enabled": 1})
+        return u.tobytes()
+
+    def frames(self, n, per_launch):
+        """Queue n consecutive frames, launching every `per_launch` (no host wait)."""
+        capi, ctx = self.capi, self.ctx
+        for i in range(n):
+            ctx.set_uniforms(capi.PASS_RAYTRACE, self.rt_uniforms(self.frame))
+            ctx.set_uniforms(capi.PASS_ACCUMULATE, self.acc_uniforms(self.frame))
+            ctx.submit(capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+            self.frame += 1
+            if (i + 1) % per_launch == 0:
+                ctx.flush()
+        ctx.flush()
+
+
+def cpu_baseline(job, budget_s=12.0):
+    """Time the CPU oracle on interleaved 1/8 shards of the same frames until the budget is
+    used.  kind = "port": the oracle is a restatement, not the reference."""
     import pt_oracle as orc
-    osc = orc.OracleScene(sc.triangles, sc.material_bytes, sc.nodes, env)
+    sc = job.sc
+    osc = orc.OracleScene(sc.triangles, sc.material_bytes, sc.nodes, job.env)
     cores = os.cpu_count() or 1
     shards = 8
-    rays = 0
-    pixels = 0
-    n = 0
+    rays = pixels = n = 0
     t0 = time.perf_counter()
     while True:
         frame = 2 + n // shards
-        _, cnt = orc.raytrace(osc, un_bytes_for_frame(frame), width, height, n % shards, shards, BLOCK_ROWS)
+        _, cnt = orc.raytrace(osc, job.rt_uniforms(frame), job.width, job.height, n % shards, shards, BLOCK_ROWS)
         rays += cnt["rays"]
         pixels += cnt["pixels"]
         n += 1
@@ -100,27 +168,149 @@ def cpu_baseline(sc, env, un_bytes_for_frame, width, height, budget_s=12.0):
         if dt >= budget_s or n >= shards * 512:
             break
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{n} interleaved 1/{shards}-image shards of the same {width}x{height} 8-bounce frames "
-                      f"({pixels} pixel jobs, {rays} rays, {dt:.1f} s, OpenMP over {cores} threads)"}
+            "sample": f"{n} interleaved 1/{shards}-image shards of the same {job.width}x{job.height} {BOUNCES}-bounce "
+                      f"frames of the {job.workload} workload ({pixels} pixel jobs, {rays} rays, {dt:.1f} s, "
+                      f"OpenMP over {cores} threads; the oracle runs the reference's walk, without distance culling)"}
+
+
+# ------------------------------------------------------------------------------------------
+# PMC passes: this same command line re-run under `rocprofv3 --pmc` as child processes
+# ------------------------------------------------------------------------------------------
+
+def under_profiler():
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or any(k.startswith("ROCPROF") for k in os.environ)
+
+
+def inner_pmc(args):
+    """Child mode: the job alone (no torch, no baseline, no output), for a counter pass."""
+    width, height = image_size(1, args.scaling)
+    if args.image:
+        width, height = (int(v) for v in args.image.lower().split("x"))
+    job = Job(args.workload, width, height, variant=args.variant)
+    per_launch = frames_per_launch(args.steps, job.ctx.batch_capacity())
+    job.frames(args.warmup, per_launch)
+    job.ctx.sync()
+    job.frames(args.steps, per_launch)
+    job.ctx.sync()
+    job.ctx.close()
+
+
+def collect_pmc(args, timed_launches, log):
+    """Runs the PMC passes; returns {counter: mean per timed launch} (the last `timed_launches`
+    dispatches of the raytrace kernel in each pass are the timed ones) or {} when unavailable."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof) or timed_launches <= 0:
+        return {}
+    out = {}
+    base = tempfile.mkdtemp(prefix="mi3pt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            d = os.path.join(base, f"pass{i}")
+            cmd = [rocprof, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--inner-pmc", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                   "--workload", args.workload, "--scaling", args.scaling, "--variant", str(args.variant)]
+            if args.image:
+                cmd += ["--image", args.image]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            except (subprocess.TimeoutExpired, OSError) as e:
+                log.append(f"pmc pass {counters}: {type(e).__name__}")
+                break                   # a pass that had to be killed: start nothing else on this GPU
+            if r.returncode != 0:
+                log.append(f"pmc pass {counters}: rc {r.returncode}: {r.stdout.decode(errors='replace')[-300:]}")
+                continue
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if KERNEL_NEEDLE in row["Kernel_Name"]:
+                            per.setdefault(row["Counter_Name"], []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+            for name, rows in per.items():
+                rows.sort()
+                vals = [v for _, v in rows[-timed_launches:]]
+                if vals:
+                    out[name] = sum(vals) / len(vals)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    return out
+
+
+def traffic_from_file(key):
+    """Fallback when no live PMC pass is possible (under a profiler, N > 1, rocprofv3 missing):
+    the committed measurement for exactly this launch shape, else nothing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            for e in json.load(f).get("entries", []):
+                if all(e.get(k) == v for k, v in key.items()):
+                    return e
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def roofline_block(m, pmc, source, num_cus):
+    """m: measurements of the timed run (see measure()); pmc: counter means per timed launch."""
+    kernel_ms = m["kernel_ms"]
+    alg_per_launch = algorithmic_bytes(m["counters"]) / max(m["launches"], 1)
+    alg_gbps = alg_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+    traffic = None
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
+    achieved = traffic / (kernel_ms * 1e-3) / 1e9 if traffic is not None and kernel_ms > 0 else None
+    block = {
+        "bound": "hbm", "achieved": round(achieved, 1) if achieved is not None else None, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved is not None else None,
+        "traffic": traffic, "traffic_source": source,
+        "traffic_rule": "(2 x FETCH_SIZE + WRITE_SIZE) KB per launch, separate rocprofv3 --pmc passes, mean over the timed launches "
+                        "(MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B); L2-to-fabric bytes, Infinity-Cache hits included",
+        "kernel": m["kernel"], "kernel_ms": round(kernel_ms, 4), "kernel_ms_exclusive": round(m["kernel_ms_exclusive"], 4),
+        "launches_timed": m["launches"], "frames_per_launch": m["frames_per_launch"],
+        "peak_achievable": HBM_ACHIEVABLE_GBS,
+        "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4) if achieved is not None else None,
+        # what SURVEY.md 8(d) calls the achieved figure: bytes the algorithm touches (in the reference's layouts, from the
+        # kernel's own counters) per second.  Served by L1 / L2 / Infinity Cache: not comparable with an HBM peak.
+        "algorithmic_bytes_per_launch": int(alg_per_launch),
+        "algorithmic_GBps": round(alg_gbps, 1) if alg_gbps is not None else None,
+        "bytes_per_ray": round(algorithmic_bytes(m["counters"]) / max(m["counters"]["rays"], 1), 1),
+        "box_tests_per_ray": round(m["counters"]["box_tests"] / max(m["counters"]["rays"], 1), 2),
+        "tri_tests_per_ray": round(m["counters"]["tri_tests"] / max(m["counters"]["rays"], 1), 2),
+    }
+    if "SQ_INSTS_VALU" in pmc and kernel_ms > 0:
+        issue_peak = num_cus * 4 * SHADER_CLOCK_HZ / 2.0          # wave64 VALU instructions per second, all SIMDs
+        block["valu_issue_frac"] = round(pmc["SQ_INSTS_VALU"] / (kernel_ms * 1e-3) / issue_peak, 4)
+        block["valu_insts_per_launch"] = int(pmc["SQ_INSTS_VALU"])
+        if pmc.get("SQ_ACTIVE_INST_VALU"):
+            block["lane_utilisation"] = round(pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]), 4)
+        if pmc.get("SQ_WAVE_CYCLES"):
+            wc = pmc["SQ_WAVE_CYCLES"]
+            block["wave_cycles"] = {"issuing": round(pmc.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3),
+                                    "waiting_for_memory": round(pmc.get("SQ_WAIT_ANY", 0.0) / wc, 3),
+                                    "issue_stalled": round(pmc.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3)}
+        block["real_bound"] = ("per-wave latency: dependent VALU chains + divergent 64-B gathers at 4 waves per SIMD; "
+                               "VALU issue x lane utilisation is the fraction of the machine's lane-op rate in use")
+    return block
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)     # one full 16-frame batch: every launch a profiler sees has the timed shape
-    ap.add_argument("--workload", default="demo", choices=["demo", "dragon"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--warmup", type=int, default=16)     # one full batch: every launch a profiler sees has the timed shape
+    ap.add_argument("--workload", default="dragon", choices=["demo", "dragon"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (children of this process)")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary (demo scene) measurement")
     ap.add_argument("--image", default=None, help="WxH override (experiments only)")
+    ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    import __graft_entry__ as ge
-    from mi3pt_host import capi, layout
+    if args.inner_pmc:
+        inner_pmc(args)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,6 +319,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
+
+    # Build (make / g++ children) BEFORE anything touches the GPU; the other ranks meet rank 0 at
+    # the process-group rendezvous below, i.e. after the build.
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+
+    import torch
+    import torch.distributed as dist
+    from mi3pt_host import capi
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     # Rehearsal mode (one GPU box): MI3PT_BENCH_REHEARSAL=1 puts every rank on device 0 and
@@ -143,163 +344,153 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if rank == 0:
-        ge.build()
-    if world > 1:
         dist.barrier()
+    capi.load_library()
 
     width, height = image_size(world, args.scaling)
     if args.image:
         width, height = (int(v) for v in args.image.lower().split("x"))
-    sc, env = build_scene(args.workload)
-    bounces = 8
-
-    def rt_uniforms(frame):
-        u = layout.UniformBlock(layout.RAYTRACE_UNIFORMS)
-        u.set({"resolution": [width, height], "aspect": width / height, "frame": frame, "maxBounces": bounces,
-               "samplesPerFrame": 1,
-               "camera": {"position": sc.camera["position"], "direction": sc.camera_direction(),
-                          "fov": sc.camera["fov"], "focalDistance": sc.camera["focalDistance"],
-                          "aperture": sc.camera["aperture"]},
-               "envMapIntensity": 1.0, "envMapRotation": 0.0})
-        return u.tobytes()
-
-    def acc_uniforms(frame):
-        u = layout.UniformBlock(layout.ACCUMULATE_UNIFORMS)
-        u.set({"resolution": [width, height], "frame": frame, "enabled": 1})
-        return u.tobytes()
-
-    stream = torch.cuda.Stream()       # the context's main stream (events below are recorded on it)
-    ctx = capi.Context(local_rank)
-    ctx.set_stream(stream.cuda_stream)
-    ctx.set_kernel_variant(args.variant)
-    ctx.enable_timing(True)            # one HIP event pair per batched raytrace launch
-    ctx.upload_bvh(sc.nodes)
-    ctx.upload_triangles(sc.triangles)
-    ctx.upload_materials(sc.material_bytes)
-    ctx.upload_environment(env)
-    ctx.set_tile(rank, world, BLOCK_ROWS)
-    ctx.resize(width, height)
-    # the accumulation image lives in a torch tensor so RCCL can gather it in place
-    accum = torch.zeros((ctx.local_rows, width, 4), dtype=torch.float32, device="cuda")
-    ctx.bind_accumulation(accum.data_ptr(), accum.numel() * 4)
-    max_rows = capi.tile_local_rows(height, 0, world, BLOCK_ROWS)
-    gathered = None
-    if world > 1:
-        send = torch.zeros((max_rows, width, 4), dtype=torch.float32, device="cuda")
-        if rank == 0:
-            gathered = [torch.empty_like(send) for _ in range(world)]
-
-    def one_frame(frame):
-        ctx.set_uniforms(capi.PASS_RAYTRACE, rt_uniforms(frame))
-        ctx.set_uniforms(capi.PASS_ACCUMULATE, acc_uniforms(frame))
-        ctx.submit(capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+    red_dev = "cpu" if rehearsal else "cuda"
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def exchange():
-        # the one exchange of the job: HDR accumulation buffers -> rank 0 over xGMI
-        with torch.cuda.stream(stream):
-            send[: ctx.local_rows].copy_(accum)
-            if rehearsal:
-                stream.synchronize()
-                host = send.cpu()
-                dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
-            else:
-                dist.gather(send, gathered, dst=0)
+    def measure(workload, steps, warmup, gather):
+        """The timed job for one workload: `warmup` untimed frames, then EXACTLY `steps` frames
+        (+ the one gather when N > 1) between barrier + synchronize on both sides."""
+        stream = torch.cuda.Stream()       # the context's main stream
+        job = Job(workload, width, height, rank, world, local_rank, args.variant, stream.cuda_stream)
+        ctx = job.ctx
+        # the accumulation image lives in a torch tensor so RCCL can gather it in place
+        accum = torch.zeros((ctx.local_rows, width, 4), dtype=torch.float32, device="cuda")
+        ctx.bind_accumulation(accum.data_ptr(), accum.numel() * 4)
+        max_rows = capi.tile_local_rows(height, 0, world, BLOCK_ROWS)
+        send = gathered = None
+        if world > 1 and gather:
+            send = torch.zeros((max_rows, width, 4), dtype=torch.float32, device="cuda")
+            if rank == 0:
+                gathered = [torch.empty_like(send) for _ in range(world)]
 
-    frame = 2
-    for _ in range(args.warmup):
-        one_frame(frame)
-        frame += 1
-    ctx.sync()
-    if world > 1 and args.warmup > 0:
-        # warm-up of the exchange too: the first gather on a communicator sets up RCCL's
-        # point-to-point channels (tens of ms), which is not part of a steady-state job
-        exchange()
+        def exchange():
+            # the one exchange of the job: HDR accumulation buffers -> rank 0 over xGMI
+            with torch.cuda.stream(stream):
+                send[: ctx.local_rows].copy_(accum)
+                if rehearsal:
+                    stream.synchronize()
+                    host = send.cpu()
+                    dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
+                else:
+                    dist.gather(send, gathered, dst=0)
+
+        per_launch = frames_per_launch(steps, ctx.batch_capacity())
+        job.frames(warmup, per_launch)
+        ctx.sync()
+        if send is not None and warmup > 0:
+            # warm-up of the exchange too: the first gather on a communicator sets up RCCL's
+            # point-to-point channels (tens of ms), which is not part of a steady-state job
+            exchange()
+            sync_all()
+        ctx.reset_counters()
+        ctx.raytrace_launch_stats(reset=True)
+
         sync_all()
-    ctx.reset_counters()
-    ctx.raytrace_launch_stats(reset=True)
+        t0 = time.perf_counter()
+        job.frames(steps, per_launch)      # ends with a flush: everything is launched, nothing waited for
+        if send is not None:
+            exchange()
+        sync_all()
+        elapsed = time.perf_counter() - t0
 
-    # ---- the timed job: K frames (raytrace kernels of consecutive frames overlap on two
-    # internal streams; the ordered accumulate runs on `stream`), then the one gather.
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_frame(frame)
-        frame += 1
-    ctx.flush()      # launch the frames still queued for batching (no host wait)
-    if world > 1:
-        exchange()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    counters = ctx.counters()
+        counters = ctx.counters()
+        launch_ms_total, launches, launch_frames = ctx.raytrace_launch_stats()
+        span_ms = ctx.raytrace_launch_span()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        c = torch.tensor([counters[k] for k in capi.COUNTER_NAMES], dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total = dict(zip(capi.COUNTER_NAMES, (int(x) for x in c.tolist())))
+        m = {"job": job, "elapsed": float(t.item()), "total": total, "counters": counters,
+             "kernel_ms": launch_ms_total / max(launches, 1), "launches": int(launches),
+             "kernel_ms_exclusive": span_ms / max(launches, 1),
+             "frames_per_launch": round(launch_frames / max(launches, 1), 2),
+             "kernel": "k_raytrace_sm<false,false,true,true> (persistent raytrace kernel: per-lane state machine, deferred-leaf "
+                       "walk, exact-image distance culling; batched frames)" if args.variant in (0, 9)
+                       else f"raytrace kernel variant {args.variant}"}
+        ctx.bind_accumulation(None, 0)
+        return m
 
-    # ---- the dominant kernel's launches inside the timed region: the library brackets every
-    # batched raytrace launch with a HIP event pair on the stream it runs on; this is the
-    # per-launch duration rocprofv3 --kernel-trace reports for k_raytrace_sm<false,false,true>.
-    launch_ms_total, launches, launch_frames = ctx.raytrace_launch_stats()
-    kernel_ms = launch_ms_total / max(launches, 1)
-
-    red_dev = "cpu" if rehearsal else "cuda"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    c = torch.tensor([counters[k] for k in capi.COUNTER_NAMES], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    total = dict(zip(capi.COUNTER_NAMES, (int(x) for x in c.tolist())))
-
+    m = measure(args.workload, args.steps, args.warmup, gather=True)
+    job = m["job"]
+    out = None
     if rank == 0:
-        rays = total["rays"]
-        steps = max(args.steps, 1)
-        per_launch_bytes = algorithmic_bytes(counters) / max(launches, 1)    # this rank's kernel
-        achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        effective = algorithmic_bytes(counters) / steps / (elapsed / steps) / 1e9
+        rays, elapsed, steps = m["total"]["rays"], m["elapsed"], max(args.steps, 1)
         out = {
             "metric": "Mrays/s", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / steps, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("default demo mesh (1,998 triangles) + synthetic env map" if args.workload == "demo"
-                                    else f"dragon-class procedural mesh ({len(sc.triangles)} triangles) + synthetic env map")
-                       + f", {width}x{height}, 8 bounces, 1 spp per step, {args.steps} steps",
-                       "triangles": int(len(sc.triangles)), "bvh_nodes": int(len(sc.nodes)),
-                       "image": [width, height], "max_bounces": bounces,
+            "config": {"workload": workload_name(args.workload, job.sc) + f", {width}x{height}, {BOUNCES} bounces, 1 spp per step, "
+                                   f"{args.steps} steps",
+                       "triangles": int(len(job.sc.triangles)), "bvh_nodes": int(len(job.sc.nodes)),
+                       "image": [width, height], "max_bounces": BOUNCES,
                        "parallelism": (f"tile-split x{world} (8-row blocks, round robin), scene replicated, "
                                        "one RCCL gather at the end") if world > 1 else "single GPU",
                        "rays_per_step": rays // steps,
-                       "frames_per_launch": round(launch_frames / max(launches, 1), 2),
+                       "frames_per_launch": m["frames_per_launch"],
                        "scheduling": "consecutive frames are batched into one persistent launch over (frame, tile) "
                                      "jobs; batches alternate between two streams; one ordered multi-frame "
                                      "accumulate per batch on the main stream"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_raytrace_sm<false,false,true> (persistent raytrace, deferred-leaf walk, batched frames)"
-                                   if args.variant in (0, 7) else f"raytrace kernel variant {args.variant}",
-                         "kernel_ms": round(kernel_ms, 4), "launches_timed": int(launches),
-                         "frames_in_timed_launches": int(launch_frames),
-                         "algorithmic_bytes_per_launch": int(per_launch_bytes),
-                         "bytes_per_ray": round(algorithmic_bytes(total) / max(rays, 1), 1),
-                         "pipelined_job_GBps": round(effective, 1),
-                         "pipelined_job_frac": round(effective / HBM_PEAK_GBS, 4),
-                         # SURVEY.md 8d asks for both the 8.0 TB/s spec and the ~6.29 TB/s a streaming
-                         # kernel reaches (MI355X_MICROARCH.md); the bytes are algorithmic, served mostly
-                         # from L1/L2, so neither bounds this kernel
-                         "peak_achievable": HBM_ACHIEVABLE_GBS,
-                         "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4)},
         }
+    job.ctx.close()
+
+    # ---- secondary workload (N = 1): BASELINE.json configs[1], the default demo mesh
+    if world == 1 and args.workload != "demo" and not args.no_also:
+        a = measure("demo", args.steps, args.warmup, gather=False)
+        out["also"] = {"demo": {"value": round(a["total"]["rays"] / a["elapsed"] / 1e6, 3), "unit": "Mrays/s",
+                                "ms_per_step": round(a["elapsed"] * 1e3 / max(args.steps, 1), 4),
+                                "workload": workload_name("demo", a["job"].sc) + f", {width}x{height}, {BOUNCES} bounces",
+                                "kernel_ms": round(a["kernel_ms"], 4), "frames_per_launch": a["frames_per_launch"],
+                                "box_tests_per_ray": round(a["counters"]["box_tests"] / max(a["counters"]["rays"], 1), 2)}}
+        a["job"].ctx.close()
+
+    if rank == 0:
+        # ---- roofline: counter passes of this very command line (children; the timed job is over)
+        log = []
+        pmc, source = {}, None
+        key = {"workload": args.workload, "image": [width, height], "frames_per_launch": m["frames_per_launch"],
+               "variant": args.variant, "n_gpus": world}
+        if world == 1 and not args.no_pmc and not under_profiler():
+            try:
+                pmc = collect_pmc(args, m["launches"], log)
+            except Exception as e:          # noqa: BLE001 -- a profiler problem must not lose the measurement
+                log.append(f"pmc: {type(e).__name__}: {e}")
+            if pmc:
+                source = "live: rocprofv3 --pmc child runs of this command line, mean over the timed launches"
+        if "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:
+            e = traffic_from_file(key)
+            if e:
+                pmc = dict(e["counters"])
+                source = "profiles/traffic.json entry for this launch shape (" + e.get("source", "") + ")"
+        out["roofline"] = roofline_block(m, pmc, source, capi_num_cus())
+        if log:
+            out["roofline"]["pmc_log"] = log
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, env, rt_uniforms, width, height)
+            out["cpu_baseline"] = cpu_baseline(job)
         print(json.dumps(out), flush=True)
-    ctx.bind_accumulation(None, 0)
-    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def capi_num_cus():
+    import torch
+    try:
+        return int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
+    except Exception:       # noqa: BLE001
+        return 256
 
 
 if __name__ == "__main__":

@@ -558,7 +558,21 @@ def test_repeated_runs_are_bit_identical(gpu_ctx, demo, env):
                          capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
         runs.append((ctx.read_texture(capi.TEX_ACCUMULATION).tobytes(), ctx.counters()))
     assert runs[0][0] == runs[1][0] == runs[2][0]
-    assert runs[0][1] == runs[1][1] == runs[2][1]
+    # the paths are the same; the default walk skips boxes behind the closest hit found SO FAR, which depends on when a
+    # lane's parked leaves get their turn (a wave-level vote), so its box / triangle counts may move a little
+    for k in pc.PATH_COUNTERS:
+        assert runs[0][1][k] == runs[1][1][k] == runs[2][1][k]
+    ctx.set_kernel_variant(7)                    # the walk that runs exactly the reference's tests: every counter repeats
+    exact = []
+    for _ in range(2):
+        ctx.reset()
+        ctx.reset_counters()
+        for f in range(2, 22):
+            pc.gpu_frame(ctx, pc.rt_uniforms(demo, w, h, frame=f, bounces=8), pc.acc_uniforms(w, h, f),
+                         capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+        exact.append((ctx.read_texture(capi.TEX_ACCUMULATION).tobytes(), ctx.counters()))
+    ctx.set_kernel_variant(0)
+    assert exact[0] == exact[1] and exact[0][0] == runs[0][0]
     ctx.resize(64, 64)
 
 

@@ -730,15 +730,20 @@ static int check_scene(const mi3pt_ctx *ctx)
 }
 
 // Analysis for the distance-culling walk (kernel variant 9; pt_kernels.hip k_raytrace_sm<.., CULL>,
-// proof in DESIGN.md section 3a).  Per child of every internal node it bounds E = |e1| * |e2|
-// over the triangles below that child -- the quantity the rounding error of the reference's
-// Moller-Trumbore code scales with -- and writes the two bounds, rounded up to 16 bits each, into
-// the node packet.  A child gets +infinity (never skipped) when something below it is outside
-// the analysis: a triangle with E > 2^-3 or with |e1| + |e2| above 16 x the scene's mean (such
-// triangles would loosen the bound for every other one), a non-finite coordinate, or a box that
-// does not contain what is below it (the walk bounds distances by boxes; the reference does not
-// care whether its boxes bound anything).  Runs when the triangles or the tree changed, on the
-// host, from the device's own copies of both.
+// proof in DESIGN.md section 3a).  The rounding error of the reference's Moller-Trumbore code
+// scales with E = |e1| * |e2| of the triangle (through kappa = E |d| / |det| <= 2 E / EPSILON for
+// |d| <= 2): a triangle it accepts with t <= tau lies within
+//     delta = W(E) * (u / EPSILON) * (tau |d|^2 + 1.65 L |d|),   W(E) = E * c1(E),  u = 2^-24,
+// of the point o + t d, with c1(E) = (11.7 b + 3.02) / (1 - (11.7 b + 1.01) u kappa),
+// b = (1 + A) / (1 - A) + 1, A = 5.85 u kappa (c1 = 26.4 for small triangles, growing with E),
+// and L = |e1| + |e2|.  Per child of every internal node this bounds W over the triangles below
+// that child and writes the two bounds, rounded up to 16 bits each, into the node packet.  A
+// child gets +infinity (never skipped) when something below it is outside the analysis: a
+// triangle too large for it (A >= 1/4 or the denominator below 1/2: E above ~0.17), one with
+// |e1| + |e2| above 16 x the scene's mean (it would loosen the L term for every other one), a
+// non-finite coordinate, or a box that does not contain what is below it (the walk bounds
+// distances by boxes; the reference does not care whether its boxes bound anything).  Runs when
+// the triangles or the tree changed, on the host, from the device's own copies of both.
 static inline uint32_t round_up_16(float f)
 {
     uint32_t b;
@@ -787,11 +792,22 @@ static int prepare_cull(mi3pt_ctx *ctx)
         if (Ls == Ls && Ls < 1e30) { mean_l += Ls; counted++; }
     }
     mean_l = counted ? mean_l / (double)counted : 0.0;
-    const double lcap = 16.0 * mean_l, ecap = 0.125;
+    const double lcap = 16.0 * mean_l;
+    const double u = std::ldexp(1.0, -24), inv_eps = 1.0 / (double)1e-6f;
+    // W(E) = E * c1(E); < 0: the triangle is outside the analysis
+    auto weight = [&](double E) -> double {
+        const double kappa = E * 2.0 * inv_eps;
+        const double A = 5.85 * u * kappa;
+        if (!(A < 0.25)) return -1.0;
+        const double b = (1.0 + A) / (1.0 - A) + 1.0;
+        const double den = 1.0 - (11.7 * b + 1.01) * u * kappa;
+        if (!(den > 0.5)) return -1.0;
+        return E * (11.7 * b + 3.02) / den;
+    };
 
-    std::vector<float> emax(n, 0.0f);       // +inf = never skip
+    std::vector<float> wmax(n, 0.0f);       // +inf = never skip
     const float inf = __builtin_inff();
-    double lmax = 0.0, eglob = 0.0;
+    double lmax = 0.0;
     auto inside = [&](const uint8_t *outer, const float mn[3], const float mx[3]) {
         for (int k = 0; k < 3; k++)
             if (!(ldf(outer, 4 * k) <= mn[k] && ldf(outer, 16 + 4 * k) >= mx[k])) return false;     // false for NaNs too
@@ -808,14 +824,13 @@ static int prepare_cull(mi3pt_ctx *ctx)
             }
             double E, Ls;
             tri_el((size_t)ldi(r, 40), E, Ls);
-            const bool ok = E == E && Ls == Ls && E <= ecap && Ls <= lcap && inside(r, mn, mx);
-            if (ok) {
-                emax[i] = (float)(E * (1.0 + 1e-6));
-                if ((double)emax[i] < E) emax[i] = std::nextafter(emax[i], inf);
+            const double W = (E == E && Ls == Ls) ? weight(E) : -1.0;
+            if (W >= 0.0 && Ls <= lcap && inside(r, mn, mx)) {
+                wmax[i] = (float)(W * (1.0 + 1e-6));
+                if ((double)wmax[i] < W) wmax[i] = std::nextafter(wmax[i], inf);
                 if (Ls > lmax) lmax = Ls;
-                if (E > eglob) eglob = E;
             } else {
-                emax[i] = inf;
+                wmax[i] = inf;
             }
         } else {
             const int32_t left = ldi(r, 32), right = ldi(r, 36);
@@ -826,9 +841,9 @@ static int prepare_cull(mi3pt_ctx *ctx)
                 float mn[3], mx[3];
                 for (int k = 0; k < 3; k++) { mn[k] = ldf(cr, 4 * k); mx[k] = ldf(cr, 16 + 4 * k); }
                 if (!inside(r, mn, mx)) e = inf;
-                if (emax[(size_t)c] > e) e = emax[(size_t)c];
+                if (wmax[(size_t)c] > e) e = wmax[(size_t)c];
             }
-            emax[i] = e;
+            wmax[i] = e;
         }
     }
     // packet numbering of mi3pt_upload_bvh: internal nodes in index order
@@ -838,8 +853,8 @@ static int prepare_cull(mi3pt_ctx *ctx)
         if (is_leaf(i)) continue;
         const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
         const int32_t left = ldi(r, 32), right = ldi(r, 36);
-        const uint32_t hl = left >= 0 ? round_up_16(emax[(size_t)left]) : 0x7f80u;
-        const uint32_t hr = right >= 0 ? round_up_16(emax[(size_t)right]) : 0x7f80u;
+        const uint32_t hl = left >= 0 ? round_up_16(wmax[(size_t)left]) : 0x7f80u;
+        const uint32_t hr = right >= 0 ? round_up_16(wmax[(size_t)right]) : 0x7f80u;
         if (pk < cull.size()) cull[pk] = (hl << 16) | hr;
         pk++;
     }
@@ -854,19 +869,12 @@ static int prepare_cull(mi3pt_ctx *ctx)
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_cull);
     if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("cull analysis: ") + hipGetErrorString(e));
-    // Constants of the bound, for the largest E and L the packets admit.  u = 2^-24;
-    // kappa_max = E_max |d|_max / EPSILON with |d| <= dn <= 2 (cull_setup) and EPSILON = fp32(1e-6).
+    // scene constants of the bound: u / EPSILON and 1.65 L_max u / EPSILON, rounded up (the 1.001 covers the
+    // handful of fp32 roundings the kernel adds when it forms delta from them)
     {
-        const double u = std::ldexp(1.0, -24), inv_eps = 1.0 / (double)1e-6f;
-        const double kmax = eglob * 2.0 * inv_eps;
-        const double A = 5.85 * u * kmax;                       // relative error of one Cramer quotient
-        const double br = (1.0 + A) / (1.0 - A) + 1.0;
-        const double cs = 5.85 * 2.0 * br + 1.01;               // coefficient of |o - a|
-        const double cl = 5.85 * br + 2.2 * br + 2.0 + cs;      // coefficient of L
-        const double den = 1.0 - cs * u * kmax;
-        if (!(A < 0.25) || !(den > 0.5)) return pt_set_error(MI3PT_ERR_STATE, "cull analysis: E cap outside the analysis");
-        const double c1 = (cs + 2.01) / den, c2 = cl / den;
-        const double ka = c1 * u * inv_eps * 1.001, kb = c2 * u * inv_eps * lmax * 1.001;
+        double scale = 1.0;
+        if (const char *e = std::getenv("MI3PT_CULL_SCALE")) scale = std::atof(e);     // EXPERIMENT ONLY: < 1 voids the proof
+        const double ka = u * inv_eps * 1.001 * scale, kb = 1.65 * lmax * u * inv_eps * 1.001 * scale;
         ctx->cull_ka = std::nextafter((float)ka, inf);
         ctx->cull_kb = std::nextafter((float)kb, inf);
     }

@@ -33,8 +33,8 @@ struct NodePacket {
     float rmin[3], rmax[3];
     uint32_t lref, rref;     // child reference: leaf -> 0x80000000 | triangleIndex, else packet index
     uint32_t flags;          // bit0 / bit1: left / right box has a non-zero coordinate outside [2^-70, 2^60]
-    uint32_t cull;           // CULL walk: upper bounds of |e1|*|e2| over the triangles below the left (high 16
-                             // bits) / right (low 16 bits) child, as the top halves of binary32 values rounded
+    uint32_t cull;           // CULL walk: upper bounds of W = |e1|*|e2|*c1 over the triangles below the left (high
+                             // 16 bits) / right (low 16 bits) child, as the top halves of binary32 values rounded
                              // up; 0x7f80 = +infinity = never skip.  Written by the context's cull analysis.
 };
 static_assert(sizeof(NodePacket) == 64, "packet is one 64-B line");

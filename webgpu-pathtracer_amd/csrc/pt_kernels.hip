@@ -909,22 +909,21 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
 // ---------------------------------------------------------------------------------
 enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
 
-// Per-segment constants of the CULL walk's distance bound.  For a triangle with
-// E = |e1| |e2| and L = |e1| + |e2| that the reference's Moller-Trumbore code accepts with
-// t <= best.t, the point o + t d lies within
-//     delta = u kappa (c1 best.t |d| + c2 L),   kappa = E |d| / |det| <= E |d| / EPSILON,  u = 2^-24
-// of the triangle, hence of every box that holds it.  The context folds c1 u / EPSILON and
-// c2 u L_max / EPSILON (c1 ~ 26.4, c2 ~ 42.5 for small triangles, larger when the scene admits
-// bigger ones; both rounded up) into SceneRefs::cull_ka / cull_kb; with dn = |dx| + |dy| + |dz| >= |d|
-//     delta <= E * (Ka * best.t + Kb),   Ka = cull_ka dn^2,   Kb = cull_kb dn.
-// Rays the analysis does not cover (a plain-division ray, dn > 2, non-finite) get Ka = Kb =
-// +infinity: nothing is skipped (a child that must never be skipped carries E = +infinity).
+// Per-segment constants of the CULL walk's distance bound.  A triangle with
+// E = |e1| |e2| and |e1| + |e2| <= L_max that the reference's Moller-Trumbore code accepts with
+// t <= best.t lies within
+//     delta = W (u / EPSILON) (best.t |d|^2 + 1.65 L_max |d|),   W = E c1(E),  u = 2^-24
+// of the point o + t d, hence so does every box that holds it (context: prepare_cull computes W
+// per child and folds the rest into SceneRefs::cull_ka / cull_kb).  Per segment:
+//     delta <= W * (Ka * best.t + Kb),   Ka = cull_ka |d|^2,   Kb = cull_kb max(1, |d|^2) >= cull_kb |d|.
+// Rays the analysis does not cover (a plain-division ray, |d| > 2, non-finite) get Ka = Kb =
+// +infinity: nothing is skipped (a child that must never be skipped carries W = +infinity).
 PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float scene_kb, float &ka, float &kb)
 {
-    const float dn = (fabsf(d.x) + fabsf(d.y)) + fabsf(d.z);
-    const bool ok = (pre.flags & 8u) == 0u && dn <= 2.0f;
-    ka = ok ? scene_ka * (dn * dn) : __builtin_inff();
-    kb = ok ? scene_kb * dn : __builtin_inff();
+    const float dd = dot(d, d) * 1.0000005f;            // >= |d|^2 (three products, two sums: 3 u relative)
+    const bool ok = (pre.flags & 8u) == 0u && dd <= 4.0f;
+    ka = ok ? scene_ka * dd : __builtin_inff();
+    kb = ok ? scene_kb * fmaxf(1.0f, dd) : __builtin_inff();
 }
 
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
@@ -942,10 +941,10 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
 // CULL (kernel variant 9, needs DEFER): exact-image distance culling.  The reference walk has no
 // upper bound by the current hit (raytrace.wgsl:118-152, 154-203): it tests every box the ray
 // touches.  A child whose box the ray enters at tmin is skipped here when, in essence,
-//     tmin  -  E * (Ka * best.t + Kb)  >  best.t
-// (on every axis i: tnear_i - E (Ka best.t + Kb) / |d_i| > best.t (1 + 2^-20) skips the child)
-// where E (packet, 16 bits per child, rounded up) bounds |e1| * |e2| over the triangles below the
-// child and Ka, Kb are per-segment constants of the ray (cull_setup).  DESIGN.md section 3a proves
+//     tmin  -  W * (Ka * best.t + Kb) / |d_k|  >  best.t
+// (precisely: tnear_i - W (Ka best.t + Kb) / |d_i| > best.t (1 + 2^-20) on ANY axis i skips the child)
+// where W (packet, 16 bits per child, rounded up) bounds |e1| * |e2| * c1 over the triangles below
+// the child and Ka, Kb are per-segment constants of the ray (cull_setup).  DESIGN.md section 3a proves
 // that every triangle below such a child, had it been tested, would have been rejected or have
 // returned t > best.t in the reference's own fp32 Moller-Trumbore arithmetic -- so the closest
 // hit, its (t, u, v) and the tie rule are untouched and images stay bit-identical, while the
