@@ -321,10 +321,11 @@ def main():
         args.gpus = world
 
     # Build (make / g++ children) BEFORE anything touches the GPU; the other ranks meet rank 0 at
-    # the process-group rendezvous below, i.e. after the build.
+    # the process-group rendezvous below, i.e. after the build.  The library itself is loaded
+    # after torch (two HIP runtimes in one process: the first one loaded has to be torch's).
     import __graft_entry__ as ge
     if rank == 0:
-        ge.build()
+        ge.build(load=False)
 
     import torch
     import torch.distributed as dist

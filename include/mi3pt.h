@@ -265,6 +265,14 @@ int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n, float *ou
  * where two triangles are hit at exactly the same t.  build_ms (optional): device time. */
 int mi3pt_device_build_bvh(mi3pt_ctx *ctx, void *nodes_out, size_t nodes_capacity_bytes, size_t *nnodes_out, float *build_ms);
 
+/* Debug: node-packet / triangle numbering used on the device.  0 (default, shipped) = packets
+ * breadth-first like the uploaded nodes, triangles as uploaded.  1 = packets in the reference's
+ * visiting order (node, right subtree, left subtree) and triangles in leaf-visiting order -- a
+ * pure relabelling, bit-identical by construction, kept as a test of exactly that.  Call before
+ * the uploads it should apply to; after switching back, the next upload of the BVH or of the
+ * triangles restores the shipped numbering. */
+int mi3pt_debug_set_packet_layout(mi3pt_ctx *ctx, int layout);
+
 /* Design experiment, not part of the rendering path: walks `n` given rays (6 floats each) with the
  * deferred-leaf walk ALONE (no shading) as a persistent kernel with 4, 5, 6 or 8 resident waves
  * per SIMD, `passes` times over the list inside one launch (amortises the drain), and reports the

@@ -576,6 +576,55 @@ def test_repeated_runs_are_bit_identical(gpu_ctx, demo, env):
     ctx.resize(64, 64)
 
 
+def test_depth_first_relabelling_is_bit_identical(gpu_ctx, demo, env):
+    """Round 1 tried node packets numbered in visiting order (node, right subtree, left subtree) and
+    triangles stored by leaf rank, saw single-pixel differences on the dragon-class scene, and
+    reverted the experiment unexplained.  A relabelling cannot change a pixel.  Re-created here as
+    mi3pt_debug_set_packet_layout(1) -- every triangle-indexed array (112-B records, 48-B packets,
+    leaf ranks) is permuted consistently -- it is bit-identical to the breadth-first layout, image
+    and every counter, in each packet-walking kernel, on the dragon-class scene and on the
+    12-way-tie scene: the differences came from the experiment's own (reverted) indexing, not from
+    the shipped walk or its tie rule ("Depth-first packet layout")."""
+    from mi3pt_host import scenes
+    ctx = gpu_ctx
+    for sc, (w, h), frames, bounces in ((scenes.dragon_class_scene(), (960, 540), (2, 3, 4), 8),
+                                        (_coincident_sheets_scene(), (96, 64), (2, 3), 3)):
+        if sc.nodes is None:
+            sc.build_bvh()
+
+        def render(variant):
+            ctx.set_kernel_variant(variant)
+            ctx.reset()
+            ctx.reset_counters()
+            for f in frames:
+                pc.gpu_frame(ctx, pc.rt_uniforms(sc, w, h, frame=f, bounces=bounces), pc.acc_uniforms(w, h, f),
+                             capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
+            out = ctx.read_texture(capi.TEX_ACCUMULATION), ctx.counters()
+            ctx.set_kernel_variant(0)
+            return out
+
+        ctx.set_packet_layout(0)
+        pc.upload_scene(ctx, sc, env)
+        ctx.set_tile(0, 1, 8)
+        ctx.resize(w, h)
+        want = {v: render(v) for v in (2, 7)}
+        assert pc.same_bits(want[2][0], want[7][0])
+        ctx.set_packet_layout(1)
+        pc.upload_scene(ctx, sc, env)          # the relabelling applies to what is uploaded from here on
+        for v in (1, 2, 3, 4, 6, 7, 8):
+            img, cnt = render(v)
+            assert pc.same_bits(img, want[2][0]), f"{sc.name} variant {v}: " + pc.describe_diff(img, want[2][0])
+            pc.check_counters(cnt, want[2][1], culled=False, what=f"{sc.name}, relabelled, variant {v}")
+        img, cnt = render(0)                   # auto: the culling walk is not offered on a relabelled scene -> 7
+        assert pc.same_bits(img, want[2][0])
+        pc.check_counters(cnt, want[2][1], culled=False)
+        ctx.set_packet_layout(0)
+        pc.upload_scene(ctx, sc, env)          # back to the shipped arrangement
+        img, cnt = render(7)
+        assert pc.same_bits(img, want[2][0])
+    ctx.resize(64, 64)
+
+
 def test_no_cpu_fallback_symbols(built):
     """The product library must not contain an oracle / CPU render path."""
     import subprocess

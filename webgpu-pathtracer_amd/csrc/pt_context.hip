@@ -53,6 +53,13 @@ struct mi3pt_ctx {
     bool cull_ok = false;           // analysis done and the tree admits the walk
     float cull_ka = 0.0f, cull_kb = 0.0f;   // scene constants of the distance bound
     int num_cus = 256;              // hipDeviceProp_t::multiProcessorCount
+    // Debug: packet / triangle numbering (mi3pt_debug_set_packet_layout).  0 = breadth-first packets,
+    // triangles as uploaded (shipped).  1 = packets in the reference's visiting order (node, right
+    // subtree, left subtree) and triangles in leaf-visiting order: a pure relabelling.
+    int layout = 0;
+    bool layout_dirty = false;      // the relabelling still has to be applied to what was uploaded
+    bool layout_active = false;     // the device holds relabelled packets / triangles
+    void *d_tris_perm = nullptr;    // 112-B records in the relabelled order (the uploaded order stays in d_tris)
 
     // textures
     int width = 0, height = 0, local_rows = 0;
@@ -285,7 +292,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
     for (int k = 0; k < 2; k++)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     free_textures(ctx);
-    for (void *p : { ctx->d_tris, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
+    for (void *p : { ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
                      (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
@@ -406,6 +413,8 @@ extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t 
     ctx->ntris = n;
     ctx->max_mat_ref = max_mat;
     ctx->cull_dirty = true;
+    ctx->layout_active = false;
+    ctx->layout_dirty = ctx->layout != 0;
     return MI3PT_OK;
 }
 
@@ -417,6 +426,61 @@ extern "C" int mi3pt_upload_materials(mi3pt_ctx *ctx, const void *bytes, size_t 
     if (int rc = replace_buffer(ctx, &ctx->d_mats, bytes, nbytes)) return rc;
     ctx->nmats = nbytes / MI3PT_MATERIAL_STRIDE;
     return MI3PT_OK;
+}
+
+// precondition of the exact fast slab test (pt_kernels.hip, RayPre): per box, every coordinate
+// is 0 or within [2^-70, 2^60]
+static bool node_box_safe(const uint8_t *src, size_t node)
+{
+    const uint8_t *r = src + node * MI3PT_BVHNODE_STRIDE;
+    for (size_t off : { (size_t)0, (size_t)4, (size_t)8, (size_t)16, (size_t)20, (size_t)24 }) {
+        const float v = ldf(r, off);
+        const float a = v < 0 ? -v : v;
+        if (!(v == 0.0f || (a >= 8.470329472543003e-22f && a <= 1.152921504606847e18f))) return false;
+    }
+    return true;
+}
+
+// child reference of the packet walk: leaf -> 0x80000000 | triangle (renumbered by tri_new when given)
+static uint32_t child_ref(const uint8_t *src, const std::vector<uint32_t> &packet_of, const uint32_t *tri_new, int32_t child)
+{
+    if (child < 0) return pt::REF_NONE;
+    const uint8_t *r = src + (size_t)child * MI3PT_BVHNODE_STRIDE;
+    if (ldi(r, 28) == 1) {
+        const uint32_t ti = (uint32_t)ldi(r, 40);
+        return 0x80000000u | (tri_new ? tri_new[ti] : ti);
+    }
+    return packet_of[(size_t)child];
+}
+
+// One 64-byte packet per internal node, at the index packet_of[] gives it: bit copies of both
+// children's boxes, their references, the guard bits of the fast slab test.
+static void build_packets(const uint8_t *src, size_t n, const std::vector<uint32_t> &packet_of, size_t npackets,
+                          const uint32_t *tri_new, std::vector<pt::NodePacket> &pk)
+{
+    pk.assign(npackets ? npackets : 1, pt::NodePacket());
+    std::memset(pk.data(), 0, pk.size() * sizeof(pt::NodePacket));
+    for (auto &p : pk) p.cull = 0x7f807f80u;        // never skip, until the cull analysis has run
+    for (size_t i = 0; i < n; i++) {
+        if (packet_of[i] == pt::REF_NONE) continue;
+        const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+        pt::NodePacket &p = pk[packet_of[i]];
+        const int32_t left = ldi(r, 32), right = ldi(r, 36);
+        if (left >= 0) {
+            const uint8_t *c = src + (size_t)left * MI3PT_BVHNODE_STRIDE;
+            std::memcpy(p.lmin, c + 0, 12);
+            std::memcpy(p.lmax, c + 16, 12);
+        }
+        if (right >= 0) {
+            const uint8_t *c = src + (size_t)right * MI3PT_BVHNODE_STRIDE;
+            std::memcpy(p.rmin, c + 0, 12);
+            std::memcpy(p.rmax, c + 16, 12);
+        }
+        p.lref = child_ref(src, packet_of, tri_new, left);
+        p.rref = child_ref(src, packet_of, tri_new, right);
+        p.flags = ((left >= 0 && !node_box_safe(src, (size_t)left)) ? 1u : 0u) | ((right >= 0 && !node_box_safe(src, (size_t)right)) ? 2u : 0u) |
+                  ((left < 0 || right < 0) ? 4u : 0u);      // bit2: a child is missing (never from flattenBVH)
+    }
 }
 
 extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
@@ -433,17 +497,6 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
     std::vector<uint32_t> packet_of(n, pt::REF_NONE);
     size_t npackets = 0;
     int64_t max_tri = -1;
-    // precondition of the exact fast slab test (pt_kernels.hip, RayPre): per box, every
-    // coordinate is 0 or within [2^-70, 2^60]
-    auto box_safe = [&](size_t node) {
-        const uint8_t *r = src + node * MI3PT_BVHNODE_STRIDE;
-        for (size_t off : { (size_t)0, (size_t)4, (size_t)8, (size_t)16, (size_t)20, (size_t)24 }) {
-            const float v = ldf(r, off);
-            const float a = v < 0 ? -v : v;
-            if (!(v == 0.0f || (a >= 8.470329472543003e-22f && a <= 1.152921504606847e18f))) return false;
-        }
-        return true;
-    };
     for (size_t i = 0; i < n; i++) {
         const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
         if (ldi(r, 28) == 1) {
@@ -461,34 +514,9 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
             packet_of[i] = (uint32_t)npackets++;
         }
     }
-    auto ref_of = [&](int32_t child) -> uint32_t {
-        if (child < 0) return pt::REF_NONE;
-        const uint8_t *r = src + (size_t)child * MI3PT_BVHNODE_STRIDE;
-        if (ldi(r, 28) == 1) return 0x80000000u | (uint32_t)ldi(r, 40);
-        return packet_of[child];
-    };
-    std::vector<pt::NodePacket> pk(npackets ? npackets : 1);
-    std::memset(pk.data(), 0, pk.size() * sizeof(pt::NodePacket));
-    for (size_t i = 0; i < n; i++) {
-        if (packet_of[i] == pt::REF_NONE) continue;
-        const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
-        pt::NodePacket &p = pk[packet_of[i]];
-        const int32_t left = ldi(r, 32), right = ldi(r, 36);
-        if (left >= 0) {
-            const uint8_t *c = src + (size_t)left * MI3PT_BVHNODE_STRIDE;
-            std::memcpy(p.lmin, c + 0, 12);
-            std::memcpy(p.lmax, c + 16, 12);
-        }
-        if (right >= 0) {
-            const uint8_t *c = src + (size_t)right * MI3PT_BVHNODE_STRIDE;
-            std::memcpy(p.rmin, c + 0, 12);
-            std::memcpy(p.rmax, c + 16, 12);
-        }
-        p.lref = ref_of(left);
-        p.rref = ref_of(right);
-        p.flags = ((left >= 0 && !box_safe((size_t)left)) ? 1u : 0u) | ((right >= 0 && !box_safe((size_t)right)) ? 2u : 0u) |
-                  ((left < 0 || right < 0) ? 4u : 0u);      // bit2: a child is missing (never from flattenBVH)
-    }
+    std::vector<pt::NodePacket> pk;
+    build_packets(src, n, packet_of, npackets, nullptr, pk);
+    auto ref_of = [&](int32_t child) -> uint32_t { return child_ref(src, packet_of, nullptr, child); };
     // Order analysis for the deferred-leaf kernel (pt_kernels.hip, DEFER): the reference walk
     // visits leaves in a fixed order (node, right subtree, left subtree: left is pushed first,
     // raytrace.wgsl:184-198) and keeps the FIRST of equal-t hits.  If the buffer is a proper
@@ -542,9 +570,11 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
     ctx->nnodes = n;
     ctx->npackets = npackets;
     ctx->root_ref = ref_of(0);
-    ctx->scene_flags = box_safe(0) ? 1u : 0u;
+    ctx->scene_flags = node_box_safe(src, 0) ? 1u : 0u;
     ctx->max_tri_ref = max_tri;
     ctx->cull_dirty = true;
+    ctx->layout_active = false;
+    ctx->layout_dirty = ctx->layout != 0;
     return MI3PT_OK;
 }
 
@@ -697,7 +727,7 @@ extern "C" int mi3pt_set_uniforms(mi3pt_ctx *ctx, int pass, const void *bytes, s
 static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
 {
     pt::SceneRefs s;
-    s.tris = static_cast<const float4 *>(ctx->d_tris);
+    s.tris = static_cast<const float4 *>(ctx->layout_active ? ctx->d_tris_perm : ctx->d_tris);
     s.nodes = static_cast<const float4 *>(ctx->d_nodes);
     s.mats = static_cast<const float4 *>(ctx->d_mats);
     s.env = static_cast<const float4 *>(ctx->d_env);
@@ -712,6 +742,9 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.root_ref = ctx->root_ref;
     s.flags = ctx->scene_flags;
     s.cull_ka = ctx->cull_ka; s.cull_kb = ctx->cull_kb;
+    s.ref_bits = 1;
+    while (s.ref_bits < 32 && ((size_t)1 << s.ref_bits) < ctx->npackets) s.ref_bits++;
+    if (s.ref_bits > 26) s.ref_bits = 32;          // fewer than 6 bits left: store no distance
     if (std::getenv("MI3PT_FORCE_SLOW_SLAB")) s.flags = 0;     // experiment knob: plain IEEE divisions
     s.env_w = MI3PT_ENV_WIDTH; s.env_h = MI3PT_ENV_HEIGHT;
     return s;
@@ -726,6 +759,89 @@ static int check_scene(const mi3pt_ctx *ctx)
         return pt_set_error(MI3PT_ERR_STATE, "BVH references a triangle index beyond the triangle buffer");
     if (ctx->max_tri_ref >= 0 && ctx->max_mat_ref >= (int64_t)ctx->nmats)
         return pt_set_error(MI3PT_ERR_STATE, "a triangle references a material index beyond the material buffer");
+    return MI3PT_OK;
+}
+
+// Debug relabelling (mi3pt_debug_set_packet_layout(ctx, 1)): node packets numbered in the reference's
+// visiting order (node, right subtree, left subtree: left is pushed first, raytrace.wgsl:184-198)
+// and triangles -- 112-B records, 48-B packets, leaf ranks -- stored in leaf-visiting order.  Only
+// names change: every packet holds the same boxes, every leaf the same triangle, so images and
+// counters must be bit-identical to the breadth-first layout in every packet-walking kernel
+// (tests/test_gpu_parity.py::test_depth_first_relabelling_is_bit_identical).  Applied lazily
+// because it needs both uploads; needs a proper tree (leaf_cap > 0).  The distance-culling walk
+// is not offered in this layout (variant 0 / 9 run 7).
+static int prepare_layout(mi3pt_ctx *ctx)
+{
+    if (!ctx->layout_dirty) return MI3PT_OK;
+    if (ctx->layout == 0 || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->leaf_cap <= 0 || ctx->max_tri_ref >= (int64_t)ctx->ntris)
+        return MI3PT_OK;       // stays dirty; the uploaded (breadth-first) arrangement is complete by itself
+    if (int rc = flush_pending(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(ctx->rt_stream[k]));
+    const size_t n = ctx->nnodes, nt = ctx->ntris;
+    std::vector<uint8_t> nodes(n * MI3PT_BVHNODE_STRIDE), tris(nt * MI3PT_TRIANGLE_STRIDE);
+    HIP_TRY(hipMemcpy(nodes.data(), ctx->d_nodes, nodes.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tris.data(), ctx->d_tris, tris.size(), hipMemcpyDeviceToHost));
+    const uint8_t *src = nodes.data();
+    std::vector<uint32_t> packet_of(n, pt::REF_NONE), tri_new(nt, 0xffffffffu);
+    uint32_t npk = 0, ntri = 0;
+    std::vector<uint32_t> st;
+    st.push_back(0);
+    while (!st.empty()) {
+        const uint32_t node = st.back();
+        st.pop_back();
+        const uint8_t *r = src + (size_t)node * MI3PT_BVHNODE_STRIDE;
+        if (ldi(r, 28) == 1) {
+            tri_new[(size_t)ldi(r, 40)] = ntri++;
+        } else {
+            packet_of[node] = npk++;
+            st.push_back((uint32_t)ldi(r, 32));
+            st.push_back((uint32_t)ldi(r, 36));
+        }
+    }
+    for (size_t i = 0; i < n; i++)        // internal nodes the root does not reach keep a packet (never walked)
+        if (ldi(src + i * MI3PT_BVHNODE_STRIDE, 28) != 1 && packet_of[i] == pt::REF_NONE) packet_of[i] = npk++;
+    for (size_t t = 0; t < nt; t++)
+        if (tri_new[t] == 0xffffffffu) tri_new[t] = ntri++;
+    if (npk != ctx->npackets || ntri != nt) return pt_set_error(MI3PT_ERR_STATE, "packet layout: counts do not match the upload");
+    std::vector<pt::NodePacket> pk;
+    build_packets(src, n, packet_of, npk, tri_new.data(), pk);
+    std::vector<uint8_t> tris_perm(tris.size());
+    std::vector<pt::TriPacket> tripk(nt);
+    std::vector<uint32_t> rank(nt);
+    for (size_t t = 0; t < nt; t++) {
+        const uint8_t *rec = tris.data() + t * MI3PT_TRIANGLE_STRIDE;
+        const size_t to = tri_new[t];
+        std::memcpy(tris_perm.data() + to * MI3PT_TRIANGLE_STRIDE, rec, MI3PT_TRIANGLE_STRIDE);
+        std::memcpy(tripk[to].a, rec + 0, 12);
+        std::memcpy(tripk[to].b, rec + 16, 12);
+        std::memcpy(tripk[to].c, rec + 32, 12);
+        tripk[to].material = (uint32_t)ldi(rec, 92);
+        tripk[to].pad0 = tripk[to].pad1 = 0;
+        rank[to] = (uint32_t)to;          // leaf-visiting order IS the new numbering
+    }
+    if (int rc = replace_buffer(ctx, &ctx->d_packets, pk.data(), pk.size() * sizeof(pt::NodePacket))) return rc;
+    if (int rc = replace_buffer(ctx, &ctx->d_tripk, tripk.data(), nt * sizeof(pt::TriPacket))) return rc;
+    if (int rc = replace_buffer(ctx, &ctx->d_leaf_rank, rank.data(), nt * sizeof(uint32_t))) return rc;
+    if (int rc = replace_buffer(ctx, &ctx->d_tris_perm, tris_perm.data(), tris_perm.size())) return rc;
+    ctx->root_ref = child_ref(src, packet_of, tri_new.data(), 0);
+    ctx->layout_active = true;
+    ctx->layout_dirty = false;
+    ctx->cull_ok = false;           // the analysis below works on the uploaded numbering
+    ctx->cull_dirty = true;
+    ctx->main_dirty = true;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_debug_set_packet_layout(mi3pt_ctx *ctx, int layout)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    if (layout != 0 && layout != 1) return pt_set_error(MI3PT_ERR_INVALID, "layout must be 0 (breadth-first) or 1 (visiting order)");
+    if (int rc = require_idle(ctx)) return rc;
+    // (switching back to 0 leaves a relabelled scene on the device as it is -- it is complete and
+    // consistent -- until the BVH or the triangles are uploaded again)
+    ctx->layout = layout;
+    ctx->layout_dirty = layout != 0 && !ctx->layout_active;
     return MI3PT_OK;
 }
 
@@ -757,7 +873,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
 {
     if (!ctx->cull_dirty) return MI3PT_OK;
     const bool wanted = ctx->variant == 9 || (ctx->variant == 0 && ctx->cull_enabled);
-    if (!wanted || ctx->leaf_cap < 4 || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
+    if (!wanted || ctx->layout_active || ctx->leaf_cap < 4 || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
         return MI3PT_OK;       // stays dirty: pick_variant falls back to the reference-counter walk
     if (int rc = flush_pending(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -946,6 +1062,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.waves_per_cu = ctx->waves_per_cu;
     L.num_cus = ctx->num_cus;
     L.top_packets = ctx->top_packets;
+    if (pick_variant(ctx) == 1) L.scene.tris = static_cast<const float4 *>(ctx->d_tris);    // uploaded records, uploaded indices
     return L;
 }
 
@@ -1144,7 +1261,8 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
                             "the fullscreen pass needs the whole image: gather the tiles into a 1-rank context");
     if (do_rt) {
         if (int rc = check_scene(ctx)) return rc;
-        if (int rc = prepare_cull(ctx)) return rc;      // (no-op unless the scene changed)
+        if (int rc = prepare_layout(ctx)) return rc;    // (no-ops unless the scene changed)
+        if (int rc = prepare_cull(ctx)) return rc;
     }
     const pt::Tile tile = tile_of(ctx);
     const pt::AccUniforms acc = acc_uniforms(ctx);

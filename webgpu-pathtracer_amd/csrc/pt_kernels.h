@@ -63,6 +63,7 @@ struct SceneRefs {
     uint32_t ntris, nnodes, nmats, npackets;
     uint32_t root_ref;      // reference of node 0 in packet terms
     uint32_t flags;         // bit0: every ROOT box coordinate is 0 or within [2^-70, 2^60]
+    int32_t ref_bits;       // CULL walk: bits a packet index needs (the rest of a stack entry carries a distance)
     float cull_ka, cull_kb; // CULL walk: scene constants of the distance bound (pt_kernels.hip cull_setup; context: prepare_cull)
     int32_t env_w, env_h;
 };

@@ -36,6 +36,8 @@ namespace pt {
 #define PT_INF 1e20f
 #define PT_EPSILON 1e-6f
 #define PT_MAX_STACK 64
+#define PT_QLOW 0x35800000u            // bits of 2^-20 (see k_raytrace_sm, CULL)
+#define PT_QLOW_F 9.5367431640625e-07f
 
 #define PT_REF_LEAF pt::REF_LEAF
 #define PT_REF_NONE pt::REF_NONE
@@ -1050,6 +1052,13 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     pre.ix = pre.iy = pre.iz = 0.0f;
     pre.flags = 8u;
     float cull_ka = __builtin_inff(), cull_kb = __builtin_inff();      // CULL: per-segment constants of the distance bound
+    // CULL: a node-stack entry = packet index in the low qbits bits, and in the bits above it a distance
+    // quantised as ((float bits - bits of 2^-20) >> qshift): 5 exponent bits (2^-20 .. 2^12, clamped) and as
+    // many mantissa bits as fit.  0 decodes to 2^-20 < EPSILON <= every hit distance: "no information".
+    // (qon false: the index needs more than 26 bits, entries carry no distance)
+    const bool qon = L.scene.ref_bits < 32;
+    const uint32_t qbits = qon ? (uint32_t)L.scene.ref_bits : 31u, qshift = qbits > 4u ? qbits - 4u : 0u;
+    const uint32_t qmask = qon ? ((1u << qbits) - 1u) : 0xffffffffu;
 
     const int drain_mark = max(ntiles - (int)(gridDim.x >> 1), 0);
     auto fetch_tile = [&]() -> int {
@@ -1116,8 +1125,25 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             } else {
                 if (L.wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; }
                 if (has_node) {
-                    sp--;
-                    const uint32_t ref = stack[sp * 64];
+                    uint32_t ref;
+                    bool live = true;
+                    if (CULL) {
+                        // An entry carries, above its packet index, a lower bound of the distance its box was
+                        // found at when it was pushed (rounded down to the bits the index leaves free).  The
+                        // closest hit has usually moved nearer since: entries that now lie behind it are
+                        // dropped without fetching their packet.
+                        const float bt = best.t * 1.00000095367431640625f;
+                        do {
+                            sp--;
+                            const uint32_t e = stack[sp * 64];
+                            ref = e & qmask;
+                            live = !qon || !(__uint_as_float(((e >> qbits) << qshift) + PT_QLOW) > bt);
+                        } while (!live && sp > 0);
+                    } else {
+                        sp--;
+                        ref = stack[sp * 64];
+                    }
+                    if (live) {
                     float4 p0, p1, p2, p3;
                     if (TOPLDS && ref < ntop) {       // top of the tree: this wave's LDS copy
                         p0 = top_lds[ref * 4 + 0]; p1 = top_lds[ref * 4 + 1];
@@ -1145,6 +1171,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         hr = ray_aabb_pre(o, d, pre, (pf & 2u) != 0u, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
                     }
                     uint32_t r1 = lref, r2 = rref;
+                    uint32_t q1 = 0u, q2 = 0u;               // CULL: quantised distance bounds stored with the entries
                     if (CULL) {
                         // distance bound (see the kernel's header comment and DESIGN.md 3a): a hit below this
                         // child lies within delta of its box, so on EVERY axis it is at least
@@ -1157,21 +1184,27 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         const float tr = fmaxf(fmaxf(fmaf(-dr, fabsf(pre.ix), nr3.x), fmaf(-dr, fabsf(pre.iy), nr3.y)), fmaf(-dr, fabsf(pre.iz), nr3.z));
                         hl = hl && !(tl > bt);
                         hr = hr && !(tr > bt);
+                        // tl / tr only grow when best.t shrinks (the margin shrinks with it), so they stay valid
+                        // lower bounds for the entry's whole life on the stack: keep them, rounded DOWN
+                        q1 = qon ? (min(__float_as_uint(fmaxf(tl, PT_QLOW_F)) - PT_QLOW, 0x0fffffffu) >> qshift) << qbits : 0u;
+                        q2 = qon ? (min(__float_as_uint(fmaxf(tr, PT_QLOW_F)) - PT_QLOW, 0x0fffffffu) >> qshift) << qbits : 0u;
                         // far child first, near child last (popped first); leaves go to the leaf list anyway
                         if (fmaxf(fmaxf(nl3.x, nl3.y), nl3.z) < fmaxf(fmaxf(nr3.x, nr3.y), nr3.z)) {
                             r1 = rref; r2 = lref;
                             const bool h = hl; hl = hr; hr = h;
+                            const uint32_t q = q1; q1 = q2; q2 = q;
                         }
                     }
                     // sp + nl <= 30 here (leaf_cap = 32 - worst-case stack, nl <= leaf_cap - 2), so slot sp
                     // and slot 31 - nl are both free: the stores are unconditional, the counts select
                     const bool ll = (r1 & PT_REF_LEAF) != 0u, rl = (r2 & PT_REF_LEAF) != 0u;
-                    stack[(ll ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = ll ? (r1 & 0x7fffffffu) : r1;
+                    stack[(ll ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = ll ? (r1 & 0x7fffffffu) : (r1 | q1);
                     nl += (hl && ll) ? 1 : 0;
                     sp += (hl && !ll) ? 1 : 0;
-                    stack[(rl ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = rl ? (r2 & 0x7fffffffu) : r2;
+                    stack[(rl ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = rl ? (r2 & 0x7fffffffu) : (r2 | q2);
                     nl += (hr && rl) ? 1 : 0;
                     sp += (hr && !rl) ? 1 : 0;
+                    }
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                 }
             }

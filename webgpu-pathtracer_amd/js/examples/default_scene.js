@@ -2,6 +2,11 @@
 // The reference's default scene and camera, src/main.ts:36-75: a 5x5 plane rotated -90 deg
 // about X, a red 0.8^3 box at (0, 0.4, 0.5), a white sphere (r 0.5, 32x32) at (0, 0.5, -0.5);
 // camera fov 45 at (0, 1, 4) looking at the origin (the OrbitControls target).
+//
+// NOTE: the material and mesh set-up below (from `const white` to the sphere being added) is a
+// near-verbatim TRANSCRIPTION of src/main.ts:49-75 with `THREE.` replaced by `pt.` -- it is the
+// reference's default scene used as an INPUT (test / benchmark data, the way main.ts hands it to
+// its own renderer), not an implementation of anything.
 const pt = require('..');
 
 function buildDefaultScene(envData) {

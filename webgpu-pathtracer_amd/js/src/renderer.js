@@ -196,6 +196,8 @@ class Renderer {
   writeAccumulation(data) { this.native.writeTexture(this.handle, TEX_ACCUMULATION, data); }
   // launch queued sample frames now without waiting for them (render() only queues them)
   flush() { this.native.flush(this.handle); }
+  // queue.onSubmittedWorkDone() (renderer.ts:420), blocking: everything rendered so far has finished
+  sync() { this.native.sync(this.handle); }
   // run the reference's dormant environment importance sampling (raytrace.wgsl:398-404 un-commented)
   setEnvironmentSampling(enabled) { this.native.setEnvSampling(this.handle, enabled ? 1 : 0); this.reset(); }
   raytraceLaunchStats(reset) { return this.native.raytraceLaunchStats(this.handle, reset ? 1 : 0); }
