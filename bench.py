@@ -136,16 +136,19 @@ class Job:
         return u.tobytes()
 
     def frames(self, n, per_launch):
-        """Queue n consecutive frames, launching every `per_launch` (no host wait)."""
+        """n consecutive frames, `per_launch` per launch: one mi3pt_submit_frames call per launch
+        (= that many Renderer.render() calls with only the frame counter moving), launched at
+        once, nothing waited for."""
         capi, ctx = self.capi, self.ctx
-        for i in range(n):
+        done = 0
+        while done < n:
+            k = min(per_launch, n - done)
             ctx.set_uniforms(capi.PASS_RAYTRACE, self.rt_uniforms(self.frame))
             ctx.set_uniforms(capi.PASS_ACCUMULATE, self.acc_uniforms(self.frame))
-            ctx.submit(capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
-            self.frame += 1
-            if (i + 1) % per_launch == 0:
-                ctx.flush()
-        ctx.flush()
+            ctx.submit_frames(capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE, k)
+            ctx.flush()
+            self.frame += k
+            done += k
 
 
 def cpu_baseline(job, budget_s=12.0):

@@ -173,6 +173,11 @@ int mi3pt_set_uniforms(mi3pt_ctx *ctx, int pass /* mi3pt_pass */, const void *by
  * RAYTRACE|ACCUMULATE in one submit runs as one fused kernel (bit-identical to
  * the two-pass result). ---- */
 int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask);
+/* `count` consecutive frames with one call: frame i is submitted with the raytrace and the
+ * accumulate uniform `frame` fields at (their current value + i); afterwards both hold current +
+ * count.  Exactly what `count` calls of Renderer.render() submit while only the frame counter
+ * moves (renderer.ts:369-377); for headless hosts that render a fixed number of samples. */
+int mi3pt_submit_frames(mi3pt_ctx *ctx, unsigned pass_mask, uint32_t count);
 int mi3pt_sync(mi3pt_ctx *ctx);   /* queue.onSubmittedWorkDone(), renderer.ts:420 */
 /* Default MI3PT_PRESENT_EXACT.  See mi3pt_present_mode. */
 int mi3pt_set_present_mode(mi3pt_ctx *ctx, int mode /* mi3pt_present_mode */);

@@ -64,3 +64,24 @@ def test_render_loop_under_node_matches_golden(built, env, tmp_path):
     assert pc.same_bits(acc[..., :3], gold["64_acc3_image"]), pc.describe_diff(acc[..., :3], gold["64_acc3_image"])
     canvas = np.frombuffer(open(out + ".canvas.rgba8", "rb").read(), np.uint8).reshape(64, 64, 4)
     assert np.array_equal(canvas, gold["64_acc3_canvas_rgba8"])
+
+
+@pytest.mark.gpu
+def test_render_loop_throughput_under_node(built, env, tmp_path):
+    """The drop-in loop at speed: Renderer.render() driven like src/renderer.ts:366-395 / src/main.ts:387-400
+    at 1920x1080, 8 bounces.  With the headless default (the canvas drawn once per launched batch) and with
+    the fullscreen pass off the loop keeps the batched rate of the C ABI; presenting this very frame on
+    every call (the reference's canvas semantics) costs a launch per frame.  All legs end with the same
+    accumulation image, and both presenting legs with the same canvas."""
+    env_path = tmp_path / "env.f32"
+    env_path.write_bytes(env.tobytes())
+    r = _node([os.path.join(JS, "tools", "bench_render_loop.js"), "--env", str(env_path), "--frames", "64"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    legs = j["legs"]
+    print(json.dumps(j))
+    assert j["same_canvas"] and j["same_accumulation"]
+    assert len({l["rays"] for l in legs.values()}) == 1
+    assert legs["no_present"]["mrays_per_s"] >= 0.9 * legs["c_abi"]["mrays_per_s"]
+    assert legs["present_latest"]["mrays_per_s"] >= 0.75 * legs["c_abi"]["mrays_per_s"]
+    assert legs["present_exact"]["mrays_per_s"] < legs["present_latest"]["mrays_per_s"]

@@ -1327,6 +1327,22 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
     return MI3PT_OK;
 }
 
+// `count` consecutive frames in one call: what `count` calls of Renderer.render() submit while
+// nothing but the frame counter changes (renderer.ts:369-377 increments it before the uniforms
+// are written) -- frame i runs with raytrace `frame` = current + i and accumulate `frame` =
+// current + i, and both blocks are left at current + count, ready for the next call.
+extern "C" int mi3pt_submit_frames(mi3pt_ctx *ctx, unsigned pass_mask, uint32_t count)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    for (uint32_t i = 0; i < count; i++) {
+        if (int rc = mi3pt_submit(ctx, pass_mask)) return rc;
+        uint32_t f = ldu(ctx->u_rt, 12) + 1u, g = ldu(ctx->u_acc, 8) + 1u;
+        std::memcpy(ctx->u_rt + 12, &f, 4);
+        std::memcpy(ctx->u_acc + 8, &g, 4);
+    }
+    return MI3PT_OK;
+}
+
 // LATEST presentation: the draw a queued frame asked for happens before the canvas is looked at.
 static int settle_canvas(mi3pt_ctx *ctx)
 {

@@ -944,7 +944,7 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
 // upper bound by the current hit (raytrace.wgsl:118-152, 154-203): it tests every box the ray
 // touches.  A child whose box the ray enters at tmin is skipped here when, in essence,
 //     tmin  -  W * (Ka * best.t + Kb) / |d_k|  >  best.t
-// (precisely: tnear_i - W (Ka best.t + Kb) / |d_i| > best.t (1 + 2^-20) on ANY axis i skips the child)
+// (precisely: solved for best.t on every axis, see the node step; ANY axis may skip the child)
 // where W (packet, 16 bits per child, rounded up) bounds |e1| * |e2| * c1 over the triangles below
 // the child and Ka, Kb are per-segment constants of the ray (cull_setup).  DESIGN.md section 3a proves
 // that every triangle below such a child, had it been tested, would have been rejected or have
@@ -1128,16 +1128,15 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     uint32_t ref;
                     bool live = true;
                     if (CULL) {
-                        // An entry carries, above its packet index, a lower bound of the distance its box was
-                        // found at when it was pushed (rounded down to the bits the index leaves free).  The
-                        // closest hit has usually moved nearer since: entries that now lie behind it are
-                        // dropped without fetching their packet.
-                        const float bt = best.t * 1.00000095367431640625f;
+                        // An entry carries, above its packet index, the distance T below which nothing under
+                        // it can be hit (rounded down to the bits the index leaves free; computed when it was
+                        // pushed, see below).  The closest hit has usually come nearer since: entries that now
+                        // lie behind it are dropped without fetching their packet.
                         do {
                             sp--;
                             const uint32_t e = stack[sp * 64];
                             ref = e & qmask;
-                            live = !qon || !(__uint_as_float(((e >> qbits) << qshift) + PT_QLOW) > bt);
+                            live = !qon || !(best.t < __uint_as_float(((e >> qbits) << qshift) + PT_QLOW));
                         } while (!live && sp > 0);
                     } else {
                         sp--;
@@ -1173,19 +1172,28 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     uint32_t r1 = lref, r2 = rref;
                     uint32_t q1 = 0u, q2 = 0u;               // CULL: quantised distance bounds stored with the entries
                     if (CULL) {
-                        // distance bound (see the kernel's header comment and DESIGN.md 3a): a hit below this
-                        // child lies within delta of its box, so on EVERY axis it is at least
-                        // tnear_i - delta / |d_i| away; skip when that exceeds the closest hit so far
+                        // Distance bound (see the kernel's header comment and DESIGN.md 3a).  A hit below a child
+                        // lies within delta = W (Ka t + Kb) of the child's box, so on EVERY axis i it is at least
+                        // tnear_i - delta / |d_i| away.  Solved for t: nothing below the child can be hit nearer
+                        // than  T = max_i (tnear_i - m_i Kb) (1 - 2^-19 - m_i Ka),  m_i = W / |d_i|  (1/(1+x) >= 1-x;
+                        // the 2^-19 covers the roundings of tnear and of these operations).  T does not depend on
+                        // the closest hit so far: the child is skipped now if best.t < T, and T travels with the
+                        // stack entry so that the entry can be dropped later, when the closest hit has come nearer.
                         const uint32_t pe = __float_as_uint(p3.w);
-                        const float rc = fmaf(cull_ka, best.t, cull_kb);
-                        const float dl = __uint_as_float(pe & 0xffff0000u) * rc, dr = __uint_as_float(pe << 16) * rc;
-                        const float bt = best.t * 1.00000095367431640625f;       // 1 + 2^-20: the roundings of tnear and of the fma
-                        const float tl = fmaxf(fmaxf(fmaf(-dl, fabsf(pre.ix), nl3.x), fmaf(-dl, fabsf(pre.iy), nl3.y)), fmaf(-dl, fabsf(pre.iz), nl3.z));
-                        const float tr = fmaxf(fmaxf(fmaf(-dr, fabsf(pre.ix), nr3.x), fmaf(-dr, fabsf(pre.iy), nr3.y)), fmaf(-dr, fabsf(pre.iz), nr3.z));
-                        hl = hl && !(tl > bt);
-                        hr = hr && !(tr > bt);
-                        // tl / tr only grow when best.t shrinks (the margin shrinks with it), so they stay valid
-                        // lower bounds for the entry's whole life on the stack: keep them, rounded DOWN
+                        const float wl = __uint_as_float(pe & 0xffff0000u), wr = __uint_as_float(pe << 16);
+                        const float aix = fabsf(pre.ix), aiy = fabsf(pre.iy), aiz = fabsf(pre.iz);
+                        const float c19 = 0.99999809265136718750f;       // 1 - 2^-19
+                        float mx = wl * aix, my = wl * aiy, mz = wl * aiz;
+                        const float tl = fmaxf(fmaxf(fmaf(-mx, cull_kb, nl3.x) * fmaxf(fmaf(-mx, cull_ka, c19), 0.0f),
+                                                     fmaf(-my, cull_kb, nl3.y) * fmaxf(fmaf(-my, cull_ka, c19), 0.0f)),
+                                               fmaf(-mz, cull_kb, nl3.z) * fmaxf(fmaf(-mz, cull_ka, c19), 0.0f));
+                        mx = wr * aix; my = wr * aiy; mz = wr * aiz;
+                        const float tr = fmaxf(fmaxf(fmaf(-mx, cull_kb, nr3.x) * fmaxf(fmaf(-mx, cull_ka, c19), 0.0f),
+                                                     fmaf(-my, cull_kb, nr3.y) * fmaxf(fmaf(-my, cull_ka, c19), 0.0f)),
+                                               fmaf(-mz, cull_kb, nr3.z) * fmaxf(fmaf(-mz, cull_ka, c19), 0.0f));
+                        hl = hl && !(best.t < tl);
+                        hr = hr && !(best.t < tr);
+                        // the thresholds, rounded DOWN to the bits the packet index leaves free in a stack entry
                         q1 = qon ? (min(__float_as_uint(fmaxf(tl, PT_QLOW_F)) - PT_QLOW, 0x0fffffffu) >> qshift) << qbits : 0u;
                         q2 = qon ? (min(__float_as_uint(fmaxf(tr, PT_QLOW_F)) - PT_QLOW, 0x0fffffffu) >> qshift) << qbits : 0u;
                         // far child first, near child last (popped first); leaves go to the leaf list anyway

@@ -32,7 +32,7 @@ SYMBOLS = (
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
     "mi3pt_set_env_sampling", "mi3pt_debug_walk_probe", "mi3pt_device_build_bvh",
-    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_debug_set_packet_layout",
+    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
 )
@@ -77,6 +77,7 @@ def load_library(path=None):
     lib.mi3pt_reset.argtypes = [c_void_p]
     lib.mi3pt_set_uniforms.argtypes = [c_void_p, c_int, c_void_p, c_size_t]
     lib.mi3pt_submit.argtypes = [c_void_p, ctypes.c_uint]
+    lib.mi3pt_submit_frames.argtypes = [c_void_p, ctypes.c_uint, ctypes.c_uint32]
     lib.mi3pt_sync.argtypes = [c_void_p]
     lib.mi3pt_flush.argtypes = [c_void_p]
     lib.mi3pt_read_texture.argtypes = [c_void_p, c_int, c_void_p, c_size_t]
@@ -263,6 +264,9 @@ class Context:
 
     def submit(self, mask):
         self._c(self.lib.mi3pt_submit(self.handle, mask))
+
+    def submit_frames(self, mask, count):
+        self._c(self.lib.mi3pt_submit_frames(self.handle, mask, count))
 
     def flush(self):
         self._c(self.lib.mi3pt_flush(self.handle))
