@@ -71,9 +71,11 @@ shade_lanes, hit_lanes = hi(raw[:, 6]).sum(), lo(raw[:, 6]).sum()
 path_lanes, segment_lanes = hi(raw[:, 7]).sum(), lo(raw[:, 7]).sum()
 print(f"walk steps {walk_steps} ({walk_steps / nframes / 1e6:.3f} M per frame), mean walking lanes/step "
       f"{walk_lanes / max(walk_steps, 1):.1f}" + ("" if raw[:, 8].any() else f", of which on a leaf {leaf_lanes / max(walk_steps, 1):.1f}"))
-print(f"service steps {service_steps} ({service_steps / nframes / 1e3:.1f} k per frame), lanes shaded/step "
-      f"{shade_lanes / max(service_steps, 1):.1f} (hits {hit_lanes / max(service_steps, 1):.1f}), path starts/step "
-      f"{path_lanes / max(service_steps, 1):.1f}, segment starts/step {segment_lanes / max(service_steps, 1):.1f}")
+hit_steps, b_steps = hi(raw[:, 12]).sum(), lo(raw[:, 12]).sum()       # service steps that served the hit group / the miss + path group
+print(f"service steps {service_steps} ({service_steps / nframes / 1e3:.1f} k per frame): {hit_steps} shaded hits, "
+      f"{hit_lanes / max(hit_steps, 1):.1f} lanes each; {b_steps} shaded misses / started paths, "
+      f"{shade_lanes / max(b_steps, 1):.1f} miss lanes + {path_lanes / max(b_steps, 1):.1f} path starts each; "
+      f"segment starts/service step {segment_lanes / max(service_steps, 1):.1f}")
 tri_steps = raw[:, 8].astype(np.int64).sum() if raw.shape[1] > 8 else 0
 if tri_steps:
     print(f"deferred-leaf walk: the walk steps above are node steps; triangle steps {tri_steps} "

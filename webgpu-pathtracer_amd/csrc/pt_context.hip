@@ -92,6 +92,7 @@ struct mi3pt_ctx {
     int storage = MI3PT_STORAGE_F32;
     int variant = 0;
     bool env_sampling = false;  // mi3pt_set_env_sampling: the reference's dormant importance-sampling lines
+    int shade_split = 0;        // MI3PT_SHADE_SPLIT: see RtLaunch::shade_split
     int leaf_min = 32;          // deferred-leaf walk: lanes with a parked leaf that trigger a triangle step (MI3PT_LEAF_MIN)
     int walk_min = 32;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
     int waves_per_cu = 16;      // 8 KB of LDS per one-wave workgroup, 128 VGPRs
@@ -241,6 +242,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     if (ctx->batch_max > BATCH_LIMIT) ctx->batch_max = BATCH_LIMIT;
     if (const char *e = std::getenv("MI3PT_WAVES_PER_CU")) ctx->waves_per_cu = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_LEAF_MIN")) ctx->leaf_min = std::atoi(e);
+    if (const char *e = std::getenv("MI3PT_SHADE_SPLIT")) ctx->shade_split = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_TOP_PACKETS")) ctx->top_packets = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_CULL")) ctx->cull_enabled = std::atoi(e) != 0;
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
@@ -742,9 +744,6 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.root_ref = ctx->root_ref;
     s.flags = ctx->scene_flags;
     s.cull_ka = ctx->cull_ka; s.cull_kb = ctx->cull_kb;
-    s.ref_bits = 1;
-    while (s.ref_bits < 32 && ((size_t)1 << s.ref_bits) < ctx->npackets) s.ref_bits++;
-    if (s.ref_bits > 26) s.ref_bits = 32;          // fewer than 6 bits left: store no distance
     if (std::getenv("MI3PT_FORCE_SLOW_SLAB")) s.flags = 0;     // experiment knob: plain IEEE divisions
     s.env_w = MI3PT_ENV_WIDTH; s.env_h = MI3PT_ENV_HEIGHT;
     return s;
@@ -1057,6 +1056,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.store_f16 = ctx->storage == MI3PT_STORAGE_F16;
     L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
     L.leaf_min = ctx->leaf_min;
+    L.shade_split = ctx->shade_split;
     L.drain_flag = nullptr;
     L.drain_seq = 0;
     L.waves_per_cu = ctx->waves_per_cu;

@@ -63,7 +63,6 @@ struct SceneRefs {
     uint32_t ntris, nnodes, nmats, npackets;
     uint32_t root_ref;      // reference of node 0 in packet terms
     uint32_t flags;         // bit0: every ROOT box coordinate is 0 or within [2^-70, 2^60]
-    int32_t ref_bits;       // CULL walk: bits a packet index needs (the rest of a stack entry carries a distance)
     float cull_ka, cull_kb; // CULL walk: scene constants of the distance bound (pt_kernels.hip cull_setup; context: prepare_cull)
     int32_t env_w, env_h;
 };
@@ -111,6 +110,7 @@ struct RtLaunch {
     int32_t store_f16;
     int32_t walk_min;            // state-machine kernel: walk while at least this many lanes are walking
     int32_t leaf_min;            // deferred-leaf walk: run a triangle step once this many lanes have a leaf parked
+    int32_t shade_split;         // service step: 0 = serve hit and miss lanes together; n = serve the larger group, the other only with >= n lanes
     uint32_t *drain_flag;        // signal word (or null): receives drain_seq when the last job has been handed out
     uint32_t drain_seq;
     int32_t top_packets;         // node packets to stage in LDS per wave (0..64)

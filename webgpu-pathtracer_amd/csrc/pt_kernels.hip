@@ -36,8 +36,6 @@ namespace pt {
 #define PT_INF 1e20f
 #define PT_EPSILON 1e-6f
 #define PT_MAX_STACK 64
-#define PT_QLOW 0x35800000u            // bits of 2^-20 (see k_raytrace_sm, CULL)
-#define PT_QLOW_F 9.5367431640625e-07f
 
 #define PT_REF_LEAF pt::REF_LEAF
 #define PT_REF_NONE pt::REF_NONE
@@ -909,7 +907,7 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
 // still executes exactly the reference's sequence of tests for its own ray, so results
 // and counters are unchanged.
 // ---------------------------------------------------------------------------------
-enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2 };
+enum { M_DEAD = 0, M_TRAV = 1, M_SHADE = 2, M_PATH = 3 };
 
 // Per-segment constants of the CULL walk's distance bound.  A triangle with
 // E = |e1| |e2| and |e1| + |e2| <= L_max that the reference's Moller-Trumbore code accepts with
@@ -944,7 +942,7 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
 // upper bound by the current hit (raytrace.wgsl:118-152, 154-203): it tests every box the ray
 // touches.  A child whose box the ray enters at tmin is skipped here when, in essence,
 //     tmin  -  W * (Ka * best.t + Kb) / |d_k|  >  best.t
-// (precisely: solved for best.t on every axis, see the node step; ANY axis may skip the child)
+// (precisely: tnear_i - W (Ka best.t + Kb) / |d_i| > best.t (1 + 2^-20) on ANY axis i skips the child)
 // where W (packet, 16 bits per child, rounded up) bounds |e1| * |e2| * c1 over the triangles below
 // the child and Ka, Kb are per-segment constants of the ray (cull_setup).  DESIGN.md section 3a proves
 // that every triangle below such a child, had it been tested, would have been rejected or have
@@ -1028,6 +1026,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     // diagnostic step statistics (wave-uniform; stored with the stamps)
     uint32_t st_walk_steps = 0, st_walk_lanes = 0, st_leaf_lanes = 0, st_service_steps = 0;
     uint32_t st_shade_lanes = 0, st_hit_lanes = 0, st_path_lanes = 0, st_segment_lanes = 0, st_tri_steps = 0;
+    uint32_t st_hit_steps = 0, st_b_steps = 0;       // service steps that served the hit group / the miss + path group
     uint64_t st_cyc_node = 0, st_cyc_tri = 0, st_cyc_service = 0, st_mark = t_begin_clk;     // shader cycles per kind of step
     int st_kind = 2;
     auto st_switch = [&](int kind) {     // diagnostic only: the time since the last switch belongs to the step that ran
@@ -1052,13 +1051,6 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     pre.ix = pre.iy = pre.iz = 0.0f;
     pre.flags = 8u;
     float cull_ka = __builtin_inff(), cull_kb = __builtin_inff();      // CULL: per-segment constants of the distance bound
-    // CULL: a node-stack entry = packet index in the low qbits bits, and in the bits above it a distance
-    // quantised as ((float bits - bits of 2^-20) >> qshift): 5 exponent bits (2^-20 .. 2^12, clamped) and as
-    // many mantissa bits as fit.  0 decodes to 2^-20 < EPSILON <= every hit distance: "no information".
-    // (qon false: the index needs more than 26 bits, entries carry no distance)
-    const bool qon = L.scene.ref_bits < 32;
-    const uint32_t qbits = qon ? (uint32_t)L.scene.ref_bits : 31u, qshift = qbits > 4u ? qbits - 4u : 0u;
-    const uint32_t qmask = qon ? ((1u << qbits) - 1u) : 0xffffffffu;
 
     const int drain_mark = max(ntiles - (int)(gridDim.x >> 1), 0);
     auto fetch_tile = [&]() -> int {
@@ -1083,11 +1075,12 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         // walk phase: an inner loop of its own, so that the path state the walk does not
         // touch stays put in its registers
         bool serviceable;
+        int nwalk = 0;
         for (;;) {
         const unsigned long long walking = __ballot(mode == M_TRAV);
-        // a lane that is not walking waits for shading or (while jobs are left) for a new job
-        serviceable = feed_empty ? (__ballot(mode == M_SHADE) != 0ull) : (walking != ~0ull);
-        const int nwalk = (int)__popcll(walking);
+        // a lane that is not walking waits for shading, for its next camera path or (while jobs are left) for a new job
+        serviceable = feed_empty ? (__ballot(mode == M_SHADE || mode == M_PATH) != 0ull) : (walking != ~0ull);
+        nwalk = (int)__popcll(walking);
         if (!(nwalk > 0 && (nwalk >= L.walk_min || !serviceable))) break;
         if (DEFER) {
             // ---- deferred-leaf walk (scenes whose leaves may be tested in any order: SceneRefs::
@@ -1125,24 +1118,8 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             } else {
                 if (L.wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; }
                 if (has_node) {
-                    uint32_t ref;
-                    bool live = true;
-                    if (CULL) {
-                        // An entry carries, above its packet index, the distance T below which nothing under
-                        // it can be hit (rounded down to the bits the index leaves free; computed when it was
-                        // pushed, see below).  The closest hit has usually come nearer since: entries that now
-                        // lie behind it are dropped without fetching their packet.
-                        do {
-                            sp--;
-                            const uint32_t e = stack[sp * 64];
-                            ref = e & qmask;
-                            live = !qon || !(best.t < __uint_as_float(((e >> qbits) << qshift) + PT_QLOW));
-                        } while (!live && sp > 0);
-                    } else {
-                        sp--;
-                        ref = stack[sp * 64];
-                    }
-                    if (live) {
+                    sp--;
+                    const uint32_t ref = stack[sp * 64];
                     float4 p0, p1, p2, p3;
                     if (TOPLDS && ref < ntop) {       // top of the tree: this wave's LDS copy
                         p0 = top_lds[ref * 4 + 0]; p1 = top_lds[ref * 4 + 1];
@@ -1170,49 +1147,33 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         hr = ray_aabb_pre(o, d, pre, (pf & 2u) != 0u, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
                     }
                     uint32_t r1 = lref, r2 = rref;
-                    uint32_t q1 = 0u, q2 = 0u;               // CULL: quantised distance bounds stored with the entries
                     if (CULL) {
-                        // Distance bound (see the kernel's header comment and DESIGN.md 3a).  A hit below a child
-                        // lies within delta = W (Ka t + Kb) of the child's box, so on EVERY axis i it is at least
-                        // tnear_i - delta / |d_i| away.  Solved for t: nothing below the child can be hit nearer
-                        // than  T = max_i (tnear_i - m_i Kb) (1 - 2^-19 - m_i Ka),  m_i = W / |d_i|  (1/(1+x) >= 1-x;
-                        // the 2^-19 covers the roundings of tnear and of these operations).  T does not depend on
-                        // the closest hit so far: the child is skipped now if best.t < T, and T travels with the
-                        // stack entry so that the entry can be dropped later, when the closest hit has come nearer.
+                        // distance bound (see the kernel's header comment and DESIGN.md 3a): a hit below this
+                        // child lies within delta of its box, so on EVERY axis it is at least
+                        // tnear_i - delta / |d_i| away; skip when that exceeds the closest hit so far
                         const uint32_t pe = __float_as_uint(p3.w);
-                        const float wl = __uint_as_float(pe & 0xffff0000u), wr = __uint_as_float(pe << 16);
-                        const float aix = fabsf(pre.ix), aiy = fabsf(pre.iy), aiz = fabsf(pre.iz);
-                        const float c19 = 0.99999809265136718750f;       // 1 - 2^-19
-                        float mx = wl * aix, my = wl * aiy, mz = wl * aiz;
-                        const float tl = fmaxf(fmaxf(fmaf(-mx, cull_kb, nl3.x) * fmaxf(fmaf(-mx, cull_ka, c19), 0.0f),
-                                                     fmaf(-my, cull_kb, nl3.y) * fmaxf(fmaf(-my, cull_ka, c19), 0.0f)),
-                                               fmaf(-mz, cull_kb, nl3.z) * fmaxf(fmaf(-mz, cull_ka, c19), 0.0f));
-                        mx = wr * aix; my = wr * aiy; mz = wr * aiz;
-                        const float tr = fmaxf(fmaxf(fmaf(-mx, cull_kb, nr3.x) * fmaxf(fmaf(-mx, cull_ka, c19), 0.0f),
-                                                     fmaf(-my, cull_kb, nr3.y) * fmaxf(fmaf(-my, cull_ka, c19), 0.0f)),
-                                               fmaf(-mz, cull_kb, nr3.z) * fmaxf(fmaf(-mz, cull_ka, c19), 0.0f));
-                        hl = hl && !(best.t < tl);
-                        hr = hr && !(best.t < tr);
-                        // the thresholds, rounded DOWN to the bits the packet index leaves free in a stack entry
-                        q1 = qon ? (min(__float_as_uint(fmaxf(tl, PT_QLOW_F)) - PT_QLOW, 0x0fffffffu) >> qshift) << qbits : 0u;
-                        q2 = qon ? (min(__float_as_uint(fmaxf(tr, PT_QLOW_F)) - PT_QLOW, 0x0fffffffu) >> qshift) << qbits : 0u;
+                        const float rc = fmaf(cull_ka, best.t, cull_kb);
+                        const float dl = __uint_as_float(pe & 0xffff0000u) * rc, dr = __uint_as_float(pe << 16) * rc;
+                        const float bt = best.t * 1.00000095367431640625f;       // 1 + 2^-20: the roundings of tnear and of the fma
+                        const float tl = fmaxf(fmaxf(fmaf(-dl, fabsf(pre.ix), nl3.x), fmaf(-dl, fabsf(pre.iy), nl3.y)), fmaf(-dl, fabsf(pre.iz), nl3.z));
+                        const float tr = fmaxf(fmaxf(fmaf(-dr, fabsf(pre.ix), nr3.x), fmaf(-dr, fabsf(pre.iy), nr3.y)), fmaf(-dr, fabsf(pre.iz), nr3.z));
+                        hl = hl && !(tl > bt);
+                        hr = hr && !(tr > bt);
                         // far child first, near child last (popped first); leaves go to the leaf list anyway
                         if (fmaxf(fmaxf(nl3.x, nl3.y), nl3.z) < fmaxf(fmaxf(nr3.x, nr3.y), nr3.z)) {
                             r1 = rref; r2 = lref;
                             const bool h = hl; hl = hr; hr = h;
-                            const uint32_t q = q1; q1 = q2; q2 = q;
                         }
                     }
                     // sp + nl <= 30 here (leaf_cap = 32 - worst-case stack, nl <= leaf_cap - 2), so slot sp
                     // and slot 31 - nl are both free: the stores are unconditional, the counts select
                     const bool ll = (r1 & PT_REF_LEAF) != 0u, rl = (r2 & PT_REF_LEAF) != 0u;
-                    stack[(ll ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = ll ? (r1 & 0x7fffffffu) : (r1 | q1);
+                    stack[(ll ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = ll ? (r1 & 0x7fffffffu) : r1;
                     nl += (hl && ll) ? 1 : 0;
                     sp += (hl && !ll) ? 1 : 0;
-                    stack[(rl ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = rl ? (r2 & 0x7fffffffu) : (r2 | q2);
+                    stack[(rl ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = rl ? (r2 & 0x7fffffffu) : r2;
                     nl += (hr && rl) ? 1 : 0;
                     sp += (hr && !rl) ? 1 : 0;
-                    }
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                 }
             }
@@ -1312,17 +1273,33 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         if (!serviceable) break;      // nobody walking, nothing waiting, no jobs left
 
         // ---- service step
+        // Two groups wait here.  H: lanes whose walk ended in a hit (material fetch, 7 rand, cosine
+        // direction: raytrace.wgsl:380-395).  B: lanes whose walk ended in a miss (equirect lookup,
+        // :396-407), lanes between two camera paths, and free lanes while jobs are left (refill + the
+        // camera ray, :441-455).  Served together, each half runs with the other half's lanes masked
+        // off.  With L.shade_split > 0, and while other lanes are still walking, a step serves the
+        // larger group and leaves the smaller one waiting (unless it has shade_split lanes by itself):
+        // the groups alternate, each at a fuller mask.  Per-lane arithmetic is untouched: same bits.
+        const unsigned long long m_hit = __ballot(mode == M_SHADE && best.tri >= 0);
+        const int n_hit = (int)__popcll(m_hit);
+        const int n_b = (int)__popcll(__ballot((mode == M_SHADE && best.tri < 0) || mode == M_PATH || (mode == M_DEAD && !feed_empty)));
+        bool do_hit = n_hit > 0, do_b = true;
+        if (L.shade_split > 0 && nwalk > 0 && n_hit > 0 && n_b > 0) {
+            if (n_hit >= n_b) do_b = n_b >= L.shade_split;
+            else do_hit = n_hit >= L.shade_split;
+        }
         if (L.wave_times) {
             st_switch(2);
             st_service_steps++;
-            st_shade_lanes += (uint32_t)__popcll(__ballot(mode == M_SHADE));
-            st_hit_lanes += (uint32_t)__popcll(__ballot(mode == M_SHADE && best.tri >= 0));
+            if (do_hit) { st_hit_steps++; st_hit_lanes += (uint32_t)n_hit; }
+            if (do_b) { st_b_steps++; st_shade_lanes += (uint32_t)__popcll(__ballot(mode == M_SHADE && best.tri < 0)); }
         }
-        bool need_path = false;       // start the slot's next camera path (or finish the pixel)
         bool need_segment = false;    // start rayBVHIntersect for (o, d)
-        if (mode == M_SHADE) {
-            bool ended;
-            if (best.tri >= 0) {      // trace(), raytrace.wgsl:380-395
+        {
+            const bool shade_hit = do_hit && mode == M_SHADE && best.tri >= 0;
+            const bool shade_miss = do_b && mode == M_SHADE && best.tri < 0;
+            bool ended = true;
+            if (shade_hit) {          // trace(), raytrace.wgsl:380-395
                 cnt.hit++;
                 f3 position, normal;
                 int32_t mi;
@@ -1342,31 +1319,33 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 ray_color = ray_color * mix(xyz(m0), xyz(m1), is_specular);
                 bounce++;
                 ended = bounce >= un.max_bounces;
-            } else {                  // :396-407
+            }
+            if (shade_miss) {         // :396-407
                 cnt.miss++;
                 float u, v;
                 env_uv_from_dir(d, sinr, cosr, u, v);
                 const f3 env = sample_env(sc.env, sc.env_w, sc.env_h, u, v);
                 light = light + (ray_color * env) * un.env_intensity;
-                ended = true;
             }
-            mode = M_DEAD;            // until a path / segment is started below
-            if (ended) {
-                incoming = incoming + light;
-                sample++;
-                if (sample >= un.samples_per_frame) {
-                    // pixel finished (:455, :477): the slot is free for the refill below
-                    write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
+            if (shade_hit || shade_miss) {
+                mode = M_DEAD;        // until a path / segment is started below
+                if (ended) {
+                    incoming = incoming + light;
+                    sample++;
+                    if (sample >= un.samples_per_frame) {
+                        // pixel finished (:455, :477): the slot is free for a refill
+                        write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
+                    } else {
+                        mode = M_PATH;
+                    }
                 } else {
-                    need_path = true;
+                    need_segment = true;
                 }
-            } else {
-                need_segment = true;
             }
         }
-        // refill: dead lanes that are not about to continue their own pixel take new jobs
-        {
-            unsigned long long dead = __ballot(mode == M_DEAD && !need_path && !need_segment);
+        // refill: free lanes take new jobs
+        if (do_b) {
+            unsigned long long dead = __ballot(mode == M_DEAD && !need_segment);
             while (dead != 0ull && !feed_empty) {
                 if (cur_used >= 64) {
                     cur_tile = next_tile;
@@ -1396,17 +1375,18 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         seed = (gx + gy * res_w) + (un.frame + slot) * 719393u + PT_SEED;    // :435-436
                         sample = 0;
                         incoming = F3(0.0f, 0.0f, 0.0f);
-                        need_path = true;
+                        mode = M_PATH;
                     }
                 }
                 cur_used += take;
                 // lanes that took a job (valid or not) leave the dead set; invalid ones rejoin next round
-                dead = __ballot(mode == M_DEAD && !need_path && !need_segment && !mine);
+                dead = __ballot(mode == M_DEAD && !need_segment && !mine);
             }
         }
-        if (L.wave_times) st_path_lanes += (uint32_t)__popcll(__ballot(need_path));
-        if (need_path) {
+        if (L.wave_times) st_path_lanes += (uint32_t)__popcll(__ballot(do_b && mode == M_PATH));
+        if (do_b && mode == M_PATH) {
             // raytrace.wgsl:441-455: next sample's camera path, or the pixel is finished
+            mode = M_DEAD;
             for (;;) {
                 if (sample >= un.samples_per_frame) {
                     write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
@@ -1462,6 +1442,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         st_switch(2);
         w[8] = st_tri_steps;
         w[9] = st_cyc_node; w[10] = st_cyc_tri; w[11] = st_cyc_service;
+        w[12] = ((uint64_t)st_hit_steps << 32) | st_b_steps;
         w[0] = t_begin_rt;
         w[1] = t_empty_rt;
         w[2] = __builtin_amdgcn_s_memrealtime();
