@@ -308,6 +308,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (children of this process)")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary (demo scene) measurement")
     ap.add_argument("--image", default=None, help="WxH override (experiments only)")
+    ap.add_argument("--tile", default=None, help="R/N: render only rank R's share of an N-way tile split on this one GPU, no gather "
+                                                 "(experiments only: profiles/scaling_model.py predicts the multi-GPU curve from it)")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -365,12 +367,13 @@ def main():
         """The timed job for one workload: `warmup` untimed frames, then EXACTLY `steps` frames
         (+ the one gather when N > 1) between barrier + synchronize on both sides."""
         stream = torch.cuda.Stream()       # the context's main stream
-        job = Job(workload, width, height, rank, world, local_rank, args.variant, stream.cuda_stream)
+        tile_rank, tile_world = (int(v) for v in args.tile.split("/")) if args.tile else (rank, world)
+        job = Job(workload, width, height, tile_rank, tile_world, local_rank, args.variant, stream.cuda_stream)
         ctx = job.ctx
         # the accumulation image lives in a torch tensor so RCCL can gather it in place
         accum = torch.zeros((ctx.local_rows, width, 4), dtype=torch.float32, device="cuda")
         ctx.bind_accumulation(accum.data_ptr(), accum.numel() * 4)
-        max_rows = capi.tile_local_rows(height, 0, world, BLOCK_ROWS)
+        max_rows = capi.tile_local_rows(height, 0, tile_world, BLOCK_ROWS)
         send = gathered = None
         if world > 1 and gather:
             send = torch.zeros((max_rows, width, 4), dtype=torch.float32, device="cuda")
@@ -451,7 +454,7 @@ def main():
     job.ctx.close()
 
     # ---- secondary workload (N = 1): BASELINE.json configs[1], the default demo mesh
-    if world == 1 and args.workload != "demo" and not args.no_also:
+    if world == 1 and args.workload != "demo" and not args.no_also and not args.tile:
         a = measure("demo", args.steps, args.warmup, gather=False)
         out["also"] = {"demo": {"value": round(a["total"]["rays"] / a["elapsed"] / 1e6, 3), "unit": "Mrays/s",
                                 "ms_per_step": round(a["elapsed"] * 1e3 / max(args.steps, 1), 4),
@@ -466,7 +469,7 @@ def main():
         pmc, source = {}, None
         key = {"workload": args.workload, "image": [width, height], "frames_per_launch": m["frames_per_launch"],
                "variant": args.variant, "n_gpus": world}
-        if world == 1 and not args.no_pmc and not under_profiler():
+        if world == 1 and not args.no_pmc and not args.tile and not under_profiler():
             try:
                 pmc = collect_pmc(args, m["launches"], log)
             except Exception as e:          # noqa: BLE001 -- a profiler problem must not lose the measurement
@@ -481,7 +484,9 @@ def main():
         out["roofline"] = roofline_block(m, pmc, source, capi_num_cus())
         if log:
             out["roofline"]["pmc_log"] = log
-        if world == 1 and not args.no_cpu_baseline:
+        if args.tile:
+            out["config"]["parallelism"] = f"EXPERIMENT: rank {args.tile} of a tile split rendered alone on one GPU, no gather"
+        if world == 1 and not args.no_cpu_baseline and not args.tile:
             out["cpu_baseline"] = cpu_baseline(job)
         print(json.dumps(out), flush=True)
     if world > 1:
