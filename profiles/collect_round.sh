@@ -1,28 +1,43 @@
 #!/bin/bash
-# Collects the measurement artefacts of a round on the GPU box into gpurun_out/<tag>_*:
-# bench lines (demo with CPU baseline, dragon), rocprofv3 kernel stats of the bench command,
-# PMC passes (instruction mix, HBM traffic) for both workloads, wave timelines, fullscreen
-# timing.  usage: bash profiles/collect_round.sh <tag>      (about 5 GPU-minutes)
+# Collects the measurement artefacts of a round on the GPU box into gpurun_out/<tag>_*: the bench
+# lines (default arguments and the driver's --steps 20 --warmup 5; demo workload too), rocprofv3
+# kernel stats + kernel trace of the bench command itself, the scaling model, the culling probe
+# on BASELINE configs 2 / 3 / 5, wave timelines, the Node render-loop bench, fullscreen timing.
+# bench.py runs its own PMC passes (roofline.traffic, valu_issue_frac, ...), so none are run here.
+# usage: bash profiles/collect_round.sh <tag>      (about 8 GPU-minutes)
 set -u
 TAG=${1:-round}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
-python bench.py > $OUT/${TAG}_demo_1080p_bench.json 2> $OUT/${TAG}_demo_bench.err
-echo "demo bench done: $(cut -c1-100 $OUT/${TAG}_demo_1080p_bench.json)"
-python bench.py --no-cpu-baseline --workload dragon > $OUT/${TAG}_dragon_1080p_bench.json 2>/dev/null
-echo "dragon bench done: $(cut -c1-100 $OUT/${TAG}_dragon_1080p_bench.json)"
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py > $OUT/${TAG}_stats.log 2>&1)
-cp $(ls $OUT/${TAG}_stats/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_demo_1080p_kernel_stats.csv
+python bench.py > $OUT/${TAG}_dragon_1080p_bench.json 2> $OUT/${TAG}_dragon_bench.err
+echo "bench (default args) done: $(cut -c1-120 $OUT/${TAG}_dragon_1080p_bench.json)"
+python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_dragon_1080p_bench_driver_args.json 2>/dev/null
+echo "bench (driver args) done: $(cut -c1-120 $OUT/${TAG}_dragon_1080p_bench_driver_args.json)"
+python bench.py --workload demo > $OUT/${TAG}_demo_1080p_bench.json 2>/dev/null
+echo "bench (demo) done: $(cut -c1-120 $OUT/${TAG}_demo_1080p_bench.json)"
+for A in "" "--steps 20 --warmup 5"; do
+  S=$(echo "$A" | tr -d ' -' ); S=${S:-default}
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_$S -- python3 $ROOT/bench.py --no-cpu-baseline --no-also $A > $OUT/${TAG}_bench_under_rocprof_$S.json 2> $OUT/${TAG}_stats_$S.err)
+  cp $(ls $OUT/${TAG}_stats_$S/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_dragon_1080p_kernel_stats_$S.csv
+  cp $(ls $OUT/${TAG}_stats_$S/*/*_kernel_trace.csv | head -1) $OUT/${TAG}_dragon_1080p_kernel_trace_$S.csv
+  rm -rf $OUT/${TAG}_stats_$S
+done
 echo "rocprof stats done"
-PASSES="1 2 4 5" STEPS=64 WARMUP=16 bash profiles/pmc_passes.sh gpurun_out/${TAG}_pmc_demo
-python profiles/pmc_summary.py $OUT/${TAG}_pmc_demo > $OUT/${TAG}_demo_pmc_per_16frame_launch.txt
-echo "demo pmc done"
-PASSES="1 4 5" STEPS=64 WARMUP=16 bash profiles/pmc_passes.sh gpurun_out/${TAG}_pmc_dragon --workload dragon
-python profiles/pmc_summary.py $OUT/${TAG}_pmc_dragon > $OUT/${TAG}_dragon_pmc_per_16frame_launch.txt
-echo "dragon pmc done"
+python profiles/scaling_model.py --steps 20 --warmup 5 > $OUT/${TAG}_scaling_model_steps20.log 2>&1
+python profiles/scaling_model.py --steps 64 --warmup 16 > $OUT/${TAG}_scaling_model_steps64.log 2>&1
+python profiles/scaling_model.py --steps 256 --warmup 16 > $OUT/${TAG}_scaling_model_steps256.log 2>&1
+echo "scaling model done"
+(python profiles/cull_probe.py demo; python profiles/cull_probe.py dragon; python profiles/cull_probe.py forest 3840x2160 8) > $OUT/${TAG}_cull_probe.log 2>&1
+echo "cull probe done"
 python profiles/wave_timeline.py 1920x1080 16 > $OUT/${TAG}_wave_timeline_demo.log 2>&1
 WORKLOAD=dragon python profiles/wave_timeline.py 1920x1080 16 > $OUT/${TAG}_wave_timeline_dragon.log 2>&1
+WORKLOAD=dragon TILE=0/8 python profiles/wave_timeline.py 1920x1080 20 > $OUT/${TAG}_wave_timeline_dragon_rank0of8_20frames.log 2>&1
 python profiles/fullscreen_time.py > $OUT/${TAG}_fullscreen_time.log 2>&1
-echo "timelines done"
+python -c "
+import sys; sys.path.insert(0, 'webgpu-pathtracer_amd/py')
+from mi3pt_host import scenes
+scenes.synthetic_env().tofile('/tmp/env.f32')"
+node webgpu-pathtracer_amd/js/tools/bench_render_loop.js --env /tmp/env.f32 --frames 64 > $OUT/${TAG}_node_render_loop.json 2>&1
+echo "timelines + loop bench done"

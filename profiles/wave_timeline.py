@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-wave lifetime and step statistics of the persistent raytrace kernel.
 
-usage: [WORKLOAD=dragon] python profiles/wave_timeline.py [WxH] [frames_per_launch]
+usage: [WORKLOAD=dragon] [TILE=R/N] [VARIANT=v] python profiles/wave_timeline.py [WxH] [frames_per_launch]
 Renders one launch of `frames_per_launch` batched frames (default 16; 1 = a single frame) of
 the demo (or dragon-class) scene at 8 bounces and prints when the resident waves begin, see the
 work queue run empty, and end (100 MHz wall clock), the shader clock they averaged, and how
@@ -24,6 +24,8 @@ sc.build_bvh()
 env = scenes.synthetic_env()
 ctx = capi.Context(0)
 pc.upload_scene(ctx, sc, env)
+if os.environ.get("TILE"):               # TILE=R/N: rank R's share of an N-way tile split
+    ctx.set_tile(*(int(v) for v in os.environ["TILE"].split("/")), 8)
 ctx.resize(w, h)
 ctx.enable_wave_times(True)
 if os.environ.get("VARIANT"):
@@ -88,3 +90,17 @@ if raw.shape[1] > 11 and raw[:, 9:12].any():
           f"service (+ loop overhead) {cyc[2] / tot:.1%};  per step: node {cyc[0] / max(walk_steps, 1):.0f}  "
           f"triangle {cyc[1] / max(tri_steps, 1):.0f}  service {cyc[2] / max(service_steps, 1):.0f} cycles")
 
+
+if raw.shape[1] > 15 and raw[:, 13:16].any():
+    tn, tt = hi(raw[:, 13]), lo(raw[:, 13])
+    ts, live = hi(raw[:, 14]), lo(raw[:, 14])
+    tl = raw[:, 15].astype(np.int64)
+    tail_us = (end - e)[e > 0] / 100.0
+    steps = (tn + tt + ts)
+    print(f"after the queue ran empty, per wave (median / max): {np.median(tail_us):.0f} / {tail_us.max():.0f} us, "
+          f"live lanes at that moment {np.median(live):.0f} / {live.max()}, steps node {np.median(tn):.0f} / {tn.max()}  "
+          f"triangle {np.median(tt):.0f} / {tt.max()}  service {np.median(ts):.0f} / {ts.max()}, "
+          f"lanes per node-or-triangle step {tl.sum() / max((tn + tt).sum(), 1):.1f}")
+    slow = np.argsort(end)[-5:]
+    for i in slow:
+        print(f"  a late wave: empty at {us(e[i]):.0f} us, end {us(end[i]):.0f} us, live {live[i]}, tail steps node {tn[i]} triangle {tt[i]} service {ts[i]}")

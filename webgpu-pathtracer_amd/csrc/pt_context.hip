@@ -92,6 +92,7 @@ struct mi3pt_ctx {
     int storage = MI3PT_STORAGE_F32;
     int variant = 0;
     bool env_sampling = false;  // mi3pt_set_env_sampling: the reference's dormant importance-sampling lines
+    int tail_policy = 7;        // MI3PT_TAIL_POLICY: see RtLaunch::tail_policy
     int shade_split = 64;       // MI3PT_SHADE_SPLIT: see RtLaunch::shade_split (64: while lanes walk, only the larger group is served)
     int leaf_min = 32;          // deferred-leaf walk: lanes with a parked leaf that trigger a triangle step (MI3PT_LEAF_MIN)
     int walk_min = 32;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
@@ -243,6 +244,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     if (const char *e = std::getenv("MI3PT_WAVES_PER_CU")) ctx->waves_per_cu = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_LEAF_MIN")) ctx->leaf_min = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_SHADE_SPLIT")) ctx->shade_split = std::atoi(e);
+    if (const char *e = std::getenv("MI3PT_TAIL_POLICY")) ctx->tail_policy = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_TOP_PACKETS")) ctx->top_packets = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_CULL")) ctx->cull_enabled = std::atoi(e) != 0;
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
@@ -1057,6 +1059,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
     L.leaf_min = ctx->leaf_min;
     L.shade_split = ctx->shade_split;
+    L.tail_policy = ctx->tail_policy;
     L.drain_flag = nullptr;
     L.drain_seq = 0;
     L.waves_per_cu = ctx->waves_per_cu;

@@ -110,6 +110,7 @@ struct RtLaunch {
     int32_t store_f16;
     int32_t walk_min;            // state-machine kernel: walk while at least this many lanes are walking
     int32_t leaf_min;            // deferred-leaf walk: run a triangle step once this many lanes have a leaf parked
+    int32_t tail_policy;         // drain-phase scheduling, bit0: larger of node / triangle group, bit1: batched service, bit2: no shade split
     int32_t shade_split;         // service step: 0 = serve hit and miss lanes together; n = serve the larger group, the other only with >= n lanes
     uint32_t *drain_flag;        // signal word (or null): receives drain_seq when the last job has been handed out
     uint32_t drain_seq;

@@ -1027,6 +1027,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     uint32_t st_walk_steps = 0, st_walk_lanes = 0, st_leaf_lanes = 0, st_service_steps = 0;
     uint32_t st_shade_lanes = 0, st_hit_lanes = 0, st_path_lanes = 0, st_segment_lanes = 0, st_tri_steps = 0;
     uint32_t st_hit_steps = 0, st_b_steps = 0;       // service steps that served the hit group / the miss + path group
+    uint32_t st_tail_node = 0, st_tail_tri = 0, st_tail_service = 0, st_tail_lanes = 0, st_live_at_empty = 0;   // after the queue ran empty
     uint64_t st_cyc_node = 0, st_cyc_tri = 0, st_cyc_service = 0, st_mark = t_begin_clk;     // shader cycles per kind of step
     int st_kind = 2;
     auto st_switch = [&](int kind) {     // diagnostic only: the time since the last switch belongs to the step that ran
@@ -1079,8 +1080,15 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         for (;;) {
         const unsigned long long walking = __ballot(mode == M_TRAV);
         // a lane that is not walking waits for shading, for its next camera path or (while jobs are left) for a new job
-        serviceable = feed_empty ? (__ballot(mode == M_SHADE || mode == M_PATH) != 0ull) : (walking != ~0ull);
+        const unsigned long long waiting = __ballot(mode == M_SHADE || mode == M_PATH);
+        serviceable = feed_empty ? (waiting != 0ull) : (walking != ~0ull);
         nwalk = (int)__popcll(walking);
+        if (feed_empty && (L.tail_policy & 2)) {
+            // Drain (no jobs left, the wave only finishes the paths it holds): the walk_min rule would
+            // run a service step -- 2.4 node steps long -- for every single lane that ends a segment.
+            // Waiting lanes are served once they are at least half as many as the walking ones.
+            if (!(nwalk > 0 && 2 * (int)__popcll(waiting) < nwalk)) break;
+        } else
         if (!(nwalk > 0 && (nwalk >= L.walk_min || !serviceable))) break;
         if (DEFER) {
             // ---- deferred-leaf walk (scenes whose leaves may be tested in any order: SceneRefs::
@@ -1097,8 +1105,10 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             const bool has_node = trav && sp > 0, has_leaf = trav && nl > 0;
             const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
             const bool full = __ballot(trav && nl > lcap - 2) != 0ull;      // a node step may park two more
-            if (full || n_node == 0 || n_leaf >= L.leaf_min) {
-                if (L.wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; }
+            // (drain: whichever kind of step serves more lanes -- waiting for n_node == 0 would leave the lanes
+            // that only have leaves idle for as long as the slowest descent takes)
+            if (full || n_node == 0 || n_leaf >= L.leaf_min || (feed_empty && (L.tail_policy & 1) && n_leaf >= n_node)) {
+                if (L.wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
                 if (has_leaf) {
                     nl--;
                     const uint32_t ti = stack[(PT_SM_LDS_DEPTH - 1 - nl) * 64];
@@ -1116,7 +1126,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                 }
             } else {
-                if (L.wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; }
+                if (L.wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
                 if (has_node) {
                     sp--;
                     const uint32_t ref = stack[sp * 64];
@@ -1284,13 +1294,14 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         const int n_hit = (int)__popcll(m_hit);
         const int n_b = (int)__popcll(__ballot((mode == M_SHADE && best.tri < 0) || mode == M_PATH || (mode == M_DEAD && !feed_empty)));
         bool do_hit = n_hit > 0, do_b = true;
-        if (L.shade_split > 0 && nwalk > 0 && n_hit > 0 && n_b > 0) {
+        if (L.shade_split > 0 && nwalk > 0 && n_hit > 0 && n_b > 0 && !(feed_empty && (L.tail_policy & 4))) {
             if (n_hit >= n_b) do_b = n_b >= L.shade_split;
             else do_hit = n_hit >= L.shade_split;
         }
         if (L.wave_times) {
             st_switch(2);
             st_service_steps++;
+            if (feed_empty) st_tail_service++;
             if (do_hit) { st_hit_steps++; st_hit_lanes += (uint32_t)n_hit; }
             if (do_b) { st_b_steps++; st_shade_lanes += (uint32_t)__popcll(__ballot(mode == M_SHADE && best.tri < 0)); }
         }
@@ -1351,7 +1362,10 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     cur_tile = next_tile;
                     if (cur_tile >= ntiles) {
                         feed_empty = true;
-                        if (L.wave_times) t_empty_rt = __builtin_amdgcn_s_memrealtime();
+                        if (L.wave_times) {
+                            t_empty_rt = __builtin_amdgcn_s_memrealtime();
+                            st_live_at_empty = (uint32_t)__popcll(__ballot(mode != M_DEAD || need_segment));
+                        }
                         break;
                     }
                     next_tile = fetch_tile();
@@ -1443,6 +1457,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         w[8] = st_tri_steps;
         w[9] = st_cyc_node; w[10] = st_cyc_tri; w[11] = st_cyc_service;
         w[12] = ((uint64_t)st_hit_steps << 32) | st_b_steps;
+        w[13] = ((uint64_t)st_tail_node << 32) | st_tail_tri;
+        w[14] = ((uint64_t)st_tail_service << 32) | st_live_at_empty;
+        w[15] = st_tail_lanes;
         w[0] = t_begin_rt;
         w[1] = t_empty_rt;
         w[2] = __builtin_amdgcn_s_memrealtime();
