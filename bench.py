@@ -135,10 +135,10 @@ class Job:
         u.set({"resolution": [self.width, self.height], "frame": frame, "enabled": 1})
         return u.tobytes()
 
-    def frames(self, n, per_launch):
+    def frames(self, n, per_launch, sync_each=False):
         """n consecutive frames, `per_launch` per launch: one mi3pt_submit_frames call per launch
         (= that many Renderer.render() calls with only the frame counter moving), launched at
-        once, nothing waited for."""
+        once, nothing waited for (sync_each: wait after every launch -- the counter passes)."""
         capi, ctx = self.capi, self.ctx
         done = 0
         while done < n:
@@ -146,7 +146,7 @@ class Job:
             ctx.set_uniforms(capi.PASS_RAYTRACE, self.rt_uniforms(self.frame))
             ctx.set_uniforms(capi.PASS_ACCUMULATE, self.acc_uniforms(self.frame))
             ctx.submit_frames(capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE, k)
-            ctx.flush()
+            ctx.sync() if sync_each else ctx.flush()
             self.frame += k
             done += k
 
@@ -186,16 +186,20 @@ def under_profiler():
 
 
 def inner_pmc(args):
-    """Child mode: the job alone (no torch, no baseline, no output), for a counter pass."""
+    """Child mode: the job alone (no torch, no baseline, no output), for a counter pass.  One launch
+    at a time: with counters on, rocprofv3 serialises kernels in the order it intercepts them on
+    the two internal queues, which need not be the order they were enqueued in -- and a launch
+    that is held (hipStreamWaitValue32) until its predecessor announces its drain can then end
+    up in front of that predecessor: a deadlock, seen as passes that never finish.  The child
+    therefore runs without the launch gate (MI3PT_GATE=0, set by the parent) and waits for
+    every launch; per-launch counters are what a serialised run measures anyway."""
     width, height = image_size(1, args.scaling)
     if args.image:
         width, height = (int(v) for v in args.image.lower().split("x"))
     job = Job(args.workload, width, height, variant=args.variant)
     per_launch = frames_per_launch(args.steps, job.ctx.batch_capacity())
-    job.frames(args.warmup, per_launch)
-    job.ctx.sync()
-    job.frames(args.steps, per_launch)
-    job.ctx.sync()
+    job.frames(args.warmup, per_launch, sync_each=True)
+    job.frames(args.steps, per_launch, sync_each=True)
     job.ctx.close()
 
 
@@ -207,7 +211,7 @@ def collect_pmc(args, timed_launches, log):
         return {}
     out = {}
     base = tempfile.mkdtemp(prefix="mi3pt_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", MI3PT_GATE="0")
     try:
         for i, counters in enumerate(PMC_PASSES):
             d = os.path.join(base, f"pass{i}")
@@ -217,7 +221,7 @@ def collect_pmc(args, timed_launches, log):
             if args.image:
                 cmd += ["--image", args.image]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
             except (subprocess.TimeoutExpired, OSError) as e:
                 log.append(f"pmc pass {counters}: {type(e).__name__}")
                 break                   # a pass that had to be killed: start nothing else on this GPU

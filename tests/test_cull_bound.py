@@ -49,8 +49,8 @@ def weight(E):
     kappa = E * 2.0 / EPS
     A = 5.85 * U * kappa
     b = (1.0 + A) / (1.0 - A) + 1.0
-    den = 1.0 - (11.7 * b + 1.01) * U * kappa
-    w = E * (11.7 * b + 3.02) / den
+    den = 1.0 - (11.7 * b + 1.02) * U * kappa
+    w = E * (11.7 * b + 3.04) / den
     return np.where((A < 0.25) & (den > 0.5), w, np.nan)
 
 

@@ -851,7 +851,7 @@ extern "C" int mi3pt_debug_set_packet_layout(mi3pt_ctx *ctx, int layout)
 // scales with E = |e1| * |e2| of the triangle (through kappa = E |d| / |det| <= 2 E / EPSILON for
 // |d| <= 2): a triangle it accepts with t <= tau lies within
 //     delta = W(E) * (u / EPSILON) * (tau |d|^2 + 1.65 L |d|),   W(E) = E * c1(E),  u = 2^-24,
-// of the point o + t d, with c1(E) = (11.7 b + 3.02) / (1 - (11.7 b + 1.01) u kappa),
+// of the point o + t d, with c1(E) = (11.7 b + 3.04) / (1 - (11.7 b + 1.02) u kappa),
 // b = (1 + A) / (1 - A) + 1, A = 5.85 u kappa (c1 = 26.4 for small triangles, growing with E),
 // and L = |e1| + |e2|.  Per child of every internal node this bounds W over the triangles below
 // that child and writes the two bounds, rounded up to 16 bits each, into the node packet.  A
@@ -917,9 +917,9 @@ static int prepare_cull(mi3pt_ctx *ctx)
         const double A = 5.85 * u * kappa;
         if (!(A < 0.25)) return -1.0;
         const double b = (1.0 + A) / (1.0 - A) + 1.0;
-        const double den = 1.0 - (11.7 * b + 1.01) * u * kappa;
+        const double den = 1.0 - (11.7 * b + 1.02) * u * kappa;
         if (!(den > 0.5)) return -1.0;
-        return E * (11.7 * b + 3.02) / den;
+        return E * (11.7 * b + 3.04) / den;
     };
 
     std::vector<float> wmax(n, 0.0f);       // +inf = never skip
