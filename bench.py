@@ -3,9 +3,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dragon|demo] [--scaling strong|weak]
 
-One STEP = one Renderer.render() frame of the hot path (raytrace + accumulate passes, 1 sample
-per pixel, whole image, 8 bounces).  The library queues consecutive frames and launches them in
-batches (bit-identical results); the timed region ends with a flush + device sync.
+One STEP = one pass of the hot path over one batch of input: FRAMES_PER_STEP = 16 consecutive
+Renderer.render() frames (raytrace + accumulate passes, 1 sample per pixel each, whole image, 8
+bounces) = 16 spp -- the unit the persistent raytrace kernel is launched on (one launch covers
+one batch of frames; bit-identical to launching frame by frame).  K steps = 16 K frames; the
+timed region ends with a flush + device sync.  (Round 1 counted a single frame as a step: with
+the driver's 20 steps that is a 9 ms job, most of it launch ramp and drain.)
 
 Headline workload (default) = the scene BASELINE.json's target is quoted on: the dragon-class
 ~870k-triangle mesh + environment map at 1920x1080 (configs[2]); `--workload demo` is
@@ -54,6 +57,7 @@ HBM_ACHIEVABLE_GBS = 6290.0     # same guide: what a streaming kernel reaches
 SHADER_CLOCK_HZ = 2.4e9         # peak engine clock used for the VALU issue rate
 BLOCK_ROWS = 8
 BOUNCES = 8
+FRAMES_PER_STEP = 16            # one step = one batch = one launch of the persistent kernel (single GPU)
 KERNEL_NEEDLE = "k_raytrace_sm"
 # counter groups of the PMC passes: one rocprofv3 run each (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
@@ -89,13 +93,13 @@ def algorithmic_bytes(c):
     return 48 * c["box_tests"] + 112 * c["tri_tests"] + 64 * c["hits"] + 64 * c["misses"] + 32 * c["pixels"]
 
 
-def frames_per_launch(steps, cap):
-    """Launches of ONE shape inside the timed region: the largest divisor-like split of the job
-    that fits the library's batch capacity (20 steps, capacity 16 -> 2 launches of 10)."""
-    if steps <= 0:
-        return 1
-    launches = -(-steps // max(cap, 1))
-    return -(-steps // launches)
+def frames_per_launch(cap):
+    """Frames one launch covers: whole steps, as many as the library's batch capacity holds (16 on
+    one GPU = one step per launch; a rank of an N-way split renders 1/N of the image per frame and
+    batches up to N steps per launch); below 16 only when memory is short."""
+    if cap >= FRAMES_PER_STEP:
+        return cap - cap % FRAMES_PER_STEP
+    return max(cap, 1)
 
 
 class Job:
@@ -197,9 +201,9 @@ def inner_pmc(args):
     if args.image:
         width, height = (int(v) for v in args.image.lower().split("x"))
     job = Job(args.workload, width, height, variant=args.variant)
-    per_launch = frames_per_launch(args.steps, job.ctx.batch_capacity())
-    job.frames(args.warmup, per_launch, sync_each=True)
-    job.frames(args.steps, per_launch, sync_each=True)
+    per_launch = frames_per_launch(job.ctx.batch_capacity())
+    job.frames(args.warmup * FRAMES_PER_STEP, per_launch, sync_each=True)
+    job.frames(args.steps * FRAMES_PER_STEP, per_launch, sync_each=True)
     job.ctx.close()
 
 
@@ -303,8 +307,8 @@ def roofline_block(m, pmc, source, num_cus):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)     # one full batch: every launch a profiler sees has the timed shape
+    ap.add_argument("--steps", type=int, default=16)      # x 16 frames = 256 spp (BASELINE.json configs[2])
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dragon", choices=["demo", "dragon"])
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--variant", type=int, default=0)
@@ -368,7 +372,7 @@ def main():
         torch.cuda.synchronize()
 
     def measure(workload, steps, warmup, gather):
-        """The timed job for one workload: `warmup` untimed frames, then EXACTLY `steps` frames
+        """The timed job for one workload: `warmup` untimed steps, then EXACTLY `steps` steps of 16 frames
         (+ the one gather when N > 1) between barrier + synchronize on both sides."""
         stream = torch.cuda.Stream()       # the context's main stream
         tile_rank, tile_world = (int(v) for v in args.tile.split("/")) if args.tile else (rank, world)
@@ -395,8 +399,8 @@ def main():
                 else:
                     dist.gather(send, gathered, dst=0)
 
-        per_launch = frames_per_launch(steps, ctx.batch_capacity())
-        job.frames(warmup, per_launch)
+        per_launch = frames_per_launch(ctx.batch_capacity())
+        job.frames(warmup * FRAMES_PER_STEP, per_launch)
         ctx.sync()
         if send is not None and warmup > 0:
             # warm-up of the exchange too: the first gather on a communicator sets up RCCL's
@@ -408,7 +412,7 @@ def main():
 
         sync_all()
         t0 = time.perf_counter()
-        job.frames(steps, per_launch)      # ends with a flush: everything is launched, nothing waited for
+        job.frames(steps * FRAMES_PER_STEP, per_launch)      # ends with a flush: everything is launched, nothing waited for
         if send is not None:
             exchange()
         sync_all()
@@ -443,8 +447,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / steps, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_name(args.workload, job.sc) + f", {width}x{height}, {BOUNCES} bounces, 1 spp per step, "
-                                   f"{args.steps} steps",
+            "config": {"workload": workload_name(args.workload, job.sc) + f", {width}x{height}, {BOUNCES} bounces, {FRAMES_PER_STEP} frames "
+                                   f"(= {FRAMES_PER_STEP} spp) per step, {args.steps} steps = {args.steps * FRAMES_PER_STEP} spp",
+                       "frames_per_step": FRAMES_PER_STEP,
                        "triangles": int(len(job.sc.triangles)), "bvh_nodes": int(len(job.sc.nodes)),
                        "image": [width, height], "max_bounces": BOUNCES,
                        "parallelism": (f"tile-split x{world} (8-row blocks, round robin), scene replicated, "

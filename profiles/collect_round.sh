@@ -26,8 +26,7 @@ for A in "" "--steps 20 --warmup 5"; do
 done
 echo "rocprof stats done"
 python profiles/scaling_model.py --steps 20 --warmup 5 > $OUT/${TAG}_scaling_model_steps20.log 2>&1
-python profiles/scaling_model.py --steps 64 --warmup 16 > $OUT/${TAG}_scaling_model_steps64.log 2>&1
-python profiles/scaling_model.py --steps 256 --warmup 16 > $OUT/${TAG}_scaling_model_steps256.log 2>&1
+python profiles/scaling_model.py --steps 4 --warmup 1 > $OUT/${TAG}_scaling_model_steps4.log 2>&1
 echo "scaling model done"
 (python profiles/cull_probe.py demo; python profiles/cull_probe.py dragon; python profiles/cull_probe.py forest 3840x2160 8) > $OUT/${TAG}_cull_probe.log 2>&1
 echo "cull probe done"

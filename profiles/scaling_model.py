@@ -2,7 +2,7 @@
 """Predicts the strong-scaling curve of bench.py from ONE GPU.  The ranks of a tile split share
 nothing but the final gather (scene replicated, no per-frame communication), so the time of an
 N-GPU job is the slowest rank's time plus the gather.  Each rank's share is rendered alone on
-this GPU (bench.py --tile R/N) with the driver's arguments; the gather is priced from the
+this GPU (bench.py --tile R/N) with the driver's arguments (a step = 16 frames); the gather is priced from the
 payload (33 MB / N per rank, point-to-point to rank 0 over distinct xGMI links, ~45 GB/s
 effective per link + ~60 us of launch / rendezvous, profiles/r01_g_gather_bench.log).
 usage: python profiles/scaling_model.py [--steps 20 --warmup 5 --workload dragon]"""
