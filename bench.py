@@ -299,6 +299,7 @@ def roofline_block(m, pmc, source, num_cus):
             block["wave_cycles"] = {"issuing": round(pmc.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3),
                                     "waiting_for_memory": round(pmc.get("SQ_WAIT_ANY", 0.0) / wc, 3),
                                     "issue_stalled": round(pmc.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3)}
+        block["pmc_counters"] = {k: round(v, 1) for k, v in sorted(pmc.items())}
         block["real_bound"] = ("per-wave latency: dependent VALU chains + divergent 64-B gathers at 4 waves per SIMD; "
                                "VALU issue x lane utilisation is the fraction of the machine's lane-op rate in use")
     return block
@@ -380,6 +381,7 @@ def main():
         ctx = job.ctx
         # the accumulation image lives in a torch tensor so RCCL can gather it in place
         accum = torch.zeros((ctx.local_rows, width, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()           # (the fill ran on torch's stream, the passes run on the context's)
         ctx.bind_accumulation(accum.data_ptr(), accum.numel() * 4)
         max_rows = capi.tile_local_rows(height, 0, tile_world, BLOCK_ROWS)
         send = gathered = None
