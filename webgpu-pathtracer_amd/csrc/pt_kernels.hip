@@ -1039,7 +1039,8 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     };
     const int lcap = L.scene.leaf_cap;      // DEFER: capacity of a lane's leaf list
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };      // per-lane: only what the in-order walk counts under divergence
+    uint32_t u_rays = 0, u_box = 0, u_tri = 0, u_hit = 0, u_miss = 0, u_pix = 0, u_slow = 0;     // wave-uniform (scalar) counts
     int mode = M_DEAD;
     f3 o = F3(0.0f, 0.0f, 0.0f), d = o, ray_color = o, light = o, incoming = o;
     uint32_t gx = 0u, gy = 0u, ly = 0u, seed = 0u, slot = 0u;
@@ -1108,6 +1109,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             // (drain: whichever kind of step serves more lanes -- waiting for n_node == 0 would leave the lanes
             // that only have leaves idle for as long as the slowest descent takes)
             if (full || n_node == 0 || n_leaf >= L.leaf_min || (feed_empty && (L.tail_policy & 1) && n_leaf >= n_node)) {
+                u_tri += (uint32_t)n_leaf;       // every lane with a parked leaf tests one (wave-uniform count: scalar)
                 if (L.wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
                 if (has_leaf) {
                     nl--;
@@ -1115,7 +1117,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
                     const float4 pb = sc.tripk[(size_t)ti * 3 + 1];
                     const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
-                    cnt.tri++;
+                    
                     float t, u, v;
                     if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v)) {
                         bool take = t < best.t;
@@ -1126,6 +1128,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                 }
             } else {
+                u_box += 2u * (uint32_t)n_node;  // proper tree: both children of every popped node are tested
                 if (L.wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
                 if (has_node) {
                     sp--;
@@ -1141,7 +1144,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     }
                     const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
                     const uint32_t pf = __float_as_uint(p3.z);
-                    cnt.box += 2;                  // proper tree: both children exist
+                    
                     bool hl, hr;
                     f3 nl3 = F3(-PT_INF, -PT_INF, -PT_INF), nr3 = nl3;       // CULL: per-axis entry distances (-INF: never skipped)
                     if (((pre.flags & 8u) | pf) == 0u) {
@@ -1309,9 +1312,11 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         {
             const bool shade_hit = do_hit && mode == M_SHADE && best.tri >= 0;
             const bool shade_miss = do_b && mode == M_SHADE && best.tri < 0;
+            u_hit += (uint32_t)__popcll(__ballot(shade_hit));
+            u_miss += (uint32_t)__popcll(__ballot(shade_miss));
             bool ended = true;
             if (shade_hit) {          // trace(), raytrace.wgsl:380-395
-                cnt.hit++;
+                
                 f3 position, normal;
                 int32_t mi;
                 finish_hit(sc, o, d, best, position, normal, mi);
@@ -1332,7 +1337,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 ended = bounce >= un.max_bounces;
             }
             if (shade_miss) {         // :396-407
-                cnt.miss++;
+                
                 float u, v;
                 env_uv_from_dir(d, sinr, cosr, u, v);
                 const f3 env = sample_env(sc.env, sc.env_w, sc.env_h, u, v);
@@ -1374,6 +1379,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 const int take = min((int)__popcll(dead), 64 - cur_used);
                 const int rank = lane_rank(dead);
                 const bool mine = ((dead >> lane) & 1ull) != 0ull && rank < take;
+                bool got_job = false;
                 if (mine) {
                     const int j = cur_used + rank;
                     const int fslot = cur_tile / ntiles_frame, ftile = cur_tile - fslot * ntiles_frame;
@@ -1384,7 +1390,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                                     (uint32_t)px < res_w && (uint32_t)pgy < res_h;     // :425-427
                     if (ok) {
                         gx = (uint32_t)px; gy = (uint32_t)pgy; ly = (uint32_t)ply;
-                        cnt.pixels++;
+                        got_job = true;
                         slot = (uint32_t)fslot;
                         seed = (gx + gy * res_w) + (un.frame + slot) * 719393u + PT_SEED;    // :435-436
                         sample = 0;
@@ -1393,6 +1399,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     }
                 }
                 cur_used += take;
+                u_pix += (uint32_t)__popcll(__ballot(got_job));
                 // lanes that took a job (valid or not) leave the dead set; invalid ones rejoin next round
                 dead = __ballot(mode == M_DEAD && !need_segment && !mine);
             }
@@ -1427,16 +1434,22 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             }
         }
         if (L.wave_times) st_segment_lanes += (uint32_t)__popcll(__ballot(need_segment));
+        {
+            const uint32_t nseg = (uint32_t)__popcll(__ballot(need_segment));
+            u_rays += nseg;
+            if (sc.nnodes != 0) u_box += nseg;      // the root box test
+        }
+        bool slow_segment = false;
         if (need_segment) {
             // raySceneIntersect + the root test of rayBVHIntersect, raytrace.wgsl:155-164, 205-211
             best.t = PT_INF; best.u = 0.0f; best.v = 0.0f; best.tri = -1;
-            cnt.rays++;
+            
             mode = M_SHADE;
             if (sc.nnodes != 0) {
                 pre = ray_prepare(o, d, sc.flags);
-                if (pre.flags & 8u) cnt.slow++;
+                slow_segment = (pre.flags & 8u) != 0u;
                 if (CULL) cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
-                cnt.box++;
+                
                 if (ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
                     if (DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
                         stack[(PT_SM_LDS_DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu;
@@ -1449,6 +1462,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 }
             }
         }
+        u_slow += (uint32_t)__popcll(__ballot(slow_segment));
     }
 
     if (L.wave_times && lane == 0) {
@@ -1479,9 +1493,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             __hip_atomic_store(L.tile_counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    const uint32_t s_rays = wave_sum(cnt.rays), s_box = wave_sum(cnt.box), s_tri = wave_sum(cnt.tri);
-    const uint32_t s_hit = wave_sum(cnt.hit), s_miss = wave_sum(cnt.miss);
-    const uint32_t s_ovf = wave_sum(cnt.overflow), s_pix = wave_sum(cnt.pixels), s_slow = wave_sum(cnt.slow);
+    const uint32_t s_rays = u_rays, s_box = wave_sum(cnt.box) + u_box, s_tri = wave_sum(cnt.tri) + u_tri;
+    const uint32_t s_hit = u_hit, s_miss = u_miss;
+    const uint32_t s_ovf = wave_sum(cnt.overflow), s_pix = u_pix, s_slow = u_slow;
     if (lane == 0 && L.block_counters) {
         uint64_t *c = L.block_counters + (size_t)blockIdx.x * CNT_COUNT;
         c[CNT_RAYS] += s_rays; c[CNT_BOX] += s_box; c[CNT_TRI] += s_tri; c[CNT_HIT] += s_hit;
