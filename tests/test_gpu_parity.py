@@ -630,3 +630,87 @@ def test_no_cpu_fallback_symbols(built):
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "orc_" not in out
+
+
+def test_submit_frames_equals_frame_by_frame_submits(gpu_ctx, demo, env):
+    """mi3pt_submit_frames(mask, n) = n submits with only the frame counter moving
+    (renderer.ts:369-377): same image, and both uniform blocks are left at frame + n."""
+    w, h = 96, 72
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+    ctx.reset()
+    for f in range(2, 25):
+        pc.gpu_frame(ctx, pc.rt_uniforms(demo, w, h, frame=f, bounces=4), pc.acc_uniforms(w, h, f), mask)
+    want = ctx.read_texture(capi.TEX_ACCUMULATION)
+    ctx.reset()
+    ctx.set_uniforms(capi.PASS_RAYTRACE, pc.rt_uniforms(demo, w, h, frame=2, bounces=4).tobytes())
+    ctx.set_uniforms(capi.PASS_ACCUMULATE, pc.acc_uniforms(w, h, 2).tobytes())
+    ctx.submit_frames(mask, 20)
+    ctx.submit_frames(mask, 3)              # continues at frame 22: the blocks were advanced
+    got = ctx.read_texture(capi.TEX_ACCUMULATION)
+    assert pc.same_bits(got, want), pc.describe_diff(got, want)
+    ctx.resize(64, 64)
+
+
+def test_present_latest_shows_every_frame_once_the_canvas_is_looked_at(gpu_ctx, orc, demo, env):
+    """MI3PT_PRESENT_LATEST: sample frames that also present are queued like any other and the
+    canvas is drawn once per launched batch; a canvas read-back (or a FULLSCREEN-only submit)
+    first launches what is queued and draws it.  What can be observed equals MI3PT_PRESENT_EXACT,
+    which redraws from this very frame on every submit -- and the oracle."""
+    w, h = 80, 56
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    everything = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE | capi.SUBMIT_FULLSCREEN
+    fs = pc.fs_uniforms(w, h, 1.0, 1, 1)
+    canvases = {}
+    for mode in (capi.PRESENT_EXACT, capi.PRESENT_LATEST):
+        ctx.set_present_mode(mode)
+        ctx.reset()
+        ctx.set_uniforms(capi.PASS_FULLSCREEN, fs.tobytes())
+        for f in range(2, 22):              # 20 frames: one full batch + 4 queued frames in LATEST mode
+            pc.gpu_frame(ctx, pc.rt_uniforms(demo, w, h, frame=f, bounces=4), pc.acc_uniforms(w, h, f), everything)
+        canvases[mode] = (ctx.read_canvas_rgba8(), ctx.read_texture(capi.TEX_CANVAS), ctx.read_texture(capi.TEX_ACCUMULATION))
+        # a FULLSCREEN-only submit (render() after sampling stopped) shows the same
+        ctx.submit(capi.SUBMIT_FULLSCREEN)
+        assert np.array_equal(ctx.read_canvas_rgba8(), canvases[mode][0])
+    ctx.set_present_mode(capi.PRESENT_EXACT)
+    for k in range(3):
+        assert np.array_equal(canvases[capi.PRESENT_EXACT][k], canvases[capi.PRESENT_LATEST][k])
+    osc = pc.oracle_scene(orc, demo, env)
+    acc = np.zeros((h, w, 4), np.float32)
+    for f in range(2, 22):
+        img, _ = orc.raytrace(osc, pc.rt_uniforms(demo, w, h, frame=f, bounces=4).tobytes(), w, h)
+        acc = orc.accumulate(pc.acc_uniforms(w, h, f).tobytes(), w, h, img, acc)
+    want_f32, want_8 = orc.fullscreen(fs.tobytes(), acc)
+    assert pc.same_bits(canvases[capi.PRESENT_LATEST][1], want_f32)
+    assert np.array_equal(canvases[capi.PRESENT_LATEST][0], want_8)
+    ctx.resize(64, 64)
+
+
+def test_batch_capacity_and_launch_statistics(gpu_ctx, demo, env):
+    w, h = 640, 360
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    for nranks, want in ((1, 16), (2, 32), (8, 128), (16, 128)):
+        ctx.set_tile(0, nranks, 8)
+        ctx.resize(w, h)
+        assert ctx.batch_capacity() == want
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    ctx.enable_timing(True)
+    ctx.raytrace_launch_stats(reset=True)
+    ctx.set_uniforms(capi.PASS_RAYTRACE, pc.rt_uniforms(demo, w, h, frame=2, bounces=8).tobytes())
+    ctx.set_uniforms(capi.PASS_ACCUMULATE, pc.acc_uniforms(w, h, 2).tobytes())
+    ctx.submit_frames(capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE, 64)
+    total_ms, launches, frames = ctx.raytrace_launch_stats()
+    span_ms = ctx.raytrace_launch_span()
+    ctx.enable_timing(False)
+    assert (launches, frames) == (4, 64)
+    assert 0 < span_ms <= total_ms * 1.01          # launches overlap at their tails: the span is shorter than the sum
+    assert span_ms >= total_ms / 4                 # ... but not shorter than one launch
+    ctx.resize(64, 64)

@@ -98,7 +98,7 @@ struct mi3pt_ctx {
     bool env_sampling = false;  // mi3pt_set_env_sampling: the reference's dormant importance-sampling lines
     int tail_policy = 7;        // MI3PT_TAIL_POLICY: see RtLaunch::tail_policy
     int shade_split = 64;       // MI3PT_SHADE_SPLIT: see RtLaunch::shade_split (64: while lanes walk, only the larger group is served)
-    int leaf_min = 32;          // deferred-leaf walk: lanes with a parked leaf that trigger a triangle step (MI3PT_LEAF_MIN)
+    int leaf_min = 24;          // deferred-leaf walk: lanes with a parked leaf that trigger a triangle step (MI3PT_LEAF_MIN)
     int walk_min = 32;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
     int waves_per_cu = 16;      // 8 KB of LDS per one-wave workgroup, 128 VGPRs
     int top_packets = 64;       // MI3PT_TOP_PACKETS
