@@ -13,8 +13,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 static thread_local std::string g_last_error;
@@ -52,6 +54,13 @@ struct mi3pt_ctx {
     bool cull_dirty = true;         // triangles or tree changed since the last analysis
     bool cull_ok = false;           // analysis done and the tree admits the walk
     float cull_ka = 0.0f, cull_kb = 0.0f;   // scene constants of the distance bound
+    // wide (4-ary) packets for kernel variant 10, built with the cull analysis
+    bool wide_enabled = true;       // MI3PT_WIDE=0: variant 0 stops at 9
+    bool wide_ok = false;
+    void *d_wide = nullptr;
+    size_t nwide = 0;
+    int wide_leaf_cap = 0;
+    uint32_t wide_root = 0;
     int num_cus = 256;              // hipDeviceProp_t::multiProcessorCount
     // Debug: packet / triangle numbering (mi3pt_debug_set_packet_layout).  0 = breadth-first packets,
     // triangles as uploaded (shipped).  1 = packets in the reference's visiting order (node, right
@@ -252,6 +261,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     if (const char *e = std::getenv("MI3PT_TAIL_POLICY")) ctx->tail_policy = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_TOP_PACKETS")) ctx->top_packets = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_CULL")) ctx->cull_enabled = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MI3PT_WIDE")) ctx->wide_enabled = std::atoi(e) != 0;
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
     CREATE_TRY(hipMalloc(&ctx->d_env, env_bytes));
@@ -301,7 +311,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
     for (int k = 0; k < 2; k++)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     free_textures(ctx);
-    for (void *p : { ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
+    for (void *p : { ctx->d_wide, ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
                      (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
@@ -355,7 +365,7 @@ extern "C" int mi3pt_set_env_sampling(mi3pt_ctx *ctx, int enabled)
 extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
-    if (variant < 0 || variant > 9) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..9");
+    if (variant < 0 || variant > 10) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..10");
     if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
     return MI3PT_OK;
@@ -745,6 +755,9 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.tripk = static_cast<const float4 *>(ctx->d_tripk);
     s.leaf_rank = static_cast<const uint32_t *>(ctx->d_leaf_rank);
     s.leaf_cap = ctx->leaf_cap;
+    s.wide = static_cast<const float4 *>(ctx->d_wide);
+    s.wide_leaf_cap = ctx->wide_ok ? ctx->wide_leaf_cap : 0;
+    s.wide_root = ctx->wide_root;
     s.cdf = static_cast<const float4 *>(ctx->d_cdf);
     s.env_sampling = (ctx->env_sampling && ctx->d_cdf) ? 1 : 0;
     s.ntris = (uint32_t)ctx->ntris; s.nnodes = (uint32_t)ctx->nnodes; s.nmats = (uint32_t)ctx->nmats;
@@ -879,7 +892,7 @@ static inline uint32_t round_up_16(float f)
 static int prepare_cull(mi3pt_ctx *ctx)
 {
     if (!ctx->cull_dirty) return MI3PT_OK;
-    const bool wanted = ctx->variant == 9 || (ctx->variant == 0 && ctx->cull_enabled);
+    const bool wanted = ctx->variant == 9 || ctx->variant == 10 || (ctx->variant == 0 && ctx->cull_enabled);
     if (!wanted || ctx->layout_active || ctx->leaf_cap < 4 || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
         return MI3PT_OK;       // stays dirty: pick_variant falls back to the reference-counter walk
     if (int rc = flush_pending(ctx)) return rc;
@@ -1001,6 +1014,117 @@ static int prepare_cull(mi3pt_ctx *ctx)
         ctx->cull_ka = std::nextafter((float)ka, inf);
         ctx->cull_kb = std::nextafter((float)kb, inf);
     }
+    // ---- wide (4-ary) packets for the WIDE walk: absorb internal children into their parent, largest
+    // surface area first, while the node has fewer than four entries.  Only a child whose box contains
+    // its own children's boxes may be absorbed (pt_kernels.h, WidePacket: the monotonicity argument).
+    ctx->wide_ok = false;
+    if (!is_leaf(0)) {
+        std::vector<uint8_t> nested(n, 0);
+        for (size_t i = 0; i < n; i++) {
+            if (is_leaf(i)) continue;
+            const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+            bool ok = true;
+            for (int32_t c : { ldi(r, 32), ldi(r, 36) }) {
+                if (c < 0 || (size_t)c >= n) { ok = false; continue; }
+                const uint8_t *cr = src + (size_t)c * MI3PT_BVHNODE_STRIDE;
+                float mn[3], mx[3];
+                for (int k = 0; k < 3; k++) { mn[k] = ldf(cr, 4 * k); mx[k] = ldf(cr, 16 + 4 * k); }
+                if (!inside(r, mn, mx)) ok = false;
+            }
+            nested[i] = ok ? 1 : 0;
+        }
+        auto area = [&](size_t i) {
+            const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+            const double x = (double)ldf(r, 16) - ldf(r, 0), y = (double)ldf(r, 20) - ldf(r, 4), z = (double)ldf(r, 24) - ldf(r, 8);
+            const double a = x * y + x * z + y * z;
+            return a == a ? a : 0.0;
+        };
+        std::vector<uint32_t> wide_of(n, pt::REF_NONE);       // binary node -> wide packet index
+        std::vector<std::array<int32_t, 4>> kids;              // per wide packet: binary child nodes (-1: empty)
+        std::vector<uint32_t> owner;                           // per wide packet: the binary node it stands for
+        std::vector<uint32_t> queue;                           // breadth-first numbering
+        queue.push_back(0);
+        wide_of[0] = 0;
+        for (size_t qi = 0; qi < queue.size(); qi++) {
+            const uint32_t x = queue[qi];
+            const uint8_t *r = src + (size_t)x * MI3PT_BVHNODE_STRIDE;
+            int32_t set[4] = { ldi(r, 32), ldi(r, 36), -1, -1 };
+            int cnt = 2;
+            while (cnt < 4) {
+                int pick = -1;
+                double best_area = -1.0;
+                for (int k = 0; k < cnt; k++) {
+                    const int32_t c = set[k];
+                    if (c < 0 || is_leaf((size_t)c) || !nested[(size_t)c] || wide_of[(size_t)c] != pt::REF_NONE) continue;
+                    const double a = area((size_t)c);
+                    if (a > best_area) { best_area = a; pick = k; }
+                }
+                if (pick < 0) break;
+                const uint8_t *cr = src + (size_t)set[pick] * MI3PT_BVHNODE_STRIDE;
+                const int32_t cl = ldi(cr, 32), crr = ldi(cr, 36);
+                set[pick] = cl;
+                set[cnt++] = crr;
+            }
+            std::array<int32_t, 4> k4 = { set[0], set[1], set[2], set[3] };
+            kids.push_back(k4);
+            owner.push_back(x);
+            for (int k = 0; k < cnt; k++) {
+                const int32_t c = set[k];
+                if (c >= 0 && !is_leaf((size_t)c) && wide_of[(size_t)c] == pt::REF_NONE) {
+                    wide_of[(size_t)c] = (uint32_t)queue.size();
+                    queue.push_back((uint32_t)c);
+                }
+            }
+        }
+        // worst-case node-stack occupancy of the wide walk (every box hit, nothing skipped): internal entries only
+        size_t worst = 1;
+        {
+            std::vector<std::pair<uint32_t, uint32_t>> work;      // (wide packet, occupancy with it on top)
+            work.emplace_back(0u, 1u);
+            while (!work.empty()) {
+                const auto [w, occ] = work.back();
+                work.pop_back();
+                uint32_t ks[4];
+                int m = 0;
+                for (int k = 0; k < 4; k++) {
+                    const int32_t c = kids[w][k];
+                    if (c >= 0 && !is_leaf((size_t)c)) ks[m++] = wide_of[(size_t)c];
+                }
+                for (int i = 0; i < m; i++) {
+                    const uint32_t oc = occ - 1 + (uint32_t)(m - i);
+                    if (oc > worst) worst = oc;
+                    work.emplace_back(ks[m - 1 - i], oc);
+                }
+            }
+        }
+        const int cap = pt::SM_WIDE_LDS_DEPTH - (int)worst;
+        if (cap >= 8 && kids.size() < 0x7fffffffu) {
+            std::vector<pt::WidePacket> wp(kids.size());
+            std::memset(wp.data(), 0, wp.size() * sizeof(pt::WidePacket));
+            for (size_t w = 0; w < kids.size(); w++) {
+                pt::WidePacket &p = wp[w];
+                uint32_t cw[4] = { 0x7f80u, 0x7f80u, 0x7f80u, 0x7f80u };
+                for (int k = 0; k < 4; k++) {
+                    const int32_t c = kids[w][k];
+                    float *box = k < 2 ? p.b01 + 6 * k : p.b23 + 6 * (k - 2);
+                    if (c < 0) { p.ref[k] = pt::REF_NONE; continue; }
+                    const uint8_t *cr = src + (size_t)c * MI3PT_BVHNODE_STRIDE;
+                    std::memcpy(box, cr + 0, 12);
+                    std::memcpy(box + 3, cr + 16, 12);
+                    p.ref[k] = is_leaf((size_t)c) ? (0x80000000u | (uint32_t)ldi(cr, 40)) : wide_of[(size_t)c];
+                    cw[k] = round_up_16(wmax[(size_t)c]);
+                    if (!node_box_safe(src, (size_t)c)) p.flags |= 1u << k;
+                }
+                p.cull01 = (cw[0] << 16) | cw[1];
+                p.cull23 = (cw[2] << 16) | cw[3];
+            }
+            if (int rc = replace_buffer(ctx, &ctx->d_wide, wp.data(), wp.size() * sizeof(pt::WidePacket))) return rc;
+            ctx->nwide = wp.size();
+            ctx->wide_leaf_cap = cap;
+            ctx->wide_root = 0;
+            ctx->wide_ok = true;
+        }
+    }
     ctx->cull_ok = true;
     ctx->cull_dirty = false;
     ctx->main_dirty = true;
@@ -1025,7 +1149,9 @@ static int pick_variant(const mi3pt_ctx *ctx)
     if (ctx->env_sampling) return 2;               // the dormant path lives in the per-pixel kernel only
     const bool defer_ok = ctx->leaf_cap >= 4;      // see mi3pt_upload_bvh: leaves may be tested out of order
     const bool cull_ok = defer_ok && ctx->cull_ok && !ctx->cull_dirty;     // see prepare_cull
-    if (ctx->variant == 0) return cull_ok && ctx->cull_enabled ? 9 : (defer_ok ? 7 : 4);
+    const bool wide_ok = cull_ok && ctx->wide_ok;
+    if (ctx->variant == 0) return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? 10 : 9) : (defer_ok ? 7 : 4);
+    if (ctx->variant == 10 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);
     if (ctx->variant == 9 && !cull_ok) return defer_ok ? 7 : 4;
     if (ctx->variant >= 7 && !defer_ok) return ctx->variant == 8 ? 6 : 4;
     return ctx->variant;

@@ -15,6 +15,7 @@ constexpr int PT_MAX_RESIDENT_WAVES = 256 * 24;
 #define PT_SM_LDS_DEPTH_VALUE 32
 #endif
 constexpr int SM_LDS_DEPTH = PT_SM_LDS_DEPTH_VALUE;
+constexpr int SM_WIDE_LDS_DEPTH = 40;      // WIDE walk: 10 KB per wave, 16 waves = the CU's 160 KB
 
 
 // per-pass counters, see mi3pt_counter in include/mi3pt.h
@@ -39,6 +40,23 @@ struct NodePacket {
 };
 static_assert(sizeof(NodePacket) == 64, "packet is one 64-B line");
 
+// "Wide packet": up to FOUR child boxes of a node obtained by absorbing internal children into their
+// parent (a child is absorbed only if its box contains its own children's boxes, and boxes are bit
+// copies of the uploaded records).  The fp32 slab test is monotone under nesting (every operation in
+// it is a correctly rounded, hence monotone, function of the box coordinates), so a ray that the
+// reference's test rejects at an absorbed node is rejected at each of that node's children too: the
+// wide walk reaches exactly the leaves the reference's walk reaches, in half the node steps.
+// 128 bytes = two lines; used by the WIDE walk (kernel variant 10).
+struct WidePacket {
+    float b01[12];           // boxes 0 and 1 in the NodePacket arrangement: mn0 mx0 mn1 mx1
+    float b23[12];           // boxes 2 and 3
+    uint32_t ref[4];         // child references (leaf: REF_LEAF | triangle, else wide packet index, REF_NONE: empty slot)
+    uint32_t cull01, cull23; // culling weights, 16 bits each (as NodePacket::cull)
+    uint32_t flags;          // bits 0-3: box i has a non-zero coordinate outside [2^-70, 2^60]
+    uint32_t pad;
+};
+static_assert(sizeof(WidePacket) == 128, "two 64-B lines");
+
 // 48-byte triangle record for intersection only (positions + material index); the
 // vertex normals (only needed for the one closest hit per ray) stay in the uploaded
 // 112-B records.
@@ -55,9 +73,12 @@ struct SceneRefs {
     const float4 *mats;     // reference layout, 4 x float4 per material
     const float4 *env;      // rgba32float texels
     const float4 *packets;  // NodePacket array (internal nodes, breadth-first), or null
+    const float4 *wide;     // WidePacket array (WIDE walk), or null
     const float4 *tripk;    // TriPacket array, or null
     const uint32_t *leaf_rank;  // per triangle: rank of its leaf in the reference's visiting order
     int32_t leaf_cap;       // > 0: leaves may be tested out of order; LDS slots available for deferred leaves
+    int32_t wide_leaf_cap;  // the same for the WIDE walk's 40-entry stack (>= 8 or the walk is not offered)
+    uint32_t wide_root;     // reference of node 0 in wide-packet terms
     const float4 *cdf;      // environment CDF texels (R marginal, G conditional, B sin-weighted luminance), or null
     int32_t env_sampling;   // 1: the reference's dormant importance-sampling lines run (per-pixel kernels only)
     uint32_t ntris, nnodes, nmats, npackets;

@@ -949,14 +949,19 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
 // returned t > best.t in the reference's own fp32 Moller-Trumbore arithmetic -- so the closest
 // hit, its (t, u, v) and the tie rule are untouched and images stay bit-identical, while the
 // box / triangle COUNTERS drop below the reference's.  Children are pushed far first, near last.
-template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false>
+//
+// WIDE (kernel variant 10, needs CULL): the walk runs on 4-ary "wide packets" (pt_kernels.h) -- up
+// to four child boxes per node step, half as many dependent round trips per ray.  The leaves reached
+// are exactly the reference's (monotone slab test under nesting); 40 stack entries per lane in LDS.
+template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false, bool WIDE = false>
 __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
 {
+    constexpr int DEPTH = WIDE ? SM_WIDE_LDS_DEPTH : PT_SM_LDS_DEPTH;      // LDS stack entries per lane (deferred walks)
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
     // deeper entries (rare: the stack holds about one entry per tree level) go to this
     // wave's slice of a global overflow area, so the 64-entry abort semantics are kept
     // while a wave only needs 8 KB of LDS.
-    __shared__ uint32_t stack_lds[PT_SM_LDS_DEPTH * 64];
+    __shared__ uint32_t stack_lds[DEPTH * 64];
     // BVH node packets staged in LDS: packets are numbered breadth-first, so the first
     // PT_SM_TOP_PACKETS of them ARE the top levels of the tree (raytrace.ts:667-678), which
     // every ray walks.  One-wave workgroups (a multi-wave workgroup would hold its LDS and
@@ -1037,7 +1042,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         st_mark = now;
         st_kind = kind;
     };
-    const int lcap = L.scene.leaf_cap;      // DEFER: capacity of a lane's leaf list
+    const int lcap = WIDE ? L.scene.wide_leaf_cap : L.scene.leaf_cap;      // DEFER: capacity of a lane's leaf list
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };      // per-lane: only what the in-order walk counts under divergence
     uint32_t u_rays = 0, u_box = 0, u_tri = 0, u_hit = 0, u_miss = 0, u_pix = 0, u_slow = 0;     // wave-uniform (scalar) counts
@@ -1105,7 +1110,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             const bool trav = mode == M_TRAV;
             const bool has_node = trav && sp > 0, has_leaf = trav && nl > 0;
             const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
-            const bool full = __ballot(trav && nl > lcap - 2) != 0ull;      // a node step may park two more
+            const bool full = __ballot(trav && nl > lcap - (WIDE ? 4 : 2)) != 0ull;      // a node step may park two (WIDE: four) more
             // (drain: whichever kind of step serves more lanes -- waiting for n_node == 0 would leave the lanes
             // that only have leaves idle for as long as the slowest descent takes)
             if (full || n_node == 0 || n_leaf >= L.leaf_min || (feed_empty && (L.tail_policy & 1) && n_leaf >= n_node)) {
@@ -1113,7 +1118,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (L.wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
                 if (has_leaf) {
                     nl--;
-                    const uint32_t ti = stack[(PT_SM_LDS_DEPTH - 1 - nl) * 64];
+                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64];
                     const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
                     const float4 pb = sc.tripk[(size_t)ti * 3 + 1];
                     const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
@@ -1128,8 +1133,69 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                 }
             } else {
-                u_box += 2u * (uint32_t)n_node;  // proper tree: both children of every popped node are tested
+                if (!WIDE) u_box += 2u * (uint32_t)n_node;  // proper tree: both children of every popped node are tested (WIDE: per lane)
                 if (L.wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
+                if (WIDE) {
+                  if (has_node) {
+                    sp--;
+                    const uint32_t ref = stack[sp * 64];
+                    const float4 *P = sc.wide + (size_t)ref * 8;
+                    const float4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3], q4 = P[4], q5 = P[5], q6 = P[6], q7 = P[7];
+                    uint32_t cr[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
+                    const uint32_t wf = __float_as_uint(q7.z);
+                    bool hit[4];
+                    f3 tn[4];
+                    tn[0] = tn[1] = tn[2] = tn[3] = F3(-PT_INF, -PT_INF, -PT_INF);
+                    if (((pre.flags & 8u) | (wf & 15u)) == 0u) {
+                        hit[0] = ray_aabb_fast_t(o, d, pre, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn[0]);
+                        hit[1] = ray_aabb_fast_t(o, d, pre, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn[1]);
+                        hit[2] = ray_aabb_fast_t(o, d, pre, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tn[2]);
+                        hit[3] = ray_aabb_fast_t(o, d, pre, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tn[3]);
+                    } else {
+                        hit[0] = ray_aabb_pre(o, d, pre, (wf & 1u) != 0u, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                        hit[1] = ray_aabb_pre(o, d, pre, (wf & 2u) != 0u, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                        hit[2] = ray_aabb_pre(o, d, pre, (wf & 4u) != 0u, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y);
+                        hit[3] = ray_aabb_pre(o, d, pre, (wf & 8u) != 0u, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w);
+                    }
+                    // distance bound per child, entry distances as sort keys
+                    const float rc = fmaf(cull_ka, best.t, cull_kb);
+                    const float bt = best.t * 1.00000095367431640625f;
+                    const uint32_t w01 = __float_as_uint(q7.x), w23 = __float_as_uint(q7.y);
+                    const float wgt[4] = { __uint_as_float(w01 & 0xffff0000u), __uint_as_float(w01 << 16),
+                                           __uint_as_float(w23 & 0xffff0000u), __uint_as_float(w23 << 16) };
+                    float key[4];
+                    uint32_t nvalid = 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool valid = cr[k] != PT_REF_NONE;
+                        nvalid += valid ? 1u : 0u;
+                        const float dk = wgt[k] * rc;
+                        const float tc = fmaxf(fmaxf(fmaf(-dk, fabsf(pre.ix), tn[k].x), fmaf(-dk, fabsf(pre.iy), tn[k].y)), fmaf(-dk, fabsf(pre.iz), tn[k].z));
+                        hit[k] = hit[k] && valid && !(tc > bt);
+                        key[k] = fmaxf(fmaxf(tn[k].x, tn[k].y), tn[k].z);
+                    }
+                    cnt.box += nvalid;
+                    // far first, near last (popped first): sort the four entries by entry distance, descending
+#define PT_CSWAP(A, B)                                                                         \
+                    if (key[A] < key[B]) {                                                     \
+                        const float tk = key[A]; key[A] = key[B]; key[B] = tk;                 \
+                        const uint32_t tr_ = cr[A]; cr[A] = cr[B]; cr[B] = tr_;                \
+                        const bool th = hit[A]; hit[A] = hit[B]; hit[B] = th;                  \
+                    }
+                    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+                    // sp + nl <= DEPTH - 4 here (wide_leaf_cap = DEPTH - worst-case stack, nl <= cap - 4): slot sp and
+                    // slot DEPTH - 1 - nl are free at each of the four pushes: unconditional stores, the counts select
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool lf = (cr[k] & PT_REF_LEAF) != 0u;
+                        stack[(lf ? DEPTH - 1 - nl : sp) * 64] = lf ? (cr[k] & 0x7fffffffu) : cr[k];
+                        nl += (hit[k] && lf) ? 1 : 0;
+                        sp += (hit[k] && !lf) ? 1 : 0;
+                    }
+                    if (sp == 0 && nl == 0) mode = M_SHADE;
+                  }
+                } else
                 if (has_node) {
                     sp--;
                     const uint32_t ref = stack[sp * 64];
@@ -1181,10 +1247,10 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     // sp + nl <= 30 here (leaf_cap = 32 - worst-case stack, nl <= leaf_cap - 2), so slot sp
                     // and slot 31 - nl are both free: the stores are unconditional, the counts select
                     const bool ll = (r1 & PT_REF_LEAF) != 0u, rl = (r2 & PT_REF_LEAF) != 0u;
-                    stack[(ll ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = ll ? (r1 & 0x7fffffffu) : r1;
+                    stack[(ll ? DEPTH - 1 - nl : sp) * 64] = ll ? (r1 & 0x7fffffffu) : r1;
                     nl += (hl && ll) ? 1 : 0;
                     sp += (hl && !ll) ? 1 : 0;
-                    stack[(rl ? PT_SM_LDS_DEPTH - 1 - nl : sp) * 64] = rl ? (r2 & 0x7fffffffu) : r2;
+                    stack[(rl ? DEPTH - 1 - nl : sp) * 64] = rl ? (r2 & 0x7fffffffu) : r2;
                     nl += (hr && rl) ? 1 : 0;
                     sp += (hr && !rl) ? 1 : 0;
                     if (sp == 0 && nl == 0) mode = M_SHADE;
@@ -1452,10 +1518,10 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 
                 if (ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
                     if (DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
-                        stack[(PT_SM_LDS_DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu;
+                        stack[(DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu;
                         sp = 0; nl = 1;
                     } else {
-                        st_store(0, sc.root_ref);
+                        st_store(0, WIDE ? sc.wide_root : sc.root_ref);
                         sp = 1; nl = 0;
                     }
                     mode = M_TRAV;
@@ -1528,7 +1594,10 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
     const dim3 block(64);
     if (variant >= 3) {
         const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu, L.num_cus));
-        if (variant == 9) {                              // deferred leaves + exact-image distance culling
+        if (variant == 10) {                             // the culling walk on 4-ary wide packets
+            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true, true>), grid, block, 0, s, L);
+            else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true>), grid, block, 0, s, L);
+        } else if (variant == 9) {                       // deferred leaves + exact-image distance culling
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true>), grid, block, 0, s, L);
         } else if (variant == 3) {
