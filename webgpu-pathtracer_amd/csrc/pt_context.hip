@@ -44,6 +44,7 @@ struct mi3pt_ctx {
     void *d_packets = nullptr, *d_tripk = nullptr;
     void *d_leaf_rank = nullptr;          // per triangle: position of its leaf in the reference's visiting order
     int leaf_cap = 0;                     // LDS slots left for deferred leaves (0 = scene must be walked in order)
+    bool cull_stack_ok = false;           // the near-first walks' order-independent worst-case stack fits (upload_bvh)
     size_t ntris = 0, nnodes = 0, nmats = 0, npackets = 0;
     uint32_t root_ref = 0;
     uint32_t scene_flags = 0;
@@ -546,6 +547,7 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
     // i.e. the walk's worst-case stack occupancy (every box hit) stays below 64.
     std::vector<uint32_t> leaf_rank((size_t)(max_tri + 1 > 0 ? max_tri + 1 : 1), 0xffffffffu);
     int leaf_cap = 0;
+    bool cull_stack_ok = false;
     {
         std::vector<uint32_t> st;
         std::vector<uint8_t> seen(n, 0);
@@ -582,11 +584,36 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
         // nodes only in the deferred walk) from the bottom, parked leaves from the top.
         if (proper && worst < 64 && (int)worst_internal <= pt::SM_LDS_DEPTH - 4) leaf_cap = pt::SM_LDS_DEPTH - (int)worst_internal;
         (void)visited;      // nodes the root does not reach are never walked by the reference either
+        // The culling walks push the nearer child last, so ANY child may be the one that is descended
+        // first with all its internal siblings still stacked: occupancy(child) = occupancy(parent) - 1 +
+        // (internal children of the parent).  The maximum over the tree bounds their node stack whatever
+        // the order; it has to fit the LDS slots plus the overflow slice (pt_kernels.h SM_CULL_STACK_MAX).
+        cull_stack_ok = false;
+        if (proper && worst < 64 && !is_leaf(0)) {
+            std::vector<std::pair<uint32_t, uint32_t>> work;
+            work.emplace_back(0u, 1u);
+            size_t worst_any = 1;
+            while (!work.empty()) {
+                const auto [node, occ] = work.back();
+                work.pop_back();
+                const uint8_t *r = src + (size_t)node * MI3PT_BVHNODE_STRIDE;
+                const uint32_t kids[2] = { (uint32_t)ldi(r, 32), (uint32_t)ldi(r, 36) };
+                const uint32_t m = (is_leaf(kids[0]) ? 0u : 1u) + (is_leaf(kids[1]) ? 0u : 1u);
+                for (uint32_t c : kids) {
+                    if (is_leaf(c)) continue;
+                    const uint32_t oc = occ - 1u + m;
+                    if (oc > worst_any) worst_any = oc;
+                    work.emplace_back(c, oc);
+                }
+            }
+            cull_stack_ok = worst_any <= (size_t)pt::SM_CULL_STACK_MAX;
+        }
     }
     if (int rc = replace_buffer(ctx, &ctx->d_nodes, bytes, nbytes)) return rc;
     if (int rc = replace_buffer(ctx, &ctx->d_packets, pk.data(), pk.size() * sizeof(pt::NodePacket))) return rc;
     if (int rc = replace_buffer(ctx, &ctx->d_leaf_rank, leaf_rank.data(), leaf_rank.size() * sizeof(uint32_t))) return rc;
     ctx->leaf_cap = leaf_cap;
+    ctx->cull_stack_ok = cull_stack_ok;
     ctx->nnodes = n;
     ctx->npackets = npackets;
     ctx->root_ref = ref_of(0);
@@ -893,7 +920,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
 {
     if (!ctx->cull_dirty) return MI3PT_OK;
     const bool wanted = ctx->variant == 9 || ctx->variant == 10 || (ctx->variant == 0 && ctx->cull_enabled);
-    if (!wanted || ctx->layout_active || ctx->leaf_cap < 4 || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
+    if (!wanted || ctx->layout_active || ctx->leaf_cap < 4 || !ctx->cull_stack_ok || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
         return MI3PT_OK;       // stays dirty: pick_variant falls back to the reference-counter walk
     if (int rc = flush_pending(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1076,7 +1103,8 @@ static int prepare_cull(mi3pt_ctx *ctx)
                 }
             }
         }
-        // worst-case node-stack occupancy of the wide walk (every box hit, nothing skipped): internal entries only
+        // worst-case node-stack occupancy of the wide walk, whatever the order the children are pushed in
+        // (every box hit, nothing skipped, any child possibly descended first): internal entries only
         size_t worst = 1;
         {
             std::vector<std::pair<uint32_t, uint32_t>> work;      // (wide packet, occupancy with it on top)
@@ -1085,20 +1113,19 @@ static int prepare_cull(mi3pt_ctx *ctx)
                 const auto [w, occ] = work.back();
                 work.pop_back();
                 uint32_t ks[4];
-                int m = 0;
+                uint32_t m = 0;
                 for (int k = 0; k < 4; k++) {
                     const int32_t c = kids[w][k];
                     if (c >= 0 && !is_leaf((size_t)c)) ks[m++] = wide_of[(size_t)c];
                 }
-                for (int i = 0; i < m; i++) {
-                    const uint32_t oc = occ - 1 + (uint32_t)(m - i);
+                for (uint32_t i = 0; i < m; i++) {
+                    const uint32_t oc = occ - 1u + m;
                     if (oc > worst) worst = oc;
-                    work.emplace_back(ks[m - 1 - i], oc);
+                    work.emplace_back(ks[i], oc);
                 }
             }
         }
-        const int cap = pt::SM_WIDE_LDS_DEPTH - (int)worst;
-        if (cap >= 8 && kids.size() < 0x7fffffffu) {
+        if (worst <= (size_t)pt::SM_CULL_STACK_MAX && kids.size() < 0x7fffffffu) {
             std::vector<pt::WidePacket> wp(kids.size());
             std::memset(wp.data(), 0, wp.size() * sizeof(pt::WidePacket));
             for (size_t w = 0; w < kids.size(); w++) {
@@ -1120,7 +1147,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
             }
             if (int rc = replace_buffer(ctx, &ctx->d_wide, wp.data(), wp.size() * sizeof(pt::WidePacket))) return rc;
             ctx->nwide = wp.size();
-            ctx->wide_leaf_cap = cap;
+            ctx->wide_leaf_cap = pt::SM_CULL_LEAF_CAP;
             ctx->wide_root = 0;
             ctx->wide_ok = true;
         }
@@ -1148,7 +1175,7 @@ static int pick_variant(const mi3pt_ctx *ctx)
 {
     if (ctx->env_sampling) return 2;               // the dormant path lives in the per-pixel kernel only
     const bool defer_ok = ctx->leaf_cap >= 4;      // see mi3pt_upload_bvh: leaves may be tested out of order
-    const bool cull_ok = defer_ok && ctx->cull_ok && !ctx->cull_dirty;     // see prepare_cull
+    const bool cull_ok = defer_ok && ctx->cull_stack_ok && ctx->cull_ok && !ctx->cull_dirty;     // see prepare_cull
     const bool wide_ok = cull_ok && ctx->wide_ok;
     if (ctx->variant == 0) return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? 10 : 9) : (defer_ok ? 7 : 4);
     if (ctx->variant == 10 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);

@@ -15,7 +15,13 @@ constexpr int PT_MAX_RESIDENT_WAVES = 256 * 24;
 #define PT_SM_LDS_DEPTH_VALUE 32
 #endif
 constexpr int SM_LDS_DEPTH = PT_SM_LDS_DEPTH_VALUE;
-constexpr int SM_WIDE_LDS_DEPTH = 40;      // WIDE walk: 10 KB per wave, 16 waves = the CU's 160 KB
+// The culling walks (CULL, WIDE) visit children near first, so their stack occupancy is not the reference order's.
+// They keep a fixed leaf list of SM_CULL_LEAF_CAP entries at the top of the LDS column, node entries in the
+// SM_LDS_DEPTH - SM_CULL_LEAF_CAP slots below it, and deeper node entries (rare) in the wave's global overflow slice
+// (PT_MAX_STACK - SM_LDS_DEPTH = 32 more per lane); the context offers them only when the order-independent worst case
+// (every box hit, every child possibly first) fits: SM_CULL_STACK_MAX entries.
+constexpr int SM_CULL_LEAF_CAP = 8;
+constexpr int SM_CULL_STACK_MAX = SM_LDS_DEPTH - SM_CULL_LEAF_CAP + 32;
 
 
 // per-pass counters, see mi3pt_counter in include/mi3pt.h
@@ -77,7 +83,7 @@ struct SceneRefs {
     const float4 *tripk;    // TriPacket array, or null
     const uint32_t *leaf_rank;  // per triangle: rank of its leaf in the reference's visiting order
     int32_t leaf_cap;       // > 0: leaves may be tested out of order; LDS slots available for deferred leaves
-    int32_t wide_leaf_cap;  // the same for the WIDE walk's 40-entry stack (>= 8 or the walk is not offered)
+    int32_t wide_leaf_cap;  // > 0: the WIDE walk is offered (wide packets built, stack bound holds)
     uint32_t wide_root;     // reference of node 0 in wide-packet terms
     const float4 *cdf;      // environment CDF texels (R marginal, G conditional, B sin-weighted luminance), or null
     int32_t env_sampling;   // 1: the reference's dormant importance-sampling lines run (per-pixel kernels only)

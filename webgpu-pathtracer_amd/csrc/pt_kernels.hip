@@ -952,11 +952,12 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
 //
 // WIDE (kernel variant 10, needs CULL): the walk runs on 4-ary "wide packets" (pt_kernels.h) -- up
 // to four child boxes per node step, half as many dependent round trips per ray.  The leaves reached
-// are exactly the reference's (monotone slab test under nesting); 40 stack entries per lane in LDS.
+// are exactly the reference's (monotone slab test under nesting).
 template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false, bool WIDE = false>
 __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
 {
-    constexpr int DEPTH = WIDE ? SM_WIDE_LDS_DEPTH : PT_SM_LDS_DEPTH;      // LDS stack entries per lane (deferred walks)
+    constexpr int DEPTH = PT_SM_LDS_DEPTH;                  // LDS stack entries per lane
+    constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
     // deeper entries (rare: the stack holds about one entry per tree level) go to this
     // wave's slice of a global overflow area, so the 64-entry abort semantics are kept
@@ -992,6 +993,25 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     };
     const SceneRefs &sc = L.scene;
     const RtUniforms &un = L.un;
+    int sp = 0;
+    int nl = 0;              // DEFER: leaves waiting in this lane's list (LDS slots DEPTH - 1, DEPTH - 2, ...)
+    // Culling walks: node entries [0, NCAP) in LDS, deeper ones in the overflow slice; leaves in the LCAP slots on top.
+    // An entry that is not taken (box missed / skipped) may still be written to the free slot `sp` (no select on the
+    // store); in the overflow range only entries that are taken are written.
+    auto cull_pop = [&]() -> uint32_t {
+        sp--;
+        uint32_t v = stack[(sp < NCAP ? sp : 0) * 64];
+        asm volatile("" : "+v"(v));          // keep this a ds_read of its own
+        if (sp >= NCAP) v = ovf[(sp - NCAP) * 64];
+        return v;
+    };
+    auto cull_push = [&](uint32_t ref, bool take) {
+        const bool lf = (ref & PT_REF_LEAF) != 0u;
+        if (lf || sp < NCAP) stack[(lf ? DEPTH - 1 - nl : sp) * 64] = lf ? (ref & 0x7fffffffu) : ref;
+        else if (take) ovf[(sp - NCAP) * 64] = ref;
+        nl += (take && lf) ? 1 : 0;
+        sp += (take && !lf) ? 1 : 0;
+    };
     const int tiles_x = (L.tile.tex_w + 7) >> 3;
     // A launch covers L.nframes consecutive frames: job = (frame slot, 8x8 tile), frame-major.
     const int ntiles_frame = tiles_x * ((L.tile.local_rows + 7) >> 3);
@@ -1042,7 +1062,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         st_mark = now;
         st_kind = kind;
     };
-    const int lcap = WIDE ? L.scene.wide_leaf_cap : L.scene.leaf_cap;      // DEFER: capacity of a lane's leaf list
+    const int lcap = CULL ? LCAP : L.scene.leaf_cap;      // DEFER: capacity of a lane's leaf list
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };      // per-lane: only what the in-order walk counts under divergence
     uint32_t u_rays = 0, u_box = 0, u_tri = 0, u_hit = 0, u_miss = 0, u_pix = 0, u_slow = 0;     // wave-uniform (scalar) counts
@@ -1050,8 +1070,6 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     f3 o = F3(0.0f, 0.0f, 0.0f), d = o, ray_color = o, light = o, incoming = o;
     uint32_t gx = 0u, gy = 0u, ly = 0u, seed = 0u, slot = 0u;
     int32_t bounce = 0, sample = 0;
-    int sp = 0;
-    int nl = 0;              // DEFER: leaves waiting in this lane's list (LDS slots 31, 30, ...)
     Best best;
     best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
     RayPre pre;
@@ -1137,8 +1155,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (L.wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
                 if (WIDE) {
                   if (has_node) {
-                    sp--;
-                    const uint32_t ref = stack[sp * 64];
+                    const uint32_t ref = cull_pop();
                     const float4 *P = sc.wide + (size_t)ref * 8;
                     const float4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3], q4 = P[4], q5 = P[5], q6 = P[6], q7 = P[7];
                     uint32_t cr[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
@@ -1184,21 +1201,16 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     }
                     PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
-                    // sp + nl <= DEPTH - 4 here (wide_leaf_cap = DEPTH - worst-case stack, nl <= cap - 4): slot sp and
-                    // slot DEPTH - 1 - nl are free at each of the four pushes: unconditional stores, the counts select
+                    // nl <= LCAP - 4 before the step (the `full` rule): the four leaf slots are free
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool lf = (cr[k] & PT_REF_LEAF) != 0u;
-                        stack[(lf ? DEPTH - 1 - nl : sp) * 64] = lf ? (cr[k] & 0x7fffffffu) : cr[k];
-                        nl += (hit[k] && lf) ? 1 : 0;
-                        sp += (hit[k] && !lf) ? 1 : 0;
-                    }
+                    for (int k = 0; k < 4; k++) cull_push(cr[k], hit[k]);
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                   }
                 } else
                 if (has_node) {
-                    sp--;
-                    const uint32_t ref = stack[sp * 64];
+                    uint32_t ref;
+                    if (CULL) ref = cull_pop();
+                    else { sp--; ref = stack[sp * 64]; }
                     float4 p0, p1, p2, p3;
                     if (TOPLDS && ref < ntop) {       // top of the tree: this wave's LDS copy
                         p0 = top_lds[ref * 4 + 0]; p1 = top_lds[ref * 4 + 1];
@@ -1246,13 +1258,18 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     }
                     // sp + nl <= 30 here (leaf_cap = 32 - worst-case stack, nl <= leaf_cap - 2), so slot sp
                     // and slot 31 - nl are both free: the stores are unconditional, the counts select
-                    const bool ll = (r1 & PT_REF_LEAF) != 0u, rl = (r2 & PT_REF_LEAF) != 0u;
-                    stack[(ll ? DEPTH - 1 - nl : sp) * 64] = ll ? (r1 & 0x7fffffffu) : r1;
-                    nl += (hl && ll) ? 1 : 0;
-                    sp += (hl && !ll) ? 1 : 0;
-                    stack[(rl ? DEPTH - 1 - nl : sp) * 64] = rl ? (r2 & 0x7fffffffu) : r2;
-                    nl += (hr && rl) ? 1 : 0;
-                    sp += (hr && !rl) ? 1 : 0;
+                    if (CULL) {
+                        cull_push(r1, hl);
+                        cull_push(r2, hr);
+                    } else {
+                        const bool ll = (r1 & PT_REF_LEAF) != 0u, rl = (r2 & PT_REF_LEAF) != 0u;
+                        stack[(ll ? DEPTH - 1 - nl : sp) * 64] = ll ? (r1 & 0x7fffffffu) : r1;
+                        nl += (hl && ll) ? 1 : 0;
+                        sp += (hl && !ll) ? 1 : 0;
+                        stack[(rl ? DEPTH - 1 - nl : sp) * 64] = rl ? (r2 & 0x7fffffffu) : r2;
+                        nl += (hr && rl) ? 1 : 0;
+                        sp += (hr && !rl) ? 1 : 0;
+                    }
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                 }
             }
