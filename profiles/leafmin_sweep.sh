@@ -1,0 +1,4 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+run() { python bench.py --no-pmc --no-cpu-baseline --steps 8 2>/dev/null | python -c 'import sys,json; j=json.loads(sys.stdin.readlines()[-1]); print(j["value"], j["also"]["demo"]["value"])'; }
+for lm in 16 24 32 40; do echo "leaf_min $lm: $(MI3PT_LEAF_MIN=$lm run)"; done

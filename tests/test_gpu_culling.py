@@ -130,6 +130,79 @@ def test_boxes_that_do_not_bound_their_triangles_are_never_skipped(gpu_ctx, orc,
     ctx.resize(64, 64)
 
 
+def _comb_scene(depth=40):
+    """A hand-made tree that drives the near-first walks' node stack past its LDS part: a spine
+    of `depth` internal nodes, each with an internal side branch (two triangles) that lies BEHIND
+    the rest of the spine as seen from the camera.  All boxes span the whole x / y range, so a ray
+    that misses every triangle still enters every box: the walk descends the (nearer) spine first
+    and one side branch per level piles up -- `depth` entries, where the LDS holds 24."""
+    pos, leaves = [], []
+    z_of = lambda k: -40.0 + k               # side branch k sits at z_of(k): farther from the camera (z = +5) for small k
+    for k in range(depth + 1):
+        for j in range(2):
+            x0 = 0.25 + 0.3 * j
+            pos.append([[x0, -0.4, z_of(k) + 0.02 * j], [x0 + 0.25, -0.4, z_of(k) + 0.02 * j], [x0 + 0.1, 0.5, z_of(k) + 0.02 * j]])
+    pos = np.array(pos, np.float64)
+    ntri = len(pos)
+    tris = layout.pack_triangles(pos, np.tile(np.array([0.0, 0.0, 1.0]), (ntri, 3, 1)), np.zeros(ntri, int))
+    nodes = np.zeros(2 * ntri - 1, layout.BVH_NODE)
+
+    def put(i, zlo, zhi, leaf=-1, left=-1, right=-1):
+        nodes[i]["min"], nodes[i]["max"] = (-1.0, -1.0, zlo - 0.1), (1.0, 1.0, zhi + 0.1)
+        nodes[i]["isLeaf"], nodes[i]["left"], nodes[i]["right"], nodes[i]["triangleIndex"] = (1 if leaf >= 0 else 0), left, right, leaf
+
+    idx = 0
+    for k in range(depth):                   # spine node k at idx: left = side branch k (idx+1, leaves idx+2, idx+3), right = idx+4
+        put(idx, z_of(k), z_of(depth), left=idx + 1, right=idx + 4)
+        put(idx + 1, z_of(k), z_of(k), left=idx + 2, right=idx + 3)
+        put(idx + 2, z_of(k), z_of(k), leaf=2 * k)
+        put(idx + 3, z_of(k), z_of(k), leaf=2 * k + 1)
+        idx += 4
+    put(idx, z_of(depth), z_of(depth), left=idx + 1, right=idx + 2)
+    put(idx + 1, z_of(depth), z_of(depth), leaf=2 * depth)
+    put(idx + 2, z_of(depth), z_of(depth), leaf=2 * depth + 1)
+    assert idx + 3 == len(nodes)
+    mats = layout.pack_materials([dict(color=(0.9, 0.8, 0.7), roughness=1.0, metalness=0.5, specularColor=(1, 1, 1))])
+    return tris, mats, nodes
+
+
+def test_node_stack_beyond_its_lds_part(gpu_ctx, orc, env):
+    """The near-first walks keep 24 node entries per lane in LDS and up to 32 more in the wave's overflow
+    slice (pt_kernels.h SM_CULL_STACK_MAX).  On the comb scene the stack reaches ~40 (binary packets) /
+    ~42 (wide packets): images and paths must still equal the oracle's."""
+    tris, mats, nodes = _comb_scene()
+    ctx = gpu_ctx
+    ctx.upload_bvh(nodes)
+    ctx.upload_triangles(tris)
+    ctx.upload_materials(mats)
+    ctx.upload_environment(env)
+    ctx.set_tile(0, 1, 8)
+    w, h = 96, 64
+    ctx.resize(w, h)
+
+    class Cam:
+        camera = dict(position=(0.0, 0.0, 5.0), fov=3.0, focalDistance=1.0, aperture=0.0)
+
+        @staticmethod
+        def camera_direction():
+            return (0.0, 0.0, -1.0)
+
+    u = pc.rt_uniforms(Cam, w, h, frame=2, bounces=4)
+    want, ocnt = orc.raytrace(orc.OracleScene(tris, mats, nodes, env), u.tobytes(), w, h)
+    assert ocnt["stack_overflows"] == 0 and 0 < ocnt["hits"] < ocnt["rays"]
+    assert ocnt["box_tests"] > 100 * ocnt["rays"]             # every ray enters (almost) every box
+    for variant in (9, 10):
+        ctx.set_kernel_variant(variant)
+        ctx.reset_counters()
+        pc.gpu_frame(ctx, u)
+        got, cnt = ctx.read_texture(capi.TEX_OUTPUT), ctx.counters()
+        ctx.set_kernel_variant(0)
+        assert pc.same_bits(got, want), f"variant {variant}: " + pc.describe_diff(got, want)
+        pc.check_counters(cnt, ocnt, culled=True, what=f"variant {variant}")
+        assert cnt["box_tests"] != ocnt["box_tests"] or variant == 9      # (it really was a culling walk, not a fallback)
+    ctx.resize(64, 64)
+
+
 def test_demo_scene_1080p_and_the_share_of_boxes_skipped(gpu_ctx, demo, env):
     ctx = gpu_ctx
     pc.upload_scene(ctx, demo, env)
@@ -141,5 +214,5 @@ def test_demo_scene_1080p_and_the_share_of_boxes_skipped(gpu_ctx, demo, env):
         got, cgot = _render(ctx, demo, w, h, range(2, 8), variant=variant)
         assert pc.same_bits(got, ref), pc.describe_diff(got, ref)
         pc.check_counters(cgot, cref, culled=True)
-        assert cgot["box_tests"] < cref["box_tests"]
+        assert cgot["box_tests"] < cref["box_tests"]           # (this view: both walks test fewer boxes than the reference)
     ctx.resize(64, 64)

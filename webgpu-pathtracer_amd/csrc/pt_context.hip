@@ -44,7 +44,8 @@ struct mi3pt_ctx {
     void *d_packets = nullptr, *d_tripk = nullptr;
     void *d_leaf_rank = nullptr;          // per triangle: position of its leaf in the reference's visiting order
     int leaf_cap = 0;                     // LDS slots left for deferred leaves (0 = scene must be walked in order)
-    bool cull_stack_ok = false;           // the near-first walks' order-independent worst-case stack fits (upload_bvh)
+    bool cull_stack_ok = false;           // proper tree, the 64-entry abort cannot fire, and the near-first walks'
+                                          // order-independent worst-case stack fits (upload_bvh)
     size_t ntris = 0, nnodes = 0, nmats = 0, npackets = 0;
     uint32_t root_ref = 0;
     uint32_t scene_flags = 0;
@@ -920,7 +921,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
 {
     if (!ctx->cull_dirty) return MI3PT_OK;
     const bool wanted = ctx->variant == 9 || ctx->variant == 10 || (ctx->variant == 0 && ctx->cull_enabled);
-    if (!wanted || ctx->layout_active || ctx->leaf_cap < 4 || !ctx->cull_stack_ok || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
+    if (!wanted || ctx->layout_active || !ctx->cull_stack_ok || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
         return MI3PT_OK;       // stays dirty: pick_variant falls back to the reference-counter walk
     if (int rc = flush_pending(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1175,7 +1176,8 @@ static int pick_variant(const mi3pt_ctx *ctx)
 {
     if (ctx->env_sampling) return 2;               // the dormant path lives in the per-pixel kernel only
     const bool defer_ok = ctx->leaf_cap >= 4;      // see mi3pt_upload_bvh: leaves may be tested out of order
-    const bool cull_ok = defer_ok && ctx->cull_stack_ok && ctx->cull_ok && !ctx->cull_dirty;     // see prepare_cull
+    const bool cull_ok = ctx->cull_stack_ok && ctx->cull_ok && !ctx->cull_dirty;     // see prepare_cull (independent of defer_ok:
+                                                                                       // the culling walks have their own stack scheme)
     const bool wide_ok = cull_ok && ctx->wide_ok;
     if (ctx->variant == 0) return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? 10 : 9) : (defer_ok ? 7 : 4);
     if (ctx->variant == 10 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);

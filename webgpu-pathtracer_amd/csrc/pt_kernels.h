@@ -20,7 +20,10 @@ constexpr int SM_LDS_DEPTH = PT_SM_LDS_DEPTH_VALUE;
 // SM_LDS_DEPTH - SM_CULL_LEAF_CAP slots below it, and deeper node entries (rare) in the wave's global overflow slice
 // (PT_MAX_STACK - SM_LDS_DEPTH = 32 more per lane); the context offers them only when the order-independent worst case
 // (every box hit, every child possibly first) fits: SM_CULL_STACK_MAX entries.
-constexpr int SM_CULL_LEAF_CAP = 8;
+#ifndef PT_CULL_LEAF_CAP_VALUE
+#define PT_CULL_LEAF_CAP_VALUE 8
+#endif
+constexpr int SM_CULL_LEAF_CAP = PT_CULL_LEAF_CAP_VALUE;
 constexpr int SM_CULL_STACK_MAX = SM_LDS_DEPTH - SM_CULL_LEAF_CAP + 32;
 
 
