@@ -237,11 +237,17 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
  * child box that starts farther away than the closest hit so far, by a margin PROVEN to cover the
  * rounding of the reference's fp32 Moller-Trumbore code, is skipped, children are
  * visited near first -- the image is bit-identical, the box / triangle-test COUNTERS are lower than
- * the reference walk's (which has no such bound, raytrace.wgsl:118-203).
- * auto = 9 when the scene allows it (else 7, else 4); MI3PT_CULL=0 in the environment makes auto
- * stop at 7.  Variants 1-8 execute exactly the reference's tests (counters equal the oracle's);
+ * the reference walk's (which has no such bound, raytrace.wgsl:118-203); 10 = 9 on 4-ary "wide" packets
+ * (internal children absorbed into their parent where boxes nest: the same leaves are reached -- the
+ * fp32 slab test is monotone under nesting -- in half the node steps).  9 and 10 need a proper tree whose
+ * order-independent worst-case stack fits 56 entries.
+ * auto = 10 when the scene allows it (else 9, else 7, else 4); MI3PT_WIDE=0 / MI3PT_CULL=0 in the
+ * environment make auto stop at 9 / 7.  Variants 1-8 execute exactly the reference's tests (counters equal the oracle's);
  * all variants produce the same bits. */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
+/* The variant a raytrace submit would run right now: the selected one, or its fall-back when the
+ * uploaded scene does not admit it (tests use it to make sure nothing fell back silently). */
+int mi3pt_debug_active_variant(mi3pt_ctx *ctx, int *variant);
 /* The reference's environment importance sampling (raytrace.wgsl:315-367: getEnvironmentMapUV /
  * ...MarginalCDF / ...ConditionalCDF / ...PDF over the CDF texture of renderer.ts:159-266) is dead
  * code as shipped -- its call sites raytrace.wgsl:398 and :402-404 are commented out.  enabled = 1

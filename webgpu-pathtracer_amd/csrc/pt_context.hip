@@ -177,6 +177,10 @@ static int require_ctx(mi3pt_ctx *ctx)
 static int require_idle(mi3pt_ctx *ctx);      // require_ctx + flush of the deferred frame queue (below)
 static int flush_pending(mi3pt_ctx *ctx);
 static int settle_canvas(mi3pt_ctx *ctx);
+static int check_scene(const mi3pt_ctx *ctx);
+static int prepare_layout(mi3pt_ctx *ctx);
+static int prepare_cull(mi3pt_ctx *ctx);
+static int pick_variant(const mi3pt_ctx *ctx);
 
 extern "C" int mi3pt_abi_version(void) { return MI3PT_ABI_VERSION; }
 extern "C" const char *mi3pt_last_error(void) { return g_last_error.c_str(); }
@@ -370,6 +374,19 @@ extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
     if (variant < 0 || variant > 10) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..10");
     if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
+    return MI3PT_OK;
+}
+
+// Which kernel variant a raytrace submit would run right now (after the lazy scene analyses): the
+// selected one, or what it falls back to when the scene does not admit it.
+extern "C" int mi3pt_debug_active_variant(mi3pt_ctx *ctx, int *variant)
+{
+    if (!ctx || !variant) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (int rc = require_idle(ctx)) return rc;
+    if (int rc = check_scene(ctx)) return rc;
+    if (int rc = prepare_layout(ctx)) return rc;
+    if (int rc = prepare_cull(ctx)) return rc;
+    *variant = pick_variant(ctx);
     return MI3PT_OK;
 }
 

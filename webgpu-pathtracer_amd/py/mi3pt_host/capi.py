@@ -32,7 +32,7 @@ SYMBOLS = (
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
     "mi3pt_set_env_sampling", "mi3pt_debug_walk_probe", "mi3pt_device_build_bvh",
-    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
+    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_debug_active_variant", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf",
 )
@@ -91,6 +91,7 @@ def load_library(path=None):
                                                 ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.mi3pt_raytrace_launch_span.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.mi3pt_batch_capacity.argtypes = [c_void_p, ctypes.POINTER(c_int)]
+    lib.mi3pt_debug_active_variant.argtypes = [c_void_p, ctypes.POINTER(c_int)]
     lib.mi3pt_debug_set_packet_layout.argtypes = [c_void_p, c_int]
     lib.mi3pt_get_counters.argtypes = [c_void_p, c_void_p]
     lib.mi3pt_reset_counters.argtypes = [c_void_p]
@@ -314,6 +315,11 @@ class Context:
 
     def set_packet_layout(self, layout):
         self._c(self.lib.mi3pt_debug_set_packet_layout(self.handle, int(layout)))
+
+    def active_variant(self):
+        v = ctypes.c_int()
+        self._c(self.lib.mi3pt_debug_active_variant(self.handle, ctypes.byref(v)))
+        return v.value
 
     def batch_capacity(self):
         n = ctypes.c_int()
