@@ -1199,7 +1199,7 @@ static int pick_variant(const mi3pt_ctx *ctx)
     if (ctx->variant == 0) return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? 10 : 9) : (defer_ok ? 7 : 4);
     if (ctx->variant == 10 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);
     if (ctx->variant == 9 && !cull_ok) return defer_ok ? 7 : 4;
-    if (ctx->variant >= 7 && !defer_ok) return ctx->variant == 8 ? 6 : 4;
+    if ((ctx->variant == 7 || ctx->variant == 8) && !defer_ok) return ctx->variant == 8 ? 6 : 4;
     return ctx->variant;
 }
 // the walk the probe runs: 1 = uploaded records, 2 = packets, 3 = packets + prepared-reciprocal slab test
