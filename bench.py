@@ -433,9 +433,10 @@ def main():
              "kernel_ms": launch_ms_total / max(launches, 1), "launches": int(launches),
              "kernel_ms_exclusive": span_ms / max(launches, 1),
              "frames_per_launch": round(launch_frames / max(launches, 1), 2),
-             "kernel": "k_raytrace_sm<false,false,true,true> (persistent raytrace kernel: per-lane state machine, deferred-leaf "
-                       "walk, exact-image distance culling; batched frames)" if args.variant in (0, 9)
-                       else f"raytrace kernel variant {args.variant}"}
+             "kernel": (lambda v: {10: "k_raytrace_sm<false,false,true,true,true>", 9: "k_raytrace_sm<false,false,true,true,false>"}
+                        .get(v, f"raytrace kernel variant {v}") + " (persistent raytrace kernel: per-lane state machine, deferred-leaf walk"
+                        + (" with exact-image distance culling" if v >= 9 else "") + (" on 4-ary wide packets" if v == 10 else "")
+                        + "; batched frames)")(ctx.active_variant())}
         ctx.bind_accumulation(None, 0)
         return m
 

@@ -13,11 +13,14 @@
 //       triangle packets -- same tests in the same order, a third of the loads.
 //       Kept as the on-device references of the parity tests (kernel variants 1 and 2).
 //   k_raytrace_persistent      variant 3: persistent waves with lane refill only
-//   k_raytrace_sm<FUSE, TOPLDS, DEFER>
+//   k_raytrace_sm<FUSE, TOPLDS, DEFER, CULL, WIDE>
 //       the shipped kernel: persistent one-wave workgroups, per-lane state machine with node /
-//       triangle / service steps, (frame slot, tile) jobs from a self-cleaning queue;
-//       DEFER = leaves parked and tested in steps of their own (variant 7, the default when
-//       the tree allows it), !DEFER = in-order walk (variant 4; 5 = other walk threshold),
+//       triangle / service steps (the service step split into a hit-shading and a miss / path
+//       group), (frame slot, tile) jobs from a self-cleaning queue;
+//       DEFER = leaves parked and tested in steps of their own (variant 7: exactly the reference's
+//       tests), !DEFER = in-order walk (variant 4; 5 = other walk threshold),
+//       CULL = DEFER + exact-image distance culling, children near first (variant 9),
+//       WIDE = CULL on 4-ary wide packets (variant 10, the default when the tree allows it),
 //       TOPLDS = top of the tree staged in LDS (variants 6 and 8, measured no faster)
 //   k_accumulate[_batch]       accumulate.wgsl computeMain (one frame / an ordered batch of frames)
 //   k_fullscreen               fullscreen.wgsl fragmentMain (de-noise + tone-map)
