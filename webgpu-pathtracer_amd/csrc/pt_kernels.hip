@@ -1058,10 +1058,17 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     uint32_t st_tail_node = 0, st_tail_tri = 0, st_tail_service = 0, st_tail_lanes = 0, st_live_at_empty = 0;   // after the queue ran empty
     uint64_t st_cyc_node = 0, st_cyc_tri = 0, st_cyc_service = 0, st_mark = t_begin_clk;     // shader cycles per kind of step
     int st_kind = 2;
+#ifdef PT_DIAG_SERVICE      // experiment build: the service step's parts (3 hit shading, 4 miss shading, 5 refill + camera paths, 6 segment starts)
+    uint64_t st_cyc_part[4] = { 0, 0, 0, 0 };
+#endif
     auto st_switch = [&](int kind) {     // diagnostic only: the time since the last switch belongs to the step that ran
         const uint64_t now = __builtin_amdgcn_s_memtime();
         const uint64_t dt = now - st_mark;
-        if (st_kind == 0) st_cyc_node += dt; else if (st_kind == 1) st_cyc_tri += dt; else st_cyc_service += dt;
+        if (st_kind == 0) st_cyc_node += dt; else if (st_kind == 1) st_cyc_tri += dt;
+#ifdef PT_DIAG_SERVICE
+        else if (st_kind >= 3) st_cyc_part[st_kind - 3] += dt;
+#endif
+        else st_cyc_service += dt;
         st_mark = now;
         st_kind = kind;
     };
@@ -1401,6 +1408,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             u_hit += (uint32_t)__popcll(__ballot(shade_hit));
             u_miss += (uint32_t)__popcll(__ballot(shade_miss));
             bool ended = true;
+#ifdef PT_DIAG_SERVICE
+            if (L.wave_times) st_switch(3);
+#endif
             if (shade_hit) {          // trace(), raytrace.wgsl:380-395
                 
                 f3 position, normal;
@@ -1422,6 +1432,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 bounce++;
                 ended = bounce >= un.max_bounces;
             }
+#ifdef PT_DIAG_SERVICE
+            if (L.wave_times) st_switch(4);
+#endif
             if (shade_miss) {         // :396-407
                 
                 float u, v;
@@ -1445,6 +1458,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 }
             }
         }
+#ifdef PT_DIAG_SERVICE
+        if (L.wave_times) st_switch(5);
+#endif
         // refill: free lanes take new jobs
         if (do_b) {
             unsigned long long dead = __ballot(mode == M_DEAD && !need_segment);
@@ -1519,6 +1535,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 sample++;
             }
         }
+#ifdef PT_DIAG_SERVICE
+        if (L.wave_times) st_switch(6);
+#endif
         if (L.wave_times) st_segment_lanes += (uint32_t)__popcll(__ballot(need_segment));
         {
             const uint32_t nseg = (uint32_t)__popcll(__ballot(need_segment));
@@ -1557,9 +1576,13 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         w[8] = st_tri_steps;
         w[9] = st_cyc_node; w[10] = st_cyc_tri; w[11] = st_cyc_service;
         w[12] = ((uint64_t)st_hit_steps << 32) | st_b_steps;
+#ifdef PT_DIAG_SERVICE
+        w[12] = st_cyc_part[0]; w[13] = st_cyc_part[1]; w[14] = st_cyc_part[2]; w[15] = st_cyc_part[3];
+#else
         w[13] = ((uint64_t)st_tail_node << 32) | st_tail_tri;
         w[14] = ((uint64_t)st_tail_service << 32) | st_live_at_empty;
         w[15] = st_tail_lanes;
+#endif
         w[0] = t_begin_rt;
         w[1] = t_empty_rt;
         w[2] = __builtin_amdgcn_s_memrealtime();
