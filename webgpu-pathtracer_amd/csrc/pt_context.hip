@@ -92,6 +92,7 @@ struct mi3pt_ctx {
     bool output_is_accum = false;
     uint64_t *d_block_counters = nullptr;
     uint32_t *d_tile_counter = nullptr;
+    int job_chunk = 4;                   // job tickets per draw from the queue (MI3PT_JOB_CHUNK; 1 = one atomic per job)
     uint32_t *d_drain_flag = nullptr;     // signal memory: sequence number of the last batched launch that started draining
     bool gate_enabled = false;            // launches wait on d_drain_flag (off when the memory or the wait is unavailable)
     uint32_t launch_seq = 0;              // sequence number of the last batched launch
@@ -268,6 +269,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     if (const char *e = std::getenv("MI3PT_TOP_PACKETS")) ctx->top_packets = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_CULL")) ctx->cull_enabled = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI3PT_WIDE")) ctx->wide_enabled = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MI3PT_JOB_CHUNK")) { ctx->job_chunk = std::atoi(e); if (ctx->job_chunk < 1 || ctx->job_chunk > 64) ctx->job_chunk = 1; }
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
     CREATE_TRY(hipMalloc(&ctx->d_env, env_bytes));
@@ -1234,6 +1236,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.accum = ctx->d_accum;
     L.block_counters = ctx->d_block_counters;
     L.tile_counter = ctx->d_tile_counter;
+    L.job_chunk = ctx->job_chunk;
     L.wave_times = ctx->d_wave_times;
     L.stack_overflow = ctx->d_stack_overflow;
     L.store_f16 = ctx->storage == MI3PT_STORAGE_F16;
