@@ -58,7 +58,8 @@ def _gpu_worker(rank, world, port, w, h, block, frames, outq):
     """The same flow with the DEVICE path doing the rendering: every rank owns a context on the
     one GPU of the box with its tile set, accumulates into a torch tensor bound as the
     accumulation image (bench.py's arrangement), and the tensors are gathered over gloo."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MI3PT_BATCH="4")          # 4 x world frames per launch: the 20 frames take several launches
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
     for p in (os.path.join(root, "webgpu-pathtracer_amd", "py"), here):
@@ -98,7 +99,7 @@ def _gpu_worker(rank, world, port, w, h, block, frames, outq):
 @pytest.mark.parametrize("world", [2, 3])
 def test_tile_split_on_the_device_gathers_to_the_whole_image(gpu_ctx, demo, env, world):
     """world_size 2 and 3 over gloo, the HIP path rendering (one context per rank on the one GPU;
-    20 frames: more than one batch): the gathered, de-interleaved HDR image equals the image a
+    20 frames in launches of 4 x world): the gathered, de-interleaved HDR image equals the image a
     single 1-rank context renders, bit for bit."""
     import torch.multiprocessing as mp
     from mi3pt_host import capi
