@@ -183,7 +183,7 @@ int mi3pt_sync(mi3pt_ctx *ctx);   /* queue.onSubmittedWorkDone(), renderer.ts:42
 int mi3pt_set_present_mode(mi3pt_ctx *ctx, int mode /* mi3pt_present_mode */);
 /* RAYTRACE|ACCUMULATE submits may be queued inside the library and launched together (up to
  * 32 consecutive frames whose uniforms differ only in `frame` -- 32 x nranks for a rank of a tile
- * split, at most 128, less when memory is short -- run as one kernel + one ordered
+ * split, at most 256, less when memory is short -- run as one kernel + one ordered
  * accumulate).  Every call that observes or changes device state launches the queue first;
  * mi3pt_flush does only that, without waiting -- use it before synchronising the stream
  * yourself (e.g. torch.cuda.synchronize()). */

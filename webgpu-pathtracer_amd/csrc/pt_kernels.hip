@@ -1109,7 +1109,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         have_at = __builtin_amdgcn_readfirstlane(t);
         have = c;
     };
-    int cur_tile = 0, cur_used = 64;
+    int cur_tile = 0, cur_used = 64, cur_fslot = 0, cur_ftile = 0;
+    const int grp_jobs = (L.job_group > 0 && L.job_group < ntiles_frame) ? L.job_group * L.nframes : 0;
+    const int grp_full = grp_jobs ? ntiles_frame / L.job_group : 0;
     draw();
     bool feed_empty = false;
 
@@ -1482,6 +1484,15 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         }
                         break;
                     }
+                    if (grp_jobs == 0) {            // frame-major
+                        cur_fslot = cur_tile / ntiles_frame;
+                        cur_ftile = cur_tile - cur_fslot * ntiles_frame;
+                    } else {                        // groups of L.job_group tiles, every frame of a group before the next group
+                        int g = cur_tile / grp_jobs, r = cur_tile - g * grp_jobs, gs = L.job_group;
+                        if (g >= grp_full) { g = grp_full; r = cur_tile - grp_full * grp_jobs; gs = ntiles_frame - grp_full * L.job_group; }
+                        cur_fslot = r / gs;
+                        cur_ftile = g * L.job_group + (r - cur_fslot * gs);
+                    }
                     have_at++;
                     if (--have == 0) draw();
                     cur_used = 0;
@@ -1492,7 +1503,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 bool got_job = false;
                 if (mine) {
                     const int j = cur_used + rank;
-                    const int fslot = cur_tile / ntiles_frame, ftile = cur_tile - fslot * ntiles_frame;
+                    const int fslot = cur_fslot, ftile = cur_ftile;
                     const int px = (ftile % tiles_x) * 8 + (j & 7);
                     const int ply = (ftile / tiles_x) * 8 + (j >> 3);
                     const int pgy = local_to_global_row(ply, L.tile);
