@@ -433,10 +433,10 @@ def main():
              "kernel_ms": launch_ms_total / max(launches, 1), "launches": int(launches),
              "kernel_ms_exclusive": span_ms / max(launches, 1),
              "frames_per_launch": round(launch_frames / max(launches, 1), 2),
-             "kernel": (lambda v: {10: "k_raytrace_sm<false,false,true,true,true>", 9: "k_raytrace_sm<false,false,true,true,false>"}
+             "kernel": (lambda v: {10: "k_raytrace_sm<false,false,true,true,true,true>", 9: "k_raytrace_sm<false,false,true,true,false,true>"}
                         .get(v, f"raytrace kernel variant {v}") + " (persistent raytrace kernel: per-lane state machine, deferred-leaf walk"
                         + (" with exact-image distance culling" if v >= 9 else "") + (" on 4-ary wide packets" if v == 10 else "")
-                        + "; batched frames)")(ctx.active_variant())}
+                        + ("; one-sample-per-frame specialisation" if v >= 9 else "") + "; batched frames)")(ctx.active_variant())}
         ctx.bind_accumulation(None, 0)
         return m
 

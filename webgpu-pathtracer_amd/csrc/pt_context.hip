@@ -93,6 +93,7 @@ struct mi3pt_ctx {
     uint64_t *d_block_counters = nullptr;
     uint32_t *d_tile_counter = nullptr;
     int job_group = -1;                  // MI3PT_JOB_GROUP, see RtLaunch::job_group; -1 = chosen per tile set in build_launch
+    int tri_pair = 1;                    // MI3PT_TRI_PAIR, see RtLaunch::tri_pair
     int job_chunk = 4;                   // job tickets per draw from the queue (MI3PT_JOB_CHUNK; 1 = one atomic per job)
     uint32_t *d_drain_flag = nullptr;     // signal memory: sequence number of the last batched launch that started draining
     bool gate_enabled = false;            // launches wait on d_drain_flag (off when the memory or the wait is unavailable)
@@ -271,6 +272,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     if (const char *e = std::getenv("MI3PT_TOP_PACKETS")) ctx->top_packets = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_CULL")) ctx->cull_enabled = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI3PT_WIDE")) ctx->wide_enabled = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MI3PT_TRI_PAIR")) ctx->tri_pair = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI3PT_JOB_GROUP")) ctx->job_group = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_JOB_CHUNK")) { ctx->job_chunk = std::atoi(e); if (ctx->job_chunk < 1 || ctx->job_chunk > 64) ctx->job_chunk = 1; }
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
@@ -1240,6 +1242,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.block_counters = ctx->d_block_counters;
     L.tile_counter = ctx->d_tile_counter;
     L.job_chunk = ctx->job_chunk;
+    L.tri_pair = ctx->tri_pair;
     L.job_group = ctx->job_group;
     if (ctx->job_group < 0) {
         // jobs in groups of about an eighth of a frame's tiles (whole tile rows): all frames of a launch for

@@ -725,6 +725,13 @@ PT_DEV void write_pixel(const RtLaunch &L, uint32_t gx, uint32_t gy, uint32_t ly
     }
 }
 
+// unfused store of one finished (pixel, frame slot): texel index within the slot's image
+PT_DEV void write_radiance(const RtLaunch &L, uint32_t texel, uint32_t slot, f3 color)
+{
+    L.radiance[(size_t)slot * L.slot_pixels + texel] =
+        make_float4(store_round(color.x, L.store_f16), store_round(color.y, L.store_f16), store_round(color.z, L.store_f16), 1.0f);
+}
+
 struct PathSlot {
     f3 o, d, ray_color, light, incoming;
     uint32_t gx, gy, ly, seed;
@@ -956,7 +963,7 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
 // WIDE (kernel variant 10, needs CULL): the walk runs on 4-ary "wide packets" (pt_kernels.h) -- up
 // to four child boxes per node step, half as many dependent round trips per ray.  The leaves reached
 // are exactly the reference's (monotone slab test under nesting).
-template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false, bool WIDE = false>
+template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false, bool WIDE = false, bool SPF1 = false>
 __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
 {
     constexpr int DEPTH = PT_SM_LDS_DEPTH;                  // LDS stack entries per lane
@@ -1151,21 +1158,48 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             // (drain: whichever kind of step serves more lanes -- waiting for n_node == 0 would leave the lanes
             // that only have leaves idle for as long as the slowest descent takes)
             if (full || n_node == 0 || n_leaf >= L.leaf_min || (feed_empty && (L.tail_policy & 1) && n_leaf >= n_node)) {
-                u_tri += (uint32_t)n_leaf;       // every lane with a parked leaf tests one (wave-uniform count: scalar)
+                // every lane with a parked leaf tests one -- or two, when it has two (L.tri_pair): the second triangle's
+                // loads are in flight with the first's, and the lane needs one triangle step less
+                const bool two = L.tri_pair && has_leaf && nl > 1;
+                u_tri += (uint32_t)n_leaf + (L.tri_pair ? (uint32_t)__popcll(__ballot(two)) : 0u);      // (wave-uniform count: scalar)
                 if (L.wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
                 if (has_leaf) {
                     nl--;
                     const uint32_t ti = stack[(DEPTH - 1 - nl) * 64];
-                    const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
-                    const float4 pb = sc.tripk[(size_t)ti * 3 + 1];
-                    const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
-                    
+                    uint32_t tj = ti;
+                    if (two) { nl--; tj = stack[(DEPTH - 1 - nl) * 64]; }
+                    // (the opaque statements keep each of these ONE 16-byte load: left alone, the compiler fetches the nine
+                    // coordinates as five overlapping 8- and 12-byte pieces to feed packed multiplies -- five divergent
+                    // requests per lane instead of three)
+                    float4 pa = sc.tripk[(size_t)ti * 3 + 0];
+                    float4 pb = sc.tripk[(size_t)ti * 3 + 1];
+                    float4 pc = sc.tripk[(size_t)ti * 3 + 2];
+                    float4 qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), qb = qa, qc = qa;
+                    if (two) {
+                        qa = sc.tripk[(size_t)tj * 3 + 0];
+                        qb = sc.tripk[(size_t)tj * 3 + 1];
+                        qc = sc.tripk[(size_t)tj * 3 + 2];
+                    }
+                    asm volatile("" : "+v"(pa.x), "+v"(pa.y), "+v"(pa.z), "+v"(pa.w));
+                    asm volatile("" : "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w));
+                    asm volatile("" : "+v"(pc.x), "+v"(pc.y), "+v"(pc.z), "+v"(pc.w));
                     float t, u, v;
                     if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v)) {
                         bool take = t < best.t;
                         if (t == best.t && best.tri >= 0)      // rare: the earlier leaf of the reference order wins
                             take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
                         if (take) { best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti; }
+                    }
+                    if (two) {
+                        asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qa.z), "+v"(qa.w));
+                        asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
+                        asm volatile("" : "+v"(qc.x), "+v"(qc.y), "+v"(qc.z), "+v"(qc.w));
+                    }
+                    if (two && ray_triangle(o, d, xyz(qa), xyz(qb), xyz(qc), t, u, v)) {
+                        bool take = t < best.t;
+                        if (t == best.t && best.tri >= 0)
+                            take = sc.leaf_rank[tj] < sc.leaf_rank[best.tri];
+                        if (take) { best.t = t; best.u = u; best.v = v; best.tri = (int32_t)tj; }
                     }
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                 }
@@ -1438,8 +1472,8 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 const f3 emitted = xyz(m3) * m3.w;
                 light = light + emitted * ray_color;
                 ray_color = ray_color * mix(xyz(m0), xyz(m1), is_specular);
-                bounce++;
-                ended = bounce >= un.max_bounces;
+                if constexpr (SPF1) { slot++; ended = (int32_t)(slot & 0xffffu) >= un.max_bounces; }
+                else { bounce++; ended = bounce >= un.max_bounces; }
             }
 #ifdef PT_DIAG_SERVICE
             if (L.wave_times) st_switch(4);
@@ -1454,13 +1488,18 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             if (shade_hit || shade_miss) {
                 mode = M_DEAD;        // until a path / segment is started below
                 if (ended) {
-                    incoming = incoming + light;
-                    sample++;
-                    if (sample >= un.samples_per_frame) {
-                        // pixel finished (:455, :477): the slot is free for a refill
-                        write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
+                    if constexpr (SPF1) {
+                        // one sample per frame: the pixel is finished (:455, :477); incomingLight = 0 + light
+                        write_radiance(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
                     } else {
-                        mode = M_PATH;
+                        incoming = incoming + light;
+                        sample++;
+                        if (sample >= un.samples_per_frame) {
+                            // pixel finished (:455, :477): the slot is free for a refill
+                            write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
+                        } else {
+                            mode = M_PATH;
+                        }
                     }
                 } else {
                     need_segment = true;
@@ -1471,6 +1510,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         if (L.wave_times) st_switch(5);
 #endif
         // refill: free lanes take new jobs
+        uint32_t job_px = 0u, job_py = 0u;          // SPF1: the pixel a lane has just been given (used below, in this step)
         if (do_b) {
             unsigned long long dead = __ballot(mode == M_DEAD && !need_segment);
             while (dead != 0ull && !feed_empty) {
@@ -1510,12 +1550,20 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     const bool ok = px < L.tile.tex_w && ply < L.tile.local_rows && pgy < L.tile.tex_h &&
                                     (uint32_t)px < res_w && (uint32_t)pgy < res_h;     // :425-427
                     if (ok) {
-                        gx = (uint32_t)px; gy = (uint32_t)pgy; ly = (uint32_t)ply;
                         got_job = true;
-                        slot = (uint32_t)fslot;
-                        seed = (gx + gy * res_w) + (un.frame + slot) * 719393u + PT_SEED;    // :435-436
-                        sample = 0;
-                        incoming = F3(0.0f, 0.0f, 0.0f);
+                        seed = ((uint32_t)px + (uint32_t)pgy * res_w) + (un.frame + (uint32_t)fslot) * 719393u + PT_SEED;    // :435-436
+                        if constexpr (SPF1) {
+                            // the pixel's coordinates are only needed for the camera ray, formed in this very step;
+                            // what a lane carries through its walks: texel index, frame slot << 16 | bounce
+                            job_px = (uint32_t)px; job_py = (uint32_t)pgy;
+                            gx = (uint32_t)ply * (uint32_t)L.tile.tex_w + (uint32_t)px;
+                            slot = (uint32_t)fslot << 16;
+                        } else {
+                            gx = (uint32_t)px; gy = (uint32_t)pgy; ly = (uint32_t)ply;
+                            slot = (uint32_t)fslot;
+                            sample = 0;
+                            incoming = F3(0.0f, 0.0f, 0.0f);
+                        }
                         mode = M_PATH;
                     }
                 }
@@ -1530,13 +1578,16 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             // raytrace.wgsl:441-455: next sample's camera path, or the pixel is finished
             mode = M_DEAD;
             for (;;) {
-                if (sample >= un.samples_per_frame) {
-                    write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
-                    break;
+                if constexpr (!SPF1) {
+                    if (sample >= un.samples_per_frame) {
+                        write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
+                        break;
+                    }
                 }
                 float uvx, uvy;
-                if (res_ordinary) { uvx = div_pre((float)gx, un.res_x, inv_res_x); uvy = div_pre((float)gy, un.res_y, inv_res_y); }
-                else { uvx = (float)gx / un.res_x; uvy = (float)gy / un.res_y; }
+                const uint32_t pxx = SPF1 ? job_px : gx, pyy = SPF1 ? job_py : gy;
+                if (res_ordinary) { uvx = div_pre((float)pxx, un.res_x, inv_res_x); uvy = div_pre((float)pyy, un.res_y, inv_res_y); }
+                else { uvx = (float)pxx / un.res_x; uvy = (float)pyy / un.res_y; }
                 const f3 dir0 = camera_direction(cf, un.aspect, uvx, uvy);
                 float jx, jy, kx, ky;
                 rand_point_in_circle(seed, jx, jy);
@@ -1546,12 +1597,17 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 const f3 focal = (cam_pos + dir0 * un.focal_distance) + jitter;
                 o = cam_pos + jitter2;
                 d = normalize(focal - o);
-                bounce = 0;
+                if constexpr (SPF1) slot &= 0xffff0000u; else bounce = 0;
                 light = F3(0.0f, 0.0f, 0.0f);
                 ray_color = F3(1.0f, 1.0f, 1.0f);
                 if (un.max_bounces > 0) { need_segment = true; break; }
-                incoming = incoming + light;
-                sample++;
+                if constexpr (SPF1) {       // (max_bounces == 0: the path is over before it began)
+                    write_radiance(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
+                    break;
+                } else {
+                    incoming = incoming + light;
+                    sample++;
+                }
             }
         }
 #ifdef PT_DIAG_SERVICE
@@ -1656,11 +1712,16 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
     const dim3 block(64);
     if (variant >= 3) {
         const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu, L.num_cus));
+        // (SPF1: the shipped walks' batched launches have a specialisation for samplesPerFrame == 1, the reference's
+        // default -- no per-pixel sum and sample counter to carry through the walk: five registers less)
+        const bool one = L.un.samples_per_frame == 1 && !fuse && L.un.max_bounces < 65536 && L.nframes <= 65535;
         if (variant == 10) {                             // the culling walk on 4-ary wide packets
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true, true>), grid, block, 0, s, L);
+            else if (one) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true>), grid, block, 0, s, L);
         } else if (variant == 9) {                       // deferred leaves + exact-image distance culling
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true>), grid, block, 0, s, L);
+            else if (one) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, false, true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true>), grid, block, 0, s, L);
         } else if (variant == 3) {
             if (fuse) hipLaunchKernelGGL((k_raytrace_persistent<true>), grid, block, 0, s, L);
