@@ -1241,22 +1241,25 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         nvalid += valid ? 1u : 0u;
                         const float dk = wgt[k] * rc;
                         const float tc = fmaxf(fmaxf(fmaf(-dk, fabsf(pre.ix), tn[k].x), fmaf(-dk, fabsf(pre.iy), tn[k].y)), fmaf(-dk, fabsf(pre.iz), tn[k].z));
-                        hit[k] = hit[k] && valid && !(tc > bt);
+                        // a child that is missed or skipped becomes an empty entry: the sort below then moves (key, reference)
+                        // pairs only -- selects, no branches, no lane masks to swap
+                        cr[k] = (hit[k] && !(tc > bt)) ? cr[k] : PT_REF_NONE;
                         key[k] = fmaxf(fmaxf(tn[k].x, tn[k].y), tn[k].z);
                     }
                     cnt.box += nvalid;
                     // far first, near last (popped first): sort the four entries by entry distance, descending
 #define PT_CSWAP(A, B)                                                                         \
-                    if (key[A] < key[B]) {                                                     \
-                        const float tk = key[A]; key[A] = key[B]; key[B] = tk;                 \
-                        const uint32_t tr_ = cr[A]; cr[A] = cr[B]; cr[B] = tr_;                \
-                        const bool th = hit[A]; hit[A] = hit[B]; hit[B] = th;                  \
+                    {                                                                          \
+                        const bool sw = key[A] < key[B];                                       \
+                        const float ka_ = sw ? key[B] : key[A], kb_ = sw ? key[A] : key[B];    \
+                        const uint32_t ra_ = sw ? cr[B] : cr[A], rb_ = sw ? cr[A] : cr[B];     \
+                        key[A] = ka_; key[B] = kb_; cr[A] = ra_; cr[B] = rb_;                  \
                     }
                     PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
                     // nl <= LCAP - 4 before the step (the `full` rule): the four leaf slots are free
 #pragma unroll
-                    for (int k = 0; k < 4; k++) cull_push(cr[k], hit[k]);
+                    for (int k = 0; k < 4; k++) cull_push(cr[k], cr[k] != PT_REF_NONE);
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                   }
                 } else
