@@ -239,6 +239,28 @@ PT_DEV bool ray_triangle(const f3 &o, const f3 &d, const f3 &a, const f3 &b, con
     return false;
 }
 
+// The same test without early returns (the state-machine kernel's triangle step: lanes leave a wave-wide test at
+// different points anyway, and every return is a branch + lane-mask bookkeeping): all quantities are formed, the
+// conditions are the ones above in the same sense for NaNs, and t / u / v are only meaningful when it returns true.
+PT_DEV bool ray_triangle_flat(const f3 &o, const f3 &d, const f3 &a, const f3 &b, const f3 &c,
+                              float &t, float &u, float &v)
+{
+    const f3 edge1 = b - a;
+    const f3 edge2 = c - a;
+    const f3 h = cross(d, edge2);
+    const float det = dot(edge1, h);
+    const float f = rcp_exact(det);
+    const f3 s = o - a;
+    u = f * dot(s, h);
+    const f3 q = cross(s, edge1);
+    v = f * dot(d, q);
+    t = f * dot(edge2, q);
+    const bool degenerate = det > -PT_EPSILON && det < PT_EPSILON;
+    const bool out_u = u < 0.0f || u > 1.0f;
+    const bool out_v = v < 0.0f || u + v > 1.0f;
+    return !degenerate && !out_u && !out_v && t > PT_EPSILON;
+}
+
 // raytrace.wgsl:154-203 (+ :205-211) on the uploaded records, as written: root box
 // first; pop; leaf -> its triangle, strict '<' keeps the first of equal t; internal ->
 // test left then right child box, push in that order (right is popped first); abort
@@ -1183,23 +1205,26 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     asm volatile("" : "+v"(pa.x), "+v"(pa.y), "+v"(pa.z), "+v"(pa.w));
                     asm volatile("" : "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w));
                     asm volatile("" : "+v"(pc.x), "+v"(pc.y), "+v"(pc.z), "+v"(pc.w));
-                    float t, u, v;
-                    if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v)) {
-                        bool take = t < best.t;
-                        if (t == best.t && best.tri >= 0)      // rare: the earlier leaf of the reference order wins
+                    {
+                        float t, u, v;
+                        const bool hit = ray_triangle_flat(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v);
+                        bool take = hit && t < best.t;
+                        if (hit && t == best.t && best.tri >= 0)      // rare: the earlier leaf of the reference order wins
                             take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
-                        if (take) { best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti; }
+                        best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                        best.tri = take ? (int32_t)ti : best.tri;
                     }
                     if (two) {
                         asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qa.z), "+v"(qa.w));
                         asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
                         asm volatile("" : "+v"(qc.x), "+v"(qc.y), "+v"(qc.z), "+v"(qc.w));
-                    }
-                    if (two && ray_triangle(o, d, xyz(qa), xyz(qb), xyz(qc), t, u, v)) {
-                        bool take = t < best.t;
-                        if (t == best.t && best.tri >= 0)
+                        float t, u, v;
+                        const bool hit = ray_triangle_flat(o, d, xyz(qa), xyz(qb), xyz(qc), t, u, v);
+                        bool take = hit && t < best.t;
+                        if (hit && t == best.t && best.tri >= 0)
                             take = sc.leaf_rank[tj] < sc.leaf_rank[best.tri];
-                        if (take) { best.t = t; best.u = u; best.v = v; best.tri = (int32_t)tj; }
+                        best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                        best.tri = take ? (int32_t)tj : best.tri;
                     }
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                 }
@@ -1304,13 +1329,12 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         const float bt = best.t * 1.00000095367431640625f;       // 1 + 2^-20: the roundings of tnear and of the fma
                         const float tl = fmaxf(fmaxf(fmaf(-dl, fabsf(pre.ix), nl3.x), fmaf(-dl, fabsf(pre.iy), nl3.y)), fmaf(-dl, fabsf(pre.iz), nl3.z));
                         const float tr = fmaxf(fmaxf(fmaf(-dr, fabsf(pre.ix), nr3.x), fmaf(-dr, fabsf(pre.iy), nr3.y)), fmaf(-dr, fabsf(pre.iz), nr3.z));
-                        hl = hl && !(tl > bt);
-                        hr = hr && !(tr > bt);
+                        // a child that is missed or skipped becomes an empty entry (selects: no lane masks to swap);
                         // far child first, near child last (popped first); leaves go to the leaf list anyway
-                        if (fmaxf(fmaxf(nl3.x, nl3.y), nl3.z) < fmaxf(fmaxf(nr3.x, nr3.y), nr3.z)) {
-                            r1 = rref; r2 = lref;
-                            const bool h = hl; hl = hr; hr = h;
-                        }
+                        const uint32_t el = (hl && !(tl > bt)) ? lref : PT_REF_NONE, er = (hr && !(tr > bt)) ? rref : PT_REF_NONE;
+                        const bool sw = fmaxf(fmaxf(nl3.x, nl3.y), nl3.z) < fmaxf(fmaxf(nr3.x, nr3.y), nr3.z);
+                        r1 = sw ? er : el; r2 = sw ? el : er;
+                        hl = r1 != PT_REF_NONE; hr = r2 != PT_REF_NONE;
                     }
                     // sp + nl <= 30 here (leaf_cap = 32 - worst-case stack, nl <= leaf_cap - 2), so slot sp
                     // and slot 31 - nl are both free: the stores are unconditional, the counts select
