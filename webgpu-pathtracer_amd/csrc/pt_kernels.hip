@@ -1044,6 +1044,16 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         nl += (take && lf) ? 1 : 0;
         sp += (take && !lf) ? 1 : 0;
     };
+    // The same two without the overflow slice, for a step in which no lane of the wave can reach it (a wave-uniform
+    // test at the top of the node step; almost every step): no branches, an empty entry (PT_REF_NONE, which has the
+    // leaf bit) is written to the free leaf slot and not counted.
+    auto flat_pop = [&]() -> uint32_t { sp--; return stack[sp * 64]; };
+    auto flat_push = [&](uint32_t ref) {
+        const bool lf = (ref & PT_REF_LEAF) != 0u;
+        stack[(lf ? DEPTH - 1 - nl : sp) * 64] = lf ? (ref & 0x7fffffffu) : ref;
+        nl += (lf && ref != PT_REF_NONE) ? 1 : 0;
+        sp += lf ? 0 : 1;
+    };
     const int tiles_x = (L.tile.tex_w + 7) >> 3;
     // A launch covers L.nframes consecutive frames: job = (frame slot, 8x8 tile), frame-major.
     const int ntiles_frame = tiles_x * ((L.tile.local_rows + 7) >> 3);
@@ -1231,9 +1241,11 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             } else {
                 if (!WIDE) u_box += 2u * (uint32_t)n_node;  // proper tree: both children of every popped node are tested (WIDE: per lane)
                 if (L.wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
+                // (CULL) can any lane's node entries leave the LDS part of its stack in this step?  One pop, then up to two / four pushes.
+                const bool shallow = CULL && __ballot(has_node && sp > NCAP - (WIDE ? 3 : 1)) == 0ull;
                 if (WIDE) {
                   if (has_node) {
-                    const uint32_t ref = cull_pop();
+                    const uint32_t ref = shallow ? flat_pop() : cull_pop();
                     const float4 *P = sc.wide + (size_t)ref * 8;
                     const float4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3], q4 = P[4], q5 = P[5], q6 = P[6], q7 = P[7];
                     uint32_t cr[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
@@ -1283,14 +1295,19 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
                     // nl <= LCAP - 4 before the step (the `full` rule): the four leaf slots are free
+                    if (shallow) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) cull_push(cr[k], cr[k] != PT_REF_NONE);
+                        for (int k = 0; k < 4; k++) flat_push(cr[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) cull_push(cr[k], cr[k] != PT_REF_NONE);
+                    }
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                   }
                 } else
                 if (has_node) {
                     uint32_t ref;
-                    if (CULL) ref = cull_pop();
+                    if (CULL) ref = shallow ? flat_pop() : cull_pop();
                     else { sp--; ref = stack[sp * 64]; }
                     float4 p0, p1, p2, p3;
                     if (TOPLDS && ref < ntop) {       // top of the tree: this wave's LDS copy
@@ -1338,7 +1355,10 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     }
                     // sp + nl <= 30 here (leaf_cap = 32 - worst-case stack, nl <= leaf_cap - 2), so slot sp
                     // and slot 31 - nl are both free: the stores are unconditional, the counts select
-                    if (CULL) {
+                    if (CULL && shallow) {
+                        flat_push(r1);
+                        flat_push(r2);
+                    } else if (CULL) {
                         cull_push(r1, hl);
                         cull_push(r2, hr);
                     } else {
