@@ -241,7 +241,7 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
  * (internal children absorbed into their parent where boxes nest: the same leaves are reached -- the
  * fp32 slab test is monotone under nesting -- in half the node steps).  9 and 10 need a proper tree whose
  * order-independent worst-case stack fits 56 entries.
- * auto = 10 when the scene allows it and has at least 32 768 internal nodes, else 9 (else 7, else 4); MI3PT_WIDE=0 / MI3PT_CULL=0 in the
+ * auto = 10 when the scene allows it, else 9 (else 7, else 4); MI3PT_WIDE=0 / MI3PT_CULL=0 in the
  * environment make auto stop at 9 / 7.  Variants 1-8 execute exactly the reference's tests (counters equal the oracle's);
  * all variants produce the same bits. */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);

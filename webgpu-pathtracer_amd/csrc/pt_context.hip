@@ -1206,7 +1206,7 @@ static int pick_variant(const mi3pt_ctx *ctx)
     // auto: the wide walk pays once the tree no longer sits in L1 / L2 (demo scene, 2 k nodes: binary packets 10.4, wide
     // packets 10.2 Grays/s; dragon-class 8.5 -> 8.6; 10 M-triangle forest 24 -> 21 ms per frame)
     if (ctx->variant == 0)
-        return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled && ctx->npackets >= 32768 ? 10 : 9) : (defer_ok ? 7 : 4);
+        return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? 10 : 9) : (defer_ok ? 7 : 4);
     if (ctx->variant == 10 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);
     if (ctx->variant == 9 && !cull_ok) return defer_ok ? 7 : 4;
     if ((ctx->variant == 7 || ctx->variant == 8) && !defer_ok) return ctx->variant == 8 ? 6 : 4;
