@@ -315,6 +315,31 @@ def test_raytrace_pass_bit_identical(gpu_ctx, orc, demo, env, case, variant):
     ctx.set_kernel_variant(0)
 
 
+@pytest.mark.parametrize("variant", [2, 9, 10])
+def test_pinhole_camera_with_a_negative_zero_coordinate(gpu_ctx, orc, demo, env, variant):
+    """aperture == 0 lets the shipped kernels drop the lens sample's arithmetic (its two rand()
+    calls stay): cam_pos + (+-0) is cam_pos -- unless a coordinate of cam_pos is -0, where
+    -0 + +0 = +0.  Such a camera must take the general path: image equal to the oracle's, which
+    evaluates raytrace.wgsl:447-452 as written."""
+    w, h = 96, 64
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_kernel_variant(variant)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    pos = list(demo.camera["position"])
+    for k in range(3):
+        p = list(pos)
+        p[k] = -0.0
+        u = pc.rt_uniforms(demo, w, h, frame=5, bounces=4, aperture=0.0, position=p)
+        pc.gpu_frame(ctx, u)
+        got = ctx.read_texture(capi.TEX_OUTPUT)
+        want, _ = orc.raytrace(pc.oracle_scene(orc, demo, env), u.tobytes(), w, h)
+        assert pc.same_bits(got, want), pc.describe_diff(got, want)
+    ctx.set_kernel_variant(0)
+    ctx.resize(64, 64)
+
+
 @pytest.mark.parametrize("storage", [capi.STORAGE_F32, capi.STORAGE_F16])
 @pytest.mark.parametrize("fused", [True, False])
 def test_accumulation_over_frames(gpu_ctx, orc, demo, env, storage, fused):

@@ -1081,6 +1081,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     const float inv_res_x = uni(1.0f / un.res_x), inv_res_y = uni(1.0f / un.res_y);
     const bool res_ordinary = un.res_x >= 9.5367431640625e-07f && un.res_x <= 1.099511627776e12f &&
                               un.res_y >= 9.5367431640625e-07f && un.res_y <= 1.099511627776e12f;
+    // thin lens off (aperture exactly 0, no -0 camera coordinate): see the camera path start
+    const bool pinhole = un.aperture == 0.0f && __float_as_uint(un.cam_pos[0]) != 0x80000000u &&
+                         __float_as_uint(un.cam_pos[1]) != 0x80000000u && __float_as_uint(un.cam_pos[2]) != 0x80000000u;
     const float spf_f = (float)un.samples_per_frame;
     auto per_sample = [&](const f3 &sum) {     // incomingLight / f32(samplesPerFrame), raytrace.wgsl:455 (x / 1 == x)
         return un.samples_per_frame == 1 ? sum : F3(sum.x / spf_f, sum.y / spf_f, sum.z / spf_f);
@@ -1639,10 +1642,20 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 float jx, jy, kx, ky;
                 rand_point_in_circle(seed, jx, jy);
                 const f3 jitter = F3(jx * inv_res_x, jy * inv_res_y, 0.0f);
-                rand_point_in_circle(seed, kx, ky);
-                const f3 jitter2 = F3(kx * un.aperture, ky * un.aperture, 0.0f);
                 const f3 focal = (cam_pos + dir0 * un.focal_distance) + jitter;
-                o = cam_pos + jitter2;
+                if (pinhole) {
+                    // aperture == 0 (the reference's default, scene.ts:9): the lens offset is (+-0, +-0, 0) whatever the
+                    // disk sample is (finite * 0), and cam_pos + (+-0) == cam_pos bit for bit unless a coordinate of
+                    // cam_pos is -0 (excluded): what remains of randPointInCircle (raytrace.wgsl:283-287) is its two
+                    // rand() calls, for the seed
+                    (void)rand1(seed);
+                    (void)rand1(seed);
+                    o = cam_pos;
+                } else {
+                    rand_point_in_circle(seed, kx, ky);
+                    const f3 jitter2 = F3(kx * un.aperture, ky * un.aperture, 0.0f);
+                    o = cam_pos + jitter2;
+                }
                 d = normalize(focal - o);
                 if constexpr (SPF1) slot &= 0xffff0000u; else bounce = 0;
                 light = F3(0.0f, 0.0f, 0.0f);
