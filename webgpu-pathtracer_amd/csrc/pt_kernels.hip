@@ -1000,7 +1000,11 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     // every ray walks.  One-wave workgroups (a multi-wave workgroup would hold its LDS and
     // wave slots until its slowest wave has drained) => a private 4 KB copy per wave.
     __shared__ float4 top_lds[TOPLDS ? PT_SM_TOP_PACKETS * 4 : 1];
+    // SPF1: a path's throughput and collected light are only touched by the service step; between service steps they
+    // rest here (6 floats per lane, [k][lane]) instead of in six registers carried through every node and triangle step
+    __shared__ float park_lds[SPF1 ? 6 * 64 : 1];
     const int lane = threadIdx.x;
+    float *park = park_lds + (SPF1 ? lane : 0);
     uint32_t *stack = stack_lds + lane;
     const uint32_t top_cap = (uint32_t)L.top_packets < (uint32_t)PT_SM_TOP_PACKETS ? (uint32_t)L.top_packets : (uint32_t)PT_SM_TOP_PACKETS;
     const uint32_t ntop = !TOPLDS ? 0u : (L.scene.npackets < top_cap ? L.scene.npackets : top_cap);
@@ -1501,6 +1505,12 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             u_hit += (uint32_t)__popcll(__ballot(shade_hit));
             u_miss += (uint32_t)__popcll(__ballot(shade_miss));
             bool ended = true;
+            if constexpr (SPF1) {
+                if (shade_hit || shade_miss) {
+                    ray_color = F3(park[0], park[64], park[128]);
+                    light = F3(park[192], park[256], park[320]);
+                }
+            }
 #ifdef PT_DIAG_SERVICE
             if (L.wave_times) st_switch(3);
 #endif
@@ -1680,6 +1690,14 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             if (sc.nnodes != 0) u_box += nseg;      // the root box test
         }
         bool slow_segment = false;
+        if constexpr (SPF1) {
+            if (need_segment) {
+                park[0] = ray_color.x; park[64] = ray_color.y; park[128] = ray_color.z;
+                park[192] = light.x; park[256] = light.y; park[320] = light.z;
+            }
+            ray_color = F3(0.0f, 0.0f, 0.0f);       // (dead until the lane's next shading: nothing to keep in registers)
+            light = F3(0.0f, 0.0f, 0.0f);
+        }
         if (need_segment) {
             // raySceneIntersect + the root test of rayBVHIntersect, raytrace.wgsl:155-164, 205-211
             best.t = PT_INF; best.u = 0.0f; best.v = 0.0f; best.tri = -1;
