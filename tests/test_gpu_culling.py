@@ -1,4 +1,4 @@
-"""The distance-culling walk (kernel variant 9, the default when the scene allows it) against
+"""The distance-culling walks (kernel variants 9 and 10; 10 is the default when the scene allows it) against
 the walks that execute exactly the reference's tests (raytrace.wgsl:118-203 has no bound by the
 current hit).  Contract: images bit-identical, the same paths (rays / hits /
 misses / pixels), fewer box and triangle tests.  The scenes here are chosen to stress the
