@@ -182,7 +182,7 @@ int mi3pt_sync(mi3pt_ctx *ctx);   /* queue.onSubmittedWorkDone(), renderer.ts:42
 /* Default MI3PT_PRESENT_EXACT.  See mi3pt_present_mode. */
 int mi3pt_set_present_mode(mi3pt_ctx *ctx, int mode /* mi3pt_present_mode */);
 /* RAYTRACE|ACCUMULATE submits may be queued inside the library and launched together (up to
- * 32 consecutive frames whose uniforms differ only in `frame` -- 32 x nranks for a rank of a tile
+ * 64 consecutive frames whose uniforms differ only in `frame` -- 64 x nranks for a rank of a tile
  * split, at most 256, less when memory is short -- run as one kernel + one ordered
  * accumulate).  Every call that observes or changes device state launches the queue first;
  * mi3pt_flush does only that, without waiting -- use it before synchronising the stream
@@ -255,7 +255,7 @@ int mi3pt_debug_active_variant(mi3pt_ctx *ctx, int *variant);
  * the path's light by the pdf); it needs the CDF texture and uses the per-pixel kernel (no
  * batching).  Default 0 = the shipped behaviour. */
 int mi3pt_set_env_sampling(mi3pt_ctx *ctx, int enabled);
-/* Frame pipelining (default on): RAYTRACE|ACCUMULATE submits are queued; up to 32 consecutive
+/* Frame pipelining (default on): RAYTRACE|ACCUMULATE submits are queued; up to 64 consecutive
  * frames whose uniforms differ only in `frame` run as one raytrace launch plus one ordered
  * multi-frame running mean, and launches alternate between two internal streams so the next
  * one fills the CUs while the last paths of this one drain.  Any call that observes or

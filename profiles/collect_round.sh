@@ -27,7 +27,7 @@ done
 echo "rocprof stats done"
 STEPS=20; WARM=5
 bash profiles/pmc_passes.sh gpurun_out/${TAG}_pmc_dragon --steps $STEPS --warmup $WARM
-python profiles/pmc_summary.py $OUT/${TAG}_pmc_dragon k_raytrace $((STEPS / 2)) > $OUT/${TAG}_dragon_pmc_per_launch.txt
+python profiles/pmc_summary.py $OUT/${TAG}_pmc_dragon k_raytrace $((STEPS / 4)) > $OUT/${TAG}_dragon_pmc_per_launch.txt
 rm -rf $OUT/${TAG}_pmc_dragon $OUT/${TAG}_pmc_dragon.pass*.log
 echo "pmc passes done: $(grep -c . $OUT/${TAG}_dragon_pmc_per_launch.txt) counters"
 python profiles/scaling_model.py --steps 20 --warmup 5 > $OUT/${TAG}_scaling_model_steps20.log 2>&1

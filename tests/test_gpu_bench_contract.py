@@ -20,7 +20,7 @@ def _line(out):
 
 
 def test_single_gpu_line():
-    """The driver's own arguments (--steps 20 --warmup 5; a step = 16 frames, two steps per launch): the headline is
+    """The driver's own arguments (--steps 20 --warmup 5; a step = 16 frames, four steps per launch): the headline is
     the ~870k-triangle scene the target is quoted on; the roofline fraction comes from counter passes
     of this very command line and is a fraction; the launch statistics are consistent with the wall clock."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"],
@@ -35,9 +35,9 @@ def test_single_gpu_line():
     assert j["value"] > 1000 and abs(j["value"] - j["config"]["rays_per_step"] / j["ms_per_step"] / 1e3) / j["value"] < 0.01
     roof = j["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
-    assert roof["kernel_ms"] > 0 and roof["launches_timed"] == 10 and roof["frames_per_launch"] == 32.0
+    assert roof["kernel_ms"] > 0 and roof["launches_timed"] == 5 and roof["frames_per_launch"] == 64.0
     # the non-overlapped kernel time per frame cannot exceed the wall clock per frame
-    assert roof["kernel_ms_exclusive"] / 2 <= j["ms_per_step"] * 1.02          # (one launch per two steps)
+    assert roof["kernel_ms_exclusive"] / 4 <= j["ms_per_step"] * 1.02          # (one launch per four steps)
     assert roof["kernel_ms_exclusive"] <= roof["kernel_ms"] * 1.02
     # measured by this run (rocprofv3 is on the box): HBM-side traffic, a real fraction, the issue figures
     assert roof["traffic"] is not None and roof["traffic"] > 0, roof.get("pmc_log")
@@ -60,7 +60,7 @@ def test_two_rank_rehearsal_line(scaling, image):
     j = _line(r.stdout)
     assert (j["n_gpus"], j["steps"], j["scaling"]) == (2, 4, scaling) and j["config"]["image"] == image and "cpu_baseline" not in j
     assert "tile-split x2" in j["config"]["parallelism"] and j["value"] > 100
-    assert j["config"]["frames_per_launch"] == 64.0         # a rank of a 2-way split batches 64 frames = 4 steps per launch
+    assert j["config"]["frames_per_launch"] == 64.0         # 4 steps = 64 frames: one launch (a rank of a 2-way split batches up to 128)
 
 
 def test_strong_and_weak_scaling_agree_on_one_gpu():

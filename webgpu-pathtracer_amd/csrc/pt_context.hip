@@ -133,7 +133,7 @@ struct mi3pt_ctx {
     // Anything that observes or changes device state flushes the queue first.
     struct PendingFrame { uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE]; uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE]; };
     std::vector<PendingFrame> pending;
-    int batch_max = 32;                  // MI3PT_BATCH (1 = no batching); x nranks for a tile split, see batch_limit().  32: +3 % over 16 (fewer drains), 64: +1 % more
+    int batch_max = 64;                  // MI3PT_BATCH (1 = no batching); x nranks for a tile split, see batch_limit().  16 -> 32: +3 % (fewer drains), 32 -> 64: +2 %, 64 -> 128: +1 %
     // per-launch GPU time of the batched raytrace kernel (HIP events on its own stream)
     hipEvent_t ev_rt[2][2] = {};
     bool ev_rt_pending[2] = { false, false };
