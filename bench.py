@@ -278,6 +278,7 @@ def roofline_block(m, pmc, source, num_cus):
                         "(MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B); L2-to-fabric bytes, Infinity-Cache hits included",
         "kernel": m["kernel"], "kernel_ms": round(kernel_ms, 4), "kernel_ms_exclusive": round(m["kernel_ms_exclusive"], 4),
         "launches_timed": m["launches"], "frames_per_launch": m["frames_per_launch"],
+        "kernel_ms_all_launches": round(m["kernel_ms_all"], 4), "launches_all": m["launches_all"],
         "peak_achievable": HBM_ACHIEVABLE_GBS,
         "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4) if achieved is not None else None,
         # what SURVEY.md 8(d) calls the achieved figure: bytes the algorithm touches (in the reference's layouts, from the
@@ -410,6 +411,7 @@ def main():
             exchange()
             sync_all()
         ctx.reset_counters()
+        warm_ms, warm_launches, _ = ctx.raytrace_launch_stats()      # (the warm-up's launches: for the all-launch average below)
         ctx.raytrace_launch_stats(reset=True)
 
         sync_all()
@@ -432,6 +434,9 @@ def main():
         m = {"job": job, "elapsed": float(t.item()), "total": total, "counters": counters,
              "kernel_ms": launch_ms_total / max(launches, 1), "launches": int(launches),
              "kernel_ms_exclusive": span_ms / max(launches, 1),
+             # average over EVERY launch of the process, warm-up included -- the population `rocprofv3 --stats` averages
+             # (the warm-up's launches can be shorter: W steps need not be a whole number of launches)
+             "kernel_ms_all": (launch_ms_total + warm_ms) / max(launches + warm_launches, 1), "launches_all": int(launches + warm_launches),
              "frames_per_launch": round(launch_frames / max(launches, 1), 2),
              "kernel": (lambda v: {10: "k_raytrace_sm<false,false,true,true,true,true>", 9: "k_raytrace_sm<false,false,true,true,false,true>"}
                         .get(v, f"raytrace kernel variant {v}") + " (persistent raytrace kernel: per-lane state machine, deferred-leaf walk"

@@ -39,6 +39,9 @@ def test_single_gpu_line():
     # the non-overlapped kernel time per frame cannot exceed the wall clock per frame
     assert roof["kernel_ms_exclusive"] / 4 <= j["ms_per_step"] * 1.02          # (one launch per four steps)
     assert roof["kernel_ms_exclusive"] <= roof["kernel_ms"] * 1.02
+    # the average over every launch of the process (what `rocprofv3 --stats` averages): the warm-up's 80 frames are a
+    # 64- and a 16-frame launch
+    assert roof["launches_all"] == 7 and 0 < roof["kernel_ms_all_launches"] < roof["kernel_ms"]
     # measured by this run (rocprofv3 is on the box): HBM-side traffic, a real fraction, the issue figures
     assert roof["traffic"] is not None and roof["traffic"] > 0, roof.get("pmc_log")
     assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
