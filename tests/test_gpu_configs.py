@@ -160,3 +160,91 @@ def test_config5_forest_10m_triangles_4k_tile_split_8(gpu_ctx, orc, forest, env)
     assert pc.max_rel_err(whole[1080:1088], band) <= 1e-4
     ctx.set_tile(0, 1, 8)
     ctx.resize(64, 64)
+
+
+# ---------------------------------------------------------------- the configs at their stated sample counts
+
+def _render_spp(ctx, sc, w, h, spp, variant=0, **kw):
+    """`spp` consecutive 1-spp frames (renderer.ts:369-377: frame = 2, 3, ...) into the running mean."""
+    ctx.set_kernel_variant(variant)
+    ctx.reset()
+    ctx.reset_counters()
+    ctx.set_uniforms(capi.PASS_RAYTRACE, pc.rt_uniforms(sc, w, h, frame=2, bounces=8, **kw).tobytes())
+    ctx.set_uniforms(capi.PASS_ACCUMULATE, pc.acc_uniforms(w, h, 2).tobytes())
+    ctx.submit_frames(capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE, spp)
+    img = ctx.read_texture(capi.TEX_ACCUMULATION)
+    cnt = ctx.counters()
+    ctx.set_kernel_variant(0)
+    return img, cnt
+
+
+def _same_job(got, cgot, ref, cref, pixels):
+    assert pc.same_bits(got, ref), pc.describe_diff(got, ref)
+    for k in pc.PATH_COUNTERS:
+        assert cgot[k] == cref[k], (k, cgot[k], cref[k])
+    assert cgot["pixels"] == pixels and cgot["rays"] == cgot["hits"] + cgot["misses"] and cgot["stack_overflows"] == 0
+    assert (got[..., 3] == 1.0).all()          # (a NaN colour is legitimate: normalize() of a zero vector once in ~10^8 paths, as in the reference)
+
+
+def test_config2_demo_1080p_64spp(gpu_ctx, demo, env):
+    """BASELINE.json config 2 at its stated sample count: 64 spp = one 64-frame launch of the shipped
+    kernel against 64 fused per-pixel-kernel frames (the WGSL control flow verbatim): the same
+    running mean, bit for bit."""
+    w, h, spp = 1920, 1080, 64
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    ref, cref = _render_spp(ctx, demo, w, h, spp, variant=2)
+    got, cgot = _render_spp(ctx, demo, w, h, spp)
+    _same_job(got, cgot, ref, cref, spp * w * h)
+    ctx.resize(64, 64)
+
+
+def test_config3_dragon_class_1080p_256spp(gpu_ctx, dragon, env):
+    """Config 3 at its stated 256 spp (four 64-frame launches on alternating streams)."""
+    w, h, spp = 1920, 1080, 256
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, dragon, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    ref, cref = _render_spp(ctx, dragon, w, h, spp, variant=2)
+    got, cgot = _render_spp(ctx, dragon, w, h, spp)
+    _same_job(got, cgot, ref, cref, spp * w * h)
+    assert cgot["tri_tests"] <= cref["tri_tests"]
+    ctx.resize(64, 64)
+
+
+def test_config4_dragon_dof_4k_1024spp_one_rank_of_4(gpu_ctx, dragon, env):
+    """Config 4 at its stated 1024 spp, for one rank of the 4-way tile split (the ranks share nothing
+    but the final gather; the reassembly is tested above): thin lens on, 256-frame launches."""
+    w, h, spp = 3840, 2160, 1024
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, dragon, env)
+    focal = float(np.linalg.norm(np.array(dragon.camera["position"]) - np.array([0.0, 0.5, 0.0])))
+    kw = dict(aperture=0.03, focal=focal)
+    ctx.set_tile(1, 4, 8)
+    ctx.resize(w, h)
+    assert ctx.batch_capacity() == 256
+    ref, cref = _render_spp(ctx, dragon, w, h, spp, variant=2, **kw)
+    got, cgot = _render_spp(ctx, dragon, w, h, spp, **kw)
+    _same_job(got, cgot, ref, cref, spp * w * ctx.local_rows)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(64, 64)
+
+
+def test_config5_forest_4k_4096spp_one_rank_of_8(gpu_ctx, forest, env):
+    """Config 5 at its stated 4096 spp, for one rank of the 8-way split: sixteen 256-frame launches of
+    the shipped walk (4-ary packets) against the binary culling walk; the per-pixel kernel, which
+    the three-frame test above holds both to, would take a minute for this many frames."""
+    w, h, spp = 3840, 2160, 4096
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, forest, env)
+    ctx.set_tile(3, 8, 8)
+    ctx.resize(w, h)
+    ref, cref = _render_spp(ctx, forest, w, h, spp, variant=9)
+    got, cgot = _render_spp(ctx, forest, w, h, spp, variant=10)
+    assert ctx.active_variant() == 10
+    _same_job(got, cgot, ref, cref, spp * w * ctx.local_rows)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(64, 64)

@@ -218,3 +218,39 @@ def test_demo_scene_1080p_and_the_share_of_boxes_skipped(gpu_ctx, demo, env):
         pc.check_counters(cgot, cref, culled=True)
         assert cgot["box_tests"] < cref["box_tests"]           # (this view: both walks test fewer boxes than the reference)
     ctx.resize(64, 64)
+
+
+def test_nan_rays_take_the_known_answer(gpu_ctx, orc, demo, env):
+    """A triangle whose vertex normals are zero gives normalize(0) = NaN as the shading normal, the
+    bounce direction is NaN, and such a ray passes EVERY box test of the reference's walk (min / max
+    drop the NaNs) while no triangle can accept it: a walk of the whole tree for a miss (18 s per
+    ray on a 10 M-triangle scene).  The culling walks return the miss at once; the pixels (NaNs
+    included) and the path counters equal the oracle's and the per-pixel kernel's, which walk it."""
+    nrm = demo.normals.copy()
+    nrm[::3] = 0.0                          # every third triangle: zero normals at its three vertices
+    sc = scenes.Scene(demo.positions, nrm, demo.material_index, demo.materials, "demo with zero normals")
+    sc.build_bvh(nthreads=2)
+    w, h, frames = 160, 96, (2, 3)
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, sc, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    osc = pc.oracle_scene(orc, sc, env)
+    acc = np.zeros((h, w, 4), np.float32)
+    orays = 0
+    for f in frames:
+        img, oc = orc.raytrace(osc, pc.rt_uniforms(sc, w, h, frame=f, bounces=4).tobytes(), w, h)
+        acc = orc.accumulate(pc.acc_uniforms(w, h, f).tobytes(), w, h, img, acc)
+        orays += oc["rays"]
+    assert np.isnan(acc).any()              # the case is there
+    ref, cref = _render(ctx, sc, w, h, frames, 2, bounces=4)
+    assert pc.same_bits(ref, acc), pc.describe_diff(ref, acc)
+    assert cref["rays"] == orays
+    for variant in (9, 10):
+        got, cgot = _render(ctx, sc, w, h, frames, variant, bounces=4)
+        assert ctx.active_variant() in (variant, 10)
+        assert pc.same_bits(got, acc), pc.describe_diff(got, acc)
+        for k in pc.PATH_COUNTERS:
+            assert cgot[k] == cref[k], (variant, k, cgot[k], cref[k])
+        assert cgot["box_tests"] < 0.7 * cref["box_tests"]       # the NaN rays alone walk ~4 000 boxes each in the reference
+    ctx.resize(64, 64)

@@ -1703,7 +1703,15 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             best.t = PT_INF; best.u = 0.0f; best.v = 0.0f; best.tri = -1;
             
             mode = M_SHADE;
-            if (sc.nnodes != 0) {
+            // A ray with a NaN in its origin or direction (normalize() of a zero vector upstream: it happens once in
+            // ~10^8 paths on real meshes) hits nothing in the reference -- Moller-Trumbore's determinant or its u, v, t
+            // are NaN for EVERY triangle and every acceptance test is then false (raytrace.wgsl:78-116) -- but passes
+            // every box test (min / max drop the NaNs, :136-143), i.e. walks the WHOLE tree: 18 s for one such ray on
+            // the 10 M-triangle forest.  The culling walks, which do not reproduce the reference's test counts anyway,
+            // take the known answer: a miss.  (Variants 1-8 walk it.)
+            const bool nan_ray = CULL && (!(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z) ||
+                                          !(o.x == o.x) || !(o.y == o.y) || !(o.z == o.z));
+            if (sc.nnodes != 0 && !nan_ray) {
                 pre = ray_prepare(o, d, sc.flags);
                 slow_segment = (pre.flags & 8u) != 0u;
                 if (CULL) cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
