@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 for r in $(seq 1 ${1:-3}); do
-  for L in A B; do
+  for L in ${LIBS:-A B}; do
     cp webgpu-pathtracer_amd/lib$L.so webgpu-pathtracer_amd/libmi3pt.so; touch webgpu-pathtracer_amd/libmi3pt.so
     python bench.py --no-pmc --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "
 import sys, json

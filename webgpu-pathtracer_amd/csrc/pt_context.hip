@@ -1166,6 +1166,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
                     p.ref[k] = is_leaf((size_t)c) ? (0x80000000u | (uint32_t)ldi(cr, 40)) : wide_of[(size_t)c];
                     cw[k] = round_up_16(wmax[(size_t)c]);
                     if (!node_box_safe(src, (size_t)c)) p.flags |= 1u << k;
+                    p.flags += 16u;              // bits 4..6: the number of children (the walk's box-test count)
                 }
                 p.cull01 = (cw[0] << 16) | cw[1];
                 p.cull23 = (cw[2] << 16) | cw[3];

@@ -61,7 +61,7 @@ struct WidePacket {
     float b23[12];           // boxes 2 and 3
     uint32_t ref[4];         // child references (leaf: REF_LEAF | triangle, else wide packet index, REF_NONE: empty slot)
     uint32_t cull01, cull23; // culling weights, 16 bits each (as NodePacket::cull)
-    uint32_t flags;          // bits 0-3: box i has a non-zero coordinate outside [2^-70, 2^60]
+    uint32_t flags;          // bits 0-3: box i has a non-zero coordinate outside [2^-70, 2^60]; bits 4-6: number of children
     uint32_t pad;
 };
 static_assert(sizeof(WidePacket) == 128, "two 64-B lines");

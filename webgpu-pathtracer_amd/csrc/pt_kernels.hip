@@ -1278,11 +1278,8 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     const float wgt[4] = { __uint_as_float(w01 & 0xffff0000u), __uint_as_float(w01 << 16),
                                            __uint_as_float(w23 & 0xffff0000u), __uint_as_float(w23 << 16) };
                     float key[4];
-                    uint32_t nvalid = 0u;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const bool valid = cr[k] != PT_REF_NONE;
-                        nvalid += valid ? 1u : 0u;
                         const float dk = wgt[k] * rc;
                         const float tc = fmaxf(fmaxf(fmaf(-dk, fabsf(pre.ix), tn[k].x), fmaf(-dk, fabsf(pre.iy), tn[k].y)), fmaf(-dk, fabsf(pre.iz), tn[k].z));
                         // a child that is missed or skipped becomes an empty entry: the sort below then moves (key, reference)
@@ -1290,7 +1287,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         cr[k] = (hit[k] && !(tc > bt)) ? cr[k] : PT_REF_NONE;
                         key[k] = fmaxf(fmaxf(tn[k].x, tn[k].y), tn[k].z);
                     }
-                    cnt.box += nvalid;
+                    cnt.box += (wf >> 4) & 7u;           // the packet's number of children
                     // far first, near last (popped first): sort the four entries by entry distance, descending
 #define PT_CSWAP(A, B)                                                                         \
                     {                                                                          \
