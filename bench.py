@@ -438,7 +438,7 @@ def main():
              # (the warm-up's launches can be shorter: W steps need not be a whole number of launches)
              "kernel_ms_all": (launch_ms_total + warm_ms) / max(launches + warm_launches, 1), "launches_all": int(launches + warm_launches),
              "frames_per_launch": round(launch_frames / max(launches, 1), 2),
-             "kernel": (lambda v: {10: "k_raytrace_sm<false,false,true,true,true,true>", 9: "k_raytrace_sm<false,false,true,true,false,true>"}
+             "kernel": (lambda v: {10: "k_raytrace_sm<false,false,true,true,true,true,false>", 9: "k_raytrace_sm<false,false,true,true,false,true,false>"}
                         .get(v, f"raytrace kernel variant {v}") + " (persistent raytrace kernel: per-lane state machine, deferred-leaf walk"
                         + (" with exact-image distance culling" if v >= 9 else "") + (" on 4-ary wide packets" if v == 10 else "")
                         + ("; one-sample-per-frame specialisation" if v >= 9 else "") + "; batched frames)")(ctx.active_variant())}

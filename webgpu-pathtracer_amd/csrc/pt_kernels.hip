@@ -985,9 +985,12 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
 // WIDE (kernel variant 10, needs CULL): the walk runs on 4-ary "wide packets" (pt_kernels.h) -- up
 // to four child boxes per node step, half as many dependent round trips per ray.  The leaves reached
 // are exactly the reference's (monotone slab test under nesting).
-template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false, bool WIDE = false, bool SPF1 = false>
+template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false, bool WIDE = false, bool SPF1 = false, bool DIAG = true>
 __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
 {
+    // DIAG = false (the shipped walks' batched launches when no diagnostic buffer is bound): the per-wave step statistics
+    // and stamps are compiled out -- two dozen scalar registers that the walk loop's own scalars were spilled for
+    uint64_t *const wave_times = DIAG ? L.wave_times : nullptr;
     constexpr int DEPTH = PT_SM_LDS_DEPTH;                  // LDS stack entries per lane
     constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
@@ -1094,8 +1097,8 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     };
 
     // diagnostic stamps (only when a buffer is bound): wall clock (100 MHz) and shader clock
-    const uint64_t t_begin_rt = L.wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const uint64_t t_begin_clk = L.wave_times ? __builtin_amdgcn_s_memtime() : 0ull;
+    const uint64_t t_begin_rt = wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const uint64_t t_begin_clk = wave_times ? __builtin_amdgcn_s_memtime() : 0ull;
     uint64_t t_empty_rt = 0ull;
     // diagnostic step statistics (wave-uniform; stored with the stamps)
     uint32_t st_walk_steps = 0, st_walk_lanes = 0, st_leaf_lanes = 0, st_service_steps = 0;
@@ -1201,7 +1204,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 // loads are in flight with the first's, and the lane needs one triangle step less
                 const bool two = L.tri_pair && has_leaf && nl > 1;
                 u_tri += (uint32_t)n_leaf + (L.tri_pair ? (uint32_t)__popcll(__ballot(two)) : 0u);      // (wave-uniform count: scalar)
-                if (L.wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
+                if (wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
                 if (has_leaf) {
                     nl--;
                     const uint32_t ti = stack[(DEPTH - 1 - nl) * 64];
@@ -1247,7 +1250,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 }
             } else {
                 if (!WIDE) u_box += 2u * (uint32_t)n_node;  // proper tree: both children of every popped node are tested (WIDE: per lane)
-                if (L.wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
+                if (wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
                 // (CULL) can any lane's node entries leave the LDS part of its stack in this step?  One pop, then up to two / four pushes.
                 const bool shallow = CULL && __ballot(has_node && sp > NCAP - (WIDE ? 3 : 1)) == 0ull;
                 if (WIDE) {
@@ -1381,7 +1384,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         }
         {
             // ---- walk step: one pop per walking lane (raytrace.wgsl:166-200)
-            if (L.wave_times) { st_walk_steps++; st_walk_lanes += (uint32_t)nwalk; }
+            if (wave_times) { st_walk_steps++; st_walk_lanes += (uint32_t)nwalk; }
             // Wave-uniform choice: when no walking lane needs the plain-division test or the
             // overflow part of the stack, the step runs a version without those branches
             // (stack accesses are plain LDS, both child boxes are tested and pushed without
@@ -1391,7 +1394,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (trav) {
                     sp--;
                     const uint32_t ref = stack[sp * 64];
-                    if (L.wave_times) st_leaf_lanes += (uint32_t)__popcll(__ballot((ref & PT_REF_LEAF) != 0u));
+                    if (wave_times) st_leaf_lanes += (uint32_t)__popcll(__ballot((ref & PT_REF_LEAF) != 0u));
                     if (ref & PT_REF_LEAF) {
                         const uint32_t ti = ref & 0x7fffffffu;
                         const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
@@ -1434,7 +1437,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             if (mode == M_TRAV) {
                 sp--;
                 const uint32_t ref = st_load(sp);
-                if (L.wave_times) st_leaf_lanes += (uint32_t)__popcll(__ballot((ref & PT_REF_LEAF) != 0u));
+                if (wave_times) st_leaf_lanes += (uint32_t)__popcll(__ballot((ref & PT_REF_LEAF) != 0u));
                 if (ref & PT_REF_LEAF) {
                     const uint32_t ti = ref & 0x7fffffffu;
                     const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
@@ -1488,7 +1491,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             if (n_hit >= n_b) do_b = n_b >= L.shade_split;
             else do_hit = n_hit >= L.shade_split;
         }
-        if (L.wave_times) {
+        if (wave_times) {
             st_switch(2);
             st_service_steps++;
             if (feed_empty) st_tail_service++;
@@ -1509,7 +1512,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 }
             }
 #ifdef PT_DIAG_SERVICE
-            if (L.wave_times) st_switch(3);
+            if (wave_times) st_switch(3);
 #endif
             if (shade_hit) {          // trace(), raytrace.wgsl:380-395
                 
@@ -1533,7 +1536,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 else { bounce++; ended = bounce >= un.max_bounces; }
             }
 #ifdef PT_DIAG_SERVICE
-            if (L.wave_times) st_switch(4);
+            if (wave_times) st_switch(4);
 #endif
             if (shade_miss) {         // :396-407
                 
@@ -1564,7 +1567,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             }
         }
 #ifdef PT_DIAG_SERVICE
-        if (L.wave_times) st_switch(5);
+        if (wave_times) st_switch(5);
 #endif
         // refill: free lanes take new jobs
         uint32_t job_px = 0u, job_py = 0u;          // SPF1: the pixel a lane has just been given (used below, in this step)
@@ -1575,7 +1578,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     cur_tile = have_at;
                     if (cur_tile >= ntiles) {
                         feed_empty = true;
-                        if (L.wave_times) {
+                        if (wave_times) {
                             t_empty_rt = __builtin_amdgcn_s_memrealtime();
                             st_live_at_empty = (uint32_t)__popcll(__ballot(mode != M_DEAD || need_segment));
                         }
@@ -1630,7 +1633,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 dead = __ballot(mode == M_DEAD && !need_segment && !mine);
             }
         }
-        if (L.wave_times) st_path_lanes += (uint32_t)__popcll(__ballot(do_b && mode == M_PATH));
+        if (wave_times) st_path_lanes += (uint32_t)__popcll(__ballot(do_b && mode == M_PATH));
         if (do_b && mode == M_PATH) {
             // raytrace.wgsl:441-455: next sample's camera path, or the pixel is finished
             mode = M_DEAD;
@@ -1678,9 +1681,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             }
         }
 #ifdef PT_DIAG_SERVICE
-        if (L.wave_times) st_switch(6);
+        if (wave_times) st_switch(6);
 #endif
-        if (L.wave_times) st_segment_lanes += (uint32_t)__popcll(__ballot(need_segment));
+        if (wave_times) st_segment_lanes += (uint32_t)__popcll(__ballot(need_segment));
         {
             const uint32_t nseg = (uint32_t)__popcll(__ballot(need_segment));
             u_rays += nseg;
@@ -1728,8 +1731,8 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         u_slow += (uint32_t)__popcll(__ballot(slow_segment));
     }
 
-    if (L.wave_times && lane == 0) {
-        uint64_t *w = L.wave_times + (size_t)blockIdx.x * 16;
+    if (wave_times && lane == 0) {
+        uint64_t *w = wave_times + (size_t)blockIdx.x * 16;
         st_switch(2);
         w[8] = st_tri_steps;
         w[9] = st_cyc_node; w[10] = st_cyc_tri; w[11] = st_cyc_service;
@@ -1800,10 +1803,12 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
         const bool one = L.un.samples_per_frame == 1 && !fuse && L.un.max_bounces < 65536 && L.nframes <= 65535;
         if (variant == 10) {                             // the culling walk on 4-ary wide packets
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true, true>), grid, block, 0, s, L);
+            else if (one && !L.wave_times) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true, false>), grid, block, 0, s, L);
             else if (one) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true>), grid, block, 0, s, L);
         } else if (variant == 9) {                       // deferred leaves + exact-image distance culling
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true>), grid, block, 0, s, L);
+            else if (one && !L.wave_times) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, false, true, false>), grid, block, 0, s, L);
             else if (one) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, false, true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true>), grid, block, 0, s, L);
         } else if (variant == 3) {
