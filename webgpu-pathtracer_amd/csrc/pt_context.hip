@@ -94,7 +94,7 @@ struct mi3pt_ctx {
     uint32_t *d_tile_counter = nullptr;
     int job_group = -1;                  // MI3PT_JOB_GROUP, see RtLaunch::job_group; -1 = chosen per tile set in build_launch
     int tri_pair = 1;                    // MI3PT_TRI_PAIR, see RtLaunch::tri_pair
-    int job_chunk = 4;                   // job tickets per draw from the queue (MI3PT_JOB_CHUNK; 1 = one atomic per job)
+    int job_chunk = PT_DEFAULT_JOB_CHUNK;    // job tickets per draw from the queue (MI3PT_JOB_CHUNK; 1 = one atomic per job)
     uint32_t *d_drain_flag = nullptr;     // signal memory: sequence number of the last batched launch that started draining
     bool gate_enabled = false;            // launches wait on d_drain_flag (off when the memory or the wait is unavailable)
     uint32_t launch_seq = 0;              // sequence number of the last batched launch
@@ -110,10 +110,10 @@ struct mi3pt_ctx {
     int storage = MI3PT_STORAGE_F32;
     int variant = 0;
     bool env_sampling = false;  // mi3pt_set_env_sampling: the reference's dormant importance-sampling lines
-    int tail_policy = 7;        // MI3PT_TAIL_POLICY: see RtLaunch::tail_policy
-    int shade_split = 64;       // MI3PT_SHADE_SPLIT: see RtLaunch::shade_split (64: while lanes walk, only the larger group is served)
-    int leaf_min = 24;          // deferred-leaf walk: lanes with a parked leaf that trigger a triangle step (MI3PT_LEAF_MIN)
-    int walk_min = 32;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
+    int tail_policy = PT_DEFAULT_TAIL_POLICY;        // MI3PT_TAIL_POLICY: see RtLaunch::tail_policy
+    int shade_split = PT_DEFAULT_SHADE_SPLIT;       // MI3PT_SHADE_SPLIT: see RtLaunch::shade_split (64: while lanes walk, only the larger group is served)
+    int leaf_min = PT_DEFAULT_LEAF_MIN;          // deferred-leaf walk: lanes with a parked leaf that trigger a triangle step (MI3PT_LEAF_MIN)
+    int walk_min = PT_DEFAULT_WALK_MIN;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
     int waves_per_cu = 16;      // 8 KB of LDS per one-wave workgroup, 128 VGPRs
     int top_packets = 64;       // MI3PT_TOP_PACKETS
 

@@ -124,6 +124,13 @@ struct Tile {
     int32_t rank, nranks, block_rows;
 };
 
+// The step-voting knobs' defaults (the context's initial values; the shipped kernels' tuned instantiation has them as constants)
+#define PT_DEFAULT_WALK_MIN 32
+#define PT_DEFAULT_LEAF_MIN 24
+#define PT_DEFAULT_SHADE_SPLIT 64
+#define PT_DEFAULT_TAIL_POLICY 7
+#define PT_DEFAULT_JOB_CHUNK 4
+
 struct RtLaunch {
     SceneRefs scene;
     RtUniforms un;

@@ -991,6 +991,11 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     // DIAG = false (the shipped walks' batched launches when no diagnostic buffer is bound): the per-wave step statistics
     // and stamps are compiled out -- two dozen scalar registers that the walk loop's own scalars were spilled for
     uint64_t *const wave_times = DIAG ? L.wave_times : nullptr;
+    // ... and the step-voting knobs are the defaults as constants (launch_raytrace sends any other setting to the DIAG twin)
+    const int k_walk_min = DIAG ? L.walk_min : PT_DEFAULT_WALK_MIN, k_leaf_min = DIAG ? L.leaf_min : PT_DEFAULT_LEAF_MIN;
+    const int k_shade_split = DIAG ? L.shade_split : PT_DEFAULT_SHADE_SPLIT, k_tail_policy = DIAG ? L.tail_policy : PT_DEFAULT_TAIL_POLICY;
+    const int k_job_chunk = DIAG ? L.job_chunk : PT_DEFAULT_JOB_CHUNK;
+    const bool k_tri_pair = DIAG ? L.tri_pair != 0 : true;
     constexpr int DEPTH = PT_SM_LDS_DEPTH;                  // LDS stack entries per lane
     constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
@@ -1142,7 +1147,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     // draws per wave left) tickets are drawn singly, so that no wave sits on jobs while others run dry.
     int have = 0, have_at = 0;           // tickets in hand: have_at, have_at + 1, ... (`have` of them)
     auto draw = [&]() {
-        const int c = (ntiles - have_at > 2 * L.job_chunk * (int)gridDim.x) ? L.job_chunk : 1;
+        const int c = (ntiles - have_at > 2 * k_job_chunk * (int)gridDim.x) ? k_job_chunk : 1;
         int t = 0;
         if (lane == 0) {
             t = (int)atomicAdd(L.tile_counter, (uint32_t)c);
@@ -1175,13 +1180,13 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         const unsigned long long waiting = __ballot(mode == M_SHADE || mode == M_PATH);
         serviceable = feed_empty ? (waiting != 0ull) : (walking != ~0ull);
         nwalk = (int)__popcll(walking);
-        if (feed_empty && (L.tail_policy & 2)) {
+        if (feed_empty && (k_tail_policy & 2)) {
             // Drain (no jobs left, the wave only finishes the paths it holds): the walk_min rule would
             // run a service step -- 2.4 node steps long -- for every single lane that ends a segment.
             // Waiting lanes are served once they are at least half as many as the walking ones.
             if (!(nwalk > 0 && 2 * (int)__popcll(waiting) < nwalk)) break;
         } else
-        if (!(nwalk > 0 && (nwalk >= L.walk_min || !serviceable))) break;
+        if (!(nwalk > 0 && (nwalk >= k_walk_min || !serviceable))) break;
         if (DEFER) {
             // ---- deferred-leaf walk (scenes whose leaves may be tested in any order: SceneRefs::
             // leaf_cap > 0).  In the in-order walk below a step runs the box tests for ~39 lanes
@@ -1199,11 +1204,11 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             const bool full = __ballot(trav && nl > lcap - (WIDE ? 4 : 2)) != 0ull;      // a node step may park two (WIDE: four) more
             // (drain: whichever kind of step serves more lanes -- waiting for n_node == 0 would leave the lanes
             // that only have leaves idle for as long as the slowest descent takes)
-            if (full || n_node == 0 || n_leaf >= L.leaf_min || (feed_empty && (L.tail_policy & 1) && n_leaf >= n_node)) {
+            if (full || n_node == 0 || n_leaf >= k_leaf_min || (feed_empty && (k_tail_policy & 1) && n_leaf >= n_node)) {
                 // every lane with a parked leaf tests one -- or two, when it has two (L.tri_pair): the second triangle's
                 // loads are in flight with the first's, and the lane needs one triangle step less
-                const bool two = L.tri_pair && has_leaf && nl > 1;
-                u_tri += (uint32_t)n_leaf + (L.tri_pair ? (uint32_t)__popcll(__ballot(two)) : 0u);      // (wave-uniform count: scalar)
+                const bool two = k_tri_pair && has_leaf && nl > 1;
+                u_tri += (uint32_t)n_leaf + (k_tri_pair ? (uint32_t)__popcll(__ballot(two)) : 0u);      // (wave-uniform count: scalar)
                 if (wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
                 if (has_leaf) {
                     nl--;
@@ -1487,9 +1492,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         const int n_hit = (int)__popcll(m_hit);
         const int n_b = (int)__popcll(__ballot((mode == M_SHADE && best.tri < 0) || mode == M_PATH || (mode == M_DEAD && !feed_empty)));
         bool do_hit = n_hit > 0, do_b = true;
-        if (L.shade_split > 0 && nwalk > 0 && n_hit > 0 && n_b > 0 && !(feed_empty && (L.tail_policy & 4))) {
-            if (n_hit >= n_b) do_b = n_b >= L.shade_split;
-            else do_hit = n_hit >= L.shade_split;
+        if (k_shade_split > 0 && nwalk > 0 && n_hit > 0 && n_b > 0 && !(feed_empty && (k_tail_policy & 4))) {
+            if (n_hit >= n_b) do_b = n_b >= k_shade_split;
+            else do_hit = n_hit >= k_shade_split;
         }
         if (wave_times) {
             st_switch(2);
@@ -1686,7 +1691,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         if (wave_times) st_segment_lanes += (uint32_t)__popcll(__ballot(need_segment));
         {
             const uint32_t nseg = (uint32_t)__popcll(__ballot(need_segment));
-            u_rays += nseg;
+            if (DIAG) u_rays += nseg;          // (shipped kernels: every segment ends in a hit or a miss, counted there)
             if (sc.nnodes != 0) u_box += nseg;      // the root box test
         }
         bool slow_segment = false;
@@ -1728,7 +1733,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 }
             }
         }
-        u_slow += (uint32_t)__popcll(__ballot(slow_segment));
+        if (DIAG) u_slow += (uint32_t)__popcll(__ballot(slow_segment));
     }
 
     if (wave_times && lane == 0) {
@@ -1763,7 +1768,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             __hip_atomic_store(L.tile_counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    const uint32_t s_rays = u_rays, s_box = wave_sum(cnt.box) + u_box, s_tri = wave_sum(cnt.tri) + u_tri;
+    const uint32_t s_rays = DIAG ? u_rays : u_hit + u_miss, s_box = wave_sum(cnt.box) + u_box, s_tri = wave_sum(cnt.tri) + u_tri;
     const uint32_t s_hit = u_hit, s_miss = u_miss;
     const uint32_t s_ovf = wave_sum(cnt.overflow), s_pix = u_pix, s_slow = u_slow;
     if (lane == 0 && L.block_counters) {
@@ -1801,14 +1806,18 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
         // (SPF1: the shipped walks' batched launches have a specialisation for samplesPerFrame == 1, the reference's
         // default -- no per-pixel sum and sample counter to carry through the walk: five registers less)
         const bool one = L.un.samples_per_frame == 1 && !fuse && L.un.max_bounces < 65536 && L.nframes <= 65535;
+        // the tuned twin: no diagnostic buffer and every step-voting knob at its default (baked in as constants there)
+        const bool tuned = one && !L.wave_times && L.walk_min == PT_DEFAULT_WALK_MIN && L.leaf_min == PT_DEFAULT_LEAF_MIN &&
+                           L.shade_split == PT_DEFAULT_SHADE_SPLIT && L.tail_policy == PT_DEFAULT_TAIL_POLICY &&
+                           L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1;
         if (variant == 10) {                             // the culling walk on 4-ary wide packets
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true, true>), grid, block, 0, s, L);
-            else if (one && !L.wave_times) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true, false>), grid, block, 0, s, L);
+            else if (tuned) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true, false>), grid, block, 0, s, L);
             else if (one) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true>), grid, block, 0, s, L);
         } else if (variant == 9) {                       // deferred leaves + exact-image distance culling
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true>), grid, block, 0, s, L);
-            else if (one && !L.wave_times) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, false, true, false>), grid, block, 0, s, L);
+            else if (tuned) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, false, true, false>), grid, block, 0, s, L);
             else if (one) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, false, true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true>), grid, block, 0, s, L);
         } else if (variant == 3) {
