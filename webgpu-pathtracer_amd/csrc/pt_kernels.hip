@@ -748,10 +748,12 @@ PT_DEV void write_pixel(const RtLaunch &L, uint32_t gx, uint32_t gy, uint32_t ly
 }
 
 // unfused store of one finished (pixel, frame slot): texel index within the slot's image
+template <bool F32_STORAGE = false>
 PT_DEV void write_radiance(const RtLaunch &L, uint32_t texel, uint32_t slot, f3 color)
 {
+    const int f16 = F32_STORAGE ? 0 : L.store_f16;
     L.radiance[(size_t)slot * L.slot_pixels + texel] =
-        make_float4(store_round(color.x, L.store_f16), store_round(color.y, L.store_f16), store_round(color.z, L.store_f16), 1.0f);
+        make_float4(store_round(color.x, f16), store_round(color.y, f16), store_round(color.z, f16), 1.0f);
 }
 
 struct PathSlot {
@@ -996,6 +998,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     const int k_shade_split = DIAG ? L.shade_split : PT_DEFAULT_SHADE_SPLIT, k_tail_policy = DIAG ? L.tail_policy : PT_DEFAULT_TAIL_POLICY;
     const int k_job_chunk = DIAG ? L.job_chunk : PT_DEFAULT_JOB_CHUNK;
     const bool k_tri_pair = DIAG ? L.tri_pair != 0 : true;
+    // ... as are: a scene with nodes whose root is an internal node with a guard-range box, fp32 texel storage, a
+    // resolution of ordinary magnitude, maxBounces > 0
+    constexpr bool TUNED = !DIAG;
     constexpr int DEPTH = PT_SM_LDS_DEPTH;                  // LDS stack entries per lane
     constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
@@ -1084,15 +1089,15 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     ptm::sincos(un.env_rotation, sinr, cosr);
     sinr = uni(sinr); cosr = uni(cosr);
     float4 root0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), root1 = root0;
-    if (sc.nnodes != 0) { root0 = sc.nodes[0]; root1 = sc.nodes[1]; }
+    if (TUNED || sc.nnodes != 0) { root0 = sc.nodes[0]; root1 = sc.nodes[1]; }
     root0 = make_float4(uni(root0.x), uni(root0.y), uni(root0.z), uni(root0.w));
     root1 = make_float4(uni(root1.x), uni(root1.y), uni(root1.z), uni(root1.w));
     // per-pixel divisions by launch-invariant divisors: 1 / resolution once, and pixel / resolution
     // as an exact quotient from that reciprocal (ptm::div_pre; pixel indices are 0 or >= 1, so the
     // only proviso is a resolution of ordinary magnitude -- otherwise the plain division runs)
     const float inv_res_x = uni(1.0f / un.res_x), inv_res_y = uni(1.0f / un.res_y);
-    const bool res_ordinary = un.res_x >= 9.5367431640625e-07f && un.res_x <= 1.099511627776e12f &&
-                              un.res_y >= 9.5367431640625e-07f && un.res_y <= 1.099511627776e12f;
+    const bool res_ordinary = TUNED || (un.res_x >= 9.5367431640625e-07f && un.res_x <= 1.099511627776e12f &&
+                                        un.res_y >= 9.5367431640625e-07f && un.res_y <= 1.099511627776e12f);
     // thin lens off (aperture exactly 0, no -0 camera coordinate): see the camera path start
     const bool pinhole = un.aperture == 0.0f && __float_as_uint(un.cam_pos[0]) != 0x80000000u &&
                          __float_as_uint(un.cam_pos[1]) != 0x80000000u && __float_as_uint(un.cam_pos[2]) != 0x80000000u;
@@ -1547,7 +1552,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 
                 float u, v;
                 env_uv_from_dir(d, sinr, cosr, u, v);
-                const f3 env = sample_env(sc.env, sc.env_w, sc.env_h, u, v);
+                const f3 env = sample_env(sc.env, TUNED ? 1024 : sc.env_w, TUNED ? 512 : sc.env_h, u, v);      // (the environment texture is 1024 x 512 by the API: renderer.ts:76-85)
                 light = light + (ray_color * env) * un.env_intensity;
             }
             if (shade_hit || shade_miss) {
@@ -1555,7 +1560,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (ended) {
                     if constexpr (SPF1) {
                         // one sample per frame: the pixel is finished (:455, :477); incomingLight = 0 + light
-                        write_radiance(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
+                        write_radiance<TUNED>(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
                     } else {
                         incoming = incoming + light;
                         sample++;
@@ -1675,9 +1680,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if constexpr (SPF1) slot &= 0xffff0000u; else bounce = 0;
                 light = F3(0.0f, 0.0f, 0.0f);
                 ray_color = F3(1.0f, 1.0f, 1.0f);
-                if (un.max_bounces > 0) { need_segment = true; break; }
+                if (TUNED || un.max_bounces > 0) { need_segment = true; break; }
                 if constexpr (SPF1) {       // (max_bounces == 0: the path is over before it began)
-                    write_radiance(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
+                    write_radiance<TUNED>(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
                     break;
                 } else {
                     incoming = incoming + light;
@@ -1692,7 +1697,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         {
             const uint32_t nseg = (uint32_t)__popcll(__ballot(need_segment));
             if (DIAG) u_rays += nseg;          // (shipped kernels: every segment ends in a hit or a miss, counted there)
-            if (sc.nnodes != 0) u_box += nseg;      // the root box test
+            if (TUNED || sc.nnodes != 0) u_box += nseg;      // the root box test
         }
         bool slow_segment = false;
         if constexpr (SPF1) {
@@ -1716,13 +1721,13 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             // take the known answer: a miss.  (Variants 1-8 walk it.)
             const bool nan_ray = CULL && (!(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z) ||
                                           !(o.x == o.x) || !(o.y == o.y) || !(o.z == o.z));
-            if (sc.nnodes != 0 && !nan_ray) {
+            if ((TUNED || sc.nnodes != 0) && !nan_ray) {
                 pre = ray_prepare(o, d, sc.flags);
                 slow_segment = (pre.flags & 8u) != 0u;
                 if (CULL) cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
                 
-                if (ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
-                    if (DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
+                if (ray_aabb_pre(o, d, pre, !TUNED && (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
+                    if (!TUNED && DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
                         stack[(DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu;
                         sp = 0; nl = 1;
                     } else {
@@ -1809,7 +1814,11 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
         // the tuned twin: no diagnostic buffer and every step-voting knob at its default (baked in as constants there)
         const bool tuned = one && !L.wave_times && L.walk_min == PT_DEFAULT_WALK_MIN && L.leaf_min == PT_DEFAULT_LEAF_MIN &&
                            L.shade_split == PT_DEFAULT_SHADE_SPLIT && L.tail_policy == PT_DEFAULT_TAIL_POLICY &&
-                           L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1;
+                           L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 &&
+                           L.scene.nnodes != 0 && (L.scene.flags & 1u) != 0u && (L.scene.root_ref & PT_REF_LEAF) == 0u && !L.store_f16 &&
+                           L.scene.env_w == 1024 && L.scene.env_h == 512 &&
+                           L.un.max_bounces > 0 && L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
+                           L.un.res_y >= 9.5367431640625e-07f && L.un.res_y <= 1.099511627776e12f;
         if (variant == 10) {                             // the culling walk on 4-ary wide packets
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true, true>), grid, block, 0, s, L);
             else if (tuned) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true, false>), grid, block, 0, s, L);
