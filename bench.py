@@ -301,8 +301,10 @@ def roofline_block(m, pmc, source, num_cus):
                                     "waiting_for_memory": round(pmc.get("SQ_WAIT_ANY", 0.0) / wc, 3),
                                     "issue_stalled": round(pmc.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3)}
         block["pmc_counters"] = {k: round(v, 1) for k, v in sorted(pmc.items())}
-        block["real_bound"] = ("per-wave latency: dependent VALU chains + divergent 64-B gathers at 4 waves per SIMD; "
-                               "VALU issue x lane utilisation is the fraction of the machine's lane-op rate in use")
+        block["real_bound"] = ("per-wave latency: each step is a dependent chain of one LDS and one L2 / fabric round trip (a divergent "
+                               "64- or 128-B packet gather) and a few hundred instructions that a single wave issues at one per 4 cycles, "
+                               "with 4 waves per SIMD (128 VGPRs) to overlap them; VALU issue x lane utilisation is the fraction of the "
+                               "machine's lane-op rate in use")
     return block
 
 
