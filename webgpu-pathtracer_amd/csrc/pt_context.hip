@@ -79,7 +79,7 @@ struct mi3pt_ctx {
     float4 *d_radiance = nullptr, *d_accum_own = nullptr, *d_accum = nullptr, *d_canvas = nullptr;
     // Batched frames write per-frame radiance slots, one set per launch parity.  Allocated on
     // demand (an interactive host that presents every frame only ever needs one slot per
-    // parity; a batch of n > 1 frames allocates the next power of two, at most batch_cap), see ensure_slots().
+    // parity; up to 8 frames: 8 slots; more: the full batch_cap once), see ensure_slots().
     // Two sets, one per launch parity.  (MI3PT_SLOT_SETS=3, experiment: launch k+2 then reuses launch k's stream and
     // counters but not its slots, so it need not wait for the ordered mean of batch k -- which only finds room on the
     // GPU when launch k+1 drains.  Measured twice: dragon-class -1.8 %, demo +1.3 %: not the critical path.)
@@ -1292,16 +1292,16 @@ static int collect_rt_time(mi3pt_ctx *ctx, int par)
 }
 
 // Makes sure parity `par`'s slot set can hold n frames.  One frame: a single slot (the interactive
-// hosts never need more).  More: the next power of two (at most batch_cap), so a batching caller allocates once or twice.
+// hosts never need more).  Up to eight frames: eight.  More: the full batch_cap at once, so a batching caller allocates once.
 // Growing frees the old set (hipFree waits for the device, so nothing still reads it).
 static int ensure_slots(mi3pt_ctx *ctx, int par /* slot set */, int n)
 {
     if (ctx->slots_alloc[par] >= n) return MI3PT_OK;
     const size_t tex_bytes = (size_t)ctx->local_rows * ctx->width * 16;
-    // the next power of two, at most the launch depth: a host that queues a few frames at a time does not pay
-    // for (or wait seconds for the allocation of) 2 x 64 ... 256 full images it never fills
-    int want = 1;
-    while (want < n) want *= 2;
+    // one frame: one slot; up to eight: eight (a host that queues a few frames at a time does not pay for -- or wait
+    // seconds for the allocation of -- 2 x 64 ... 256 full images it never fills); more: the full launch depth at
+    // once, so that a batching caller allocates once and not again in the middle of its job
+    int want = n <= 1 ? 1 : (n <= 8 ? 8 : ctx->batch_cap);
     if (want > ctx->batch_cap) want = ctx->batch_cap;
     if (want < n) want = n;
     float4 *fresh = nullptr;
