@@ -92,6 +92,7 @@ struct mi3pt_ctx {
     bool output_is_accum = false;
     uint64_t *d_block_counters = nullptr;
     uint32_t *d_tile_counter = nullptr;
+    int job_reverse = 1;                 // MI3PT_JOB_REVERSE, see RtLaunch::job_reverse (the top band last: +0.5 % with the sky up there)
     int job_group = -1;                  // MI3PT_JOB_GROUP, see RtLaunch::job_group; -1 = chosen per tile set in build_launch
     int tri_pair = 1;                    // MI3PT_TRI_PAIR, see RtLaunch::tri_pair
     int job_chunk = PT_DEFAULT_JOB_CHUNK;    // job tickets per draw from the queue (MI3PT_JOB_CHUNK; 1 = one atomic per job)
@@ -273,6 +274,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     if (const char *e = std::getenv("MI3PT_CULL")) ctx->cull_enabled = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI3PT_WIDE")) ctx->wide_enabled = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI3PT_TRI_PAIR")) ctx->tri_pair = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MI3PT_JOB_REVERSE")) ctx->job_reverse = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI3PT_JOB_GROUP")) ctx->job_group = std::atoi(e);
     if (const char *e = std::getenv("MI3PT_JOB_CHUNK")) { ctx->job_chunk = std::atoi(e); if (ctx->job_chunk < 1 || ctx->job_chunk > 64) ctx->job_chunk = 1; }
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
@@ -1243,6 +1245,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.block_counters = ctx->d_block_counters;
     L.tile_counter = ctx->d_tile_counter;
     L.job_chunk = ctx->job_chunk;
+    L.job_reverse = ctx->job_reverse;
     L.tri_pair = ctx->tri_pair;
     L.job_group = ctx->job_group;
     if (ctx->job_group < 0) {

@@ -144,6 +144,7 @@ struct RtLaunch {
     uint32_t *tile_counter;      // work queue head of the persistent kernel (zeroed per launch)
     int32_t job_group;           // state-machine kernel: 0 = jobs frame-major; n = every frame of n consecutive tiles before the next n tiles
     int32_t tri_pair;            // deferred-leaf walks: a triangle step tests two parked triangles of a lane that has two
+    int32_t job_reverse;         // state-machine kernel: 1 = the job sequence backwards (the image's top band, usually sky, last)
     int32_t job_chunk;           // state-machine kernel: job tickets per draw from the queue while it is long (>= 1)
     uint32_t *stack_overflow;    // state-machine kernel: [grid][32][64] stack entries beyond the LDS part
     uint64_t *wave_times;        // diagnostic: [grid][4] begin / feed-empty / end (100 MHz) + shader cycles, or null

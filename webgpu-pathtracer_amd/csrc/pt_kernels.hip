@@ -1594,6 +1594,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         }
                         break;
                     }
+                    if (L.job_reverse) cur_tile = ntiles - 1 - cur_tile;      // the launch's jobs in reverse order: bottom band first, top band last
                     if (grp_jobs == 0) {            // frame-major
                         cur_fslot = cur_tile / ntiles_frame;
                         cur_ftile = cur_tile - cur_fslot * ntiles_frame;
