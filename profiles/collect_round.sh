@@ -11,26 +11,11 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
-python bench.py > $OUT/${TAG}_dragon_1080p_bench.json 2> $OUT/${TAG}_dragon_bench.err
-echo "bench (default args) done: $(cut -c1-120 $OUT/${TAG}_dragon_1080p_bench.json)"
-python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_dragon_1080p_bench_driver_args.json 2>/dev/null
-echo "bench (driver args) done: $(cut -c1-120 $OUT/${TAG}_dragon_1080p_bench_driver_args.json)"
-python bench.py --workload demo > $OUT/${TAG}_demo_1080p_bench.json 2>/dev/null
-echo "bench (demo) done: $(cut -c1-120 $OUT/${TAG}_demo_1080p_bench.json)"
-for A in "" "--steps 20 --warmup 5"; do
-  S=$(echo "$A" | tr -d ' -' ); S=${S:-default}
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_$S -- python3 $ROOT/bench.py --no-cpu-baseline --no-also $A > $OUT/${TAG}_bench_under_rocprof_$S.json 2> $OUT/${TAG}_stats_$S.err)
-  cp $(ls $OUT/${TAG}_stats_$S/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_dragon_1080p_kernel_stats_$S.csv
-  cp $(ls $OUT/${TAG}_stats_$S/*/*_kernel_trace.csv | head -1) $OUT/${TAG}_dragon_1080p_kernel_trace_$S.csv
-  rm -rf $OUT/${TAG}_stats_$S
-done
-echo "rocprof stats done"
-STEPS=20; WARM=5
-bash profiles/pmc_passes.sh gpurun_out/${TAG}_pmc_dragon --steps $STEPS --warmup $WARM
-python profiles/pmc_summary.py $OUT/${TAG}_pmc_dragon k_raytrace $((STEPS / 4)) > $OUT/${TAG}_dragon_pmc_per_launch.txt
-rm -rf $OUT/${TAG}_pmc_dragon $OUT/${TAG}_pmc_dragon.pass*.log
-echo "pmc passes done: $(grep -c . $OUT/${TAG}_dragon_pmc_per_launch.txt) counters"
+# Order matters on this pool: a box that has just run counter (--pmc) passes is slow for a while (clocks), so everything
+# that is timed without counters runs first, and the three bench lines -- each ends with its own counter passes -- are
+# spaced out.
 python profiles/scaling_model.py --steps 20 --warmup 5 > $OUT/${TAG}_scaling_model_steps20.log 2>&1
+python profiles/scaling_model.py --steps 16 --warmup 2 > $OUT/${TAG}_scaling_model_steps16.log 2>&1
 python profiles/scaling_model.py --steps 4 --warmup 1 > $OUT/${TAG}_scaling_model_steps4.log 2>&1
 echo "scaling model done"
 (python profiles/cull_probe.py demo; python profiles/cull_probe.py dragon; python profiles/cull_probe.py forest 3840x2160 8) > $OUT/${TAG}_cull_probe.log 2>&1
@@ -45,3 +30,17 @@ from mi3pt_host import scenes
 scenes.synthetic_env().tofile('/tmp/env.f32')"
 node webgpu-pathtracer_amd/js/tools/bench_render_loop.js --env /tmp/env.f32 --frames 64 > $OUT/${TAG}_node_render_loop.json 2>&1
 echo "timelines + loop bench done"
+bash profiles/rocprof_stats.sh $TAG
+python bench.py > $OUT/${TAG}_dragon_1080p_bench.json 2> $OUT/${TAG}_dragon_bench.err
+echo "bench (default args) done: $(cut -c1-120 $OUT/${TAG}_dragon_1080p_bench.json)"
+sleep 45
+python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_dragon_1080p_bench_driver_args.json 2>/dev/null
+echo "bench (driver args) done: $(cut -c1-120 $OUT/${TAG}_dragon_1080p_bench_driver_args.json)"
+sleep 45
+python bench.py --workload demo > $OUT/${TAG}_demo_1080p_bench.json 2>/dev/null
+echo "bench (demo) done: $(cut -c1-120 $OUT/${TAG}_demo_1080p_bench.json)"
+STEPS=20; WARM=5
+bash profiles/pmc_passes.sh gpurun_out/${TAG}_pmc_dragon --steps $STEPS --warmup $WARM
+python profiles/pmc_summary.py $OUT/${TAG}_pmc_dragon k_raytrace $((STEPS / 4)) > $OUT/${TAG}_dragon_pmc_per_launch.txt
+rm -rf $OUT/${TAG}_pmc_dragon $OUT/${TAG}_pmc_dragon.pass*.log
+echo "pmc passes done: $(grep -c . $OUT/${TAG}_dragon_pmc_per_launch.txt) counters"
