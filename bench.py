@@ -55,7 +55,7 @@ for p in (os.path.join(ROOT, "webgpu-pathtracer_amd", "py"), os.path.join(ROOT, 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0     # same guide: what a streaming kernel reaches
 SHADER_CLOCK_HZ = 2.4e9         # peak engine clock used for the VALU issue rate
-BLOCK_ROWS = 8
+BLOCK_ROWS = int(os.environ.get("MI3PT_BENCH_BLOCK_ROWS", "8"))     # rows per block of the tile split (experiment knob)
 BOUNCES = 8
 FRAMES_PER_STEP = 16            # one step = one batch = one launch of the persistent kernel (single GPU)
 KERNEL_NEEDLE = "k_raytrace_sm"
