@@ -568,6 +568,8 @@ PT_DEV f3 camera_direction(const CameraFrame &cf, float aspect, float uvx, float
 
 PT_DEV int local_to_global_row(int ly, const Tile &t)
 {
+    if (t.nranks == 1) return ly;                     // (wave-uniform fast paths: no division for the whole image ...
+    if (t.block_rows == 8) return ((((ly >> 3) * t.nranks + t.rank) << 3) | (ly & 7));      // ... nor for the usual 8-row blocks)
     const int b = ly / t.block_rows;
     return (b * t.nranks + t.rank) * t.block_rows + (ly - b * t.block_rows);
 }
