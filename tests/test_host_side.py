@@ -318,3 +318,22 @@ def test_renderer_rejects_bad_environment():
         r.updateEnvironmentTexture(np.zeros((256, 512, 4), np.float32))
     with pytest.raises(capi.Mi3ptError, match="floating point"):
         r.updateEnvironmentTexture(np.zeros((512, 1024, 4), np.uint8))
+
+
+def test_ticket_division_by_multiplication():
+    """The job decode of the persistent kernel divides tickets (< 2^31) by launch-invariant divisors as
+    floor(t m / 2^(31+s)), s = ceil(log2 d), m = floor(2^(31+s) / d) + 1 (pt_kernels.hip fast_div_of /
+    fast_div): the identity behind it, on edge cases and a random sample, in exact integers."""
+    import random
+    rng = random.Random(7)
+    ds = [1, 2, 3, 5, 7, 8, 240, 241, 255, 256, 257, 3840, 4050, 16320, 129600, 1036800, 2**20 - 1, 2**20, 2**20 + 1,
+          2**30, 2**31 - 1] + [rng.randrange(1, 2**31) for _ in range(300)]
+    for d in ds:
+        s = 0 if d <= 1 else (d - 1).bit_length()
+        sh = 31 + s
+        m = (1 << sh) // d + 1
+        assert m < 2**32
+        ts = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 2**31 - 1, 2**31 - d if d < 2**31 else 0] + [rng.randrange(0, 2**31) for _ in range(200)]
+        for t in ts:
+            if 0 <= t < 2**31:
+                assert (t * m) >> sh == t // d, (t, d)

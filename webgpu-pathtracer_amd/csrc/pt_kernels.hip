@@ -566,6 +566,21 @@ PT_DEV f3 camera_direction(const CameraFrame &cf, float aspect, float uvx, float
     return normalize((cf.u_dir * u + cf.v_dir * v) - cf.w * aspect);
 }
 
+// Division of a job ticket (< 2^31) by a launch-invariant divisor d >= 1 as a multiplication: with s = ceil(log2 d)
+// and m = floor(2^(31+s) / d) + 1 (which fits 32 bits), floor(t m / 2^(31+s)) = floor(t / d) for every 0 <= t < 2^31
+// (Granlund & Montgomery: m d exceeds 2^(31+s) by at most d <= 2^s, so t m / 2^(31+s) overshoots t / d by less than
+// 2^-s <= 1 / d).  The job decode divides three times per job; in scalar registers this is two multiplies and a shift.
+struct FastDiv { uint32_t m, sh; };
+PT_DEV FastDiv fast_div_of(uint32_t d)
+{
+    FastDiv f;
+    const uint32_t s = d <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(d - 1u);
+    f.sh = 31u + s;
+    f.m = (uint32_t)((1ull << f.sh) / (d ? d : 1u)) + 1u;
+    return f;
+}
+PT_DEV int fast_div(int t, const FastDiv &f) { return (int)(uint32_t)(((uint64_t)(uint32_t)t * f.m) >> f.sh); }
+
 PT_DEV int local_to_global_row(int ly, const Tile &t)
 {
     if (t.nranks == 1) return ly;                     // (wave-uniform fast paths: no division for the whole image ...
@@ -1173,6 +1188,11 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     int cur_tile = 0, cur_used = 64, cur_fslot = 0, cur_ftile = 0;
     const int grp_jobs = (L.job_group > 0 && L.job_group < ntiles_frame) ? L.job_group * L.nframes : 0;
     const int grp_full = grp_jobs ? ntiles_frame / L.job_group : 0;
+    const int grp_last = grp_jobs ? ntiles_frame - grp_full * L.job_group : 1;       // tiles in the (shorter) last group
+    auto uni_div = [](FastDiv f) { f.m = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.m); f.sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.sh); return f; };
+    const FastDiv dv_frame = uni_div(fast_div_of((uint32_t)ntiles_frame)), dv_grp = uni_div(fast_div_of((uint32_t)(grp_jobs ? grp_jobs : 1)));
+    const FastDiv dv_gs = uni_div(fast_div_of((uint32_t)(L.job_group > 0 ? L.job_group : 1))), dv_last = uni_div(fast_div_of((uint32_t)(grp_last > 0 ? grp_last : 1)));
+    const FastDiv dv_tx = uni_div(fast_div_of((uint32_t)tiles_x));
     draw();
     bool feed_empty = false;
 
@@ -1598,12 +1618,13 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     }
                     if (L.job_reverse) cur_tile = ntiles - 1 - cur_tile;      // the launch's jobs in reverse order: bottom band first, top band last
                     if (grp_jobs == 0) {            // frame-major
-                        cur_fslot = cur_tile / ntiles_frame;
+                        cur_fslot = fast_div(cur_tile, dv_frame);
                         cur_ftile = cur_tile - cur_fslot * ntiles_frame;
                     } else {                        // groups of L.job_group tiles, every frame of a group before the next group
-                        int g = cur_tile / grp_jobs, r = cur_tile - g * grp_jobs, gs = L.job_group;
-                        if (g >= grp_full) { g = grp_full; r = cur_tile - grp_full * grp_jobs; gs = ntiles_frame - grp_full * L.job_group; }
-                        cur_fslot = r / gs;
+                        int g = fast_div(cur_tile, dv_grp), r = cur_tile - g * grp_jobs, gs = L.job_group;
+                        const bool last = g >= grp_full;
+                        if (last) { g = grp_full; r = cur_tile - grp_full * grp_jobs; gs = grp_last; }
+                        cur_fslot = last ? fast_div(r, dv_last) : fast_div(r, dv_gs);
                         cur_ftile = g * L.job_group + (r - cur_fslot * gs);
                     }
                     have_at++;
@@ -1617,8 +1638,9 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (mine) {
                     const int j = cur_used + rank;
                     const int fslot = cur_fslot, ftile = cur_ftile;
-                    const int px = (ftile % tiles_x) * 8 + (j & 7);
-                    const int ply = (ftile / tiles_x) * 8 + (j >> 3);
+                    const int trow = fast_div(ftile, dv_tx);
+                    const int px = (ftile - trow * tiles_x) * 8 + (j & 7);
+                    const int ply = trow * 8 + (j >> 3);
                     const int pgy = local_to_global_row(ply, L.tile);
                     const bool ok = px < L.tile.tex_w && ply < L.tile.local_rows && pgy < L.tile.tex_h &&
                                     (uint32_t)px < res_w && (uint32_t)pgy < res_h;     // :425-427
