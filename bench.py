@@ -194,9 +194,9 @@ def inner_pmc(args):
     at a time: with counters on, rocprofv3 serialises kernels in the order it intercepts them on
     the two internal queues, which need not be the order they were enqueued in -- and a launch
     that is held (hipStreamWaitValue32) until its predecessor announces its drain can then end
-    up in front of that predecessor: a deadlock, seen as passes that never finish.  The child
-    therefore runs without the launch gate (MI3PT_GATE=0, set by the parent) and waits for
-    every launch; per-launch counters are what a serialised run measures anyway."""
+    up in front of that predecessor: a deadlock, seen as passes that never finish.  The library
+    therefore switches its launch gate off when a profiler is attached (mi3pt_create), and the
+    child waits for every launch; per-launch counters are what a serialised run measures anyway."""
     width, height = image_size(1, args.scaling)
     if args.image:
         width, height = (int(v) for v in args.image.lower().split("x"))
@@ -215,7 +215,7 @@ def collect_pmc(args, timed_launches, log):
         return {}
     out = {}
     base = tempfile.mkdtemp(prefix="mi3pt_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", MI3PT_GATE="0")
+    env = dict(os.environ, TMPDIR="/tmp")
     try:
         for i, counters in enumerate(PMC_PASSES):
             d = os.path.join(base, f"pass{i}")

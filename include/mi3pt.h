@@ -241,10 +241,43 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
  * (internal children absorbed into their parent where boxes nest: the same leaves are reached -- the
  * fp32 slab test is monotone under nesting -- in half the node steps).  9 and 10 need a proper tree whose
  * order-independent worst-case stack fits 56 entries.
- * auto = 10 when the scene allows it, else 9 (else 7, else 4); MI3PT_WIDE=0 / MI3PT_CULL=0 in the
- * environment make auto stop at 9 / 7.  Variants 1-8 execute exactly the reference's tests (counters equal the oracle's);
- * all variants produce the same bits. */
+ * 11 = 10 with the FILTERED slab test in the shipped batched launch: each box is decided from approximate quotients
+ * (one multiplication instead of an exact division each) whenever the two ends of the approximate interval lie more
+ * than 2^-21 (relative) apart, which PROVES the reference's decision (csrc/pt_kernels.hip slab_q0; tests/test_slab_filter.py);
+ * any other box runs the exact test.  12 = 11 with the culling condition evaluated on one axis only (cheaper, skips
+ * less).  Launch flavours other than the batched one (fused, diagnostic, samplesPerFrame != 1) run 10's code under 11 / 12.
+ * auto = 10, 11 or 12 when the scene allows the wide walk -- chosen per scene from the tree's statistics (thin leaves
+ * met per step; size of the culling margins: csrc/pt_context.hip prepare_cull), speed only -- else 9 (else 7, else 4);
+ * MI3PT_OPT_WIDE / MI3PT_OPT_CULL = 0 make auto stop at 9 / 7.  Variants 1-8 execute exactly the reference's tests
+ * (counters equal the oracle's); all variants produce the same bits. */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
+/* Scheduling options: how the same work is cut into launches, steps and jobs.  NONE of them changes a bit of any image
+ * or a path counter (tests/test_gpu_parity.py holds each to the defaults' output); they exist for the sweeps under
+ * profiles/ and for the tests.  The library reads NO environment variable for them: a build with -DMI3PT_EXPERIMENTS
+ * (make -C webgpu-pathtracer_amd/csrc experiments -> libmi3pt_exp.so) maps MI3PT_<NAME> variables onto this call at
+ * mi3pt_create and adds two switches that DO change what is computed (plain-division slab tests; a scaled culling margin,
+ * which voids its proof) -- those exist in no release object. */
+typedef enum mi3pt_option {
+    MI3PT_OPT_WALK_MIN = 0,    /* walk while at least this many lanes are walking (32) */
+    MI3PT_OPT_LEAF_MIN = 1,    /* run a triangle step once this many lanes have a leaf parked (24) */
+    MI3PT_OPT_SHADE_SPLIT = 2, /* service step: serve the larger of the hit / miss groups, the other only with >= n lanes (64) */
+    MI3PT_OPT_TAIL_POLICY = 3, /* drain-phase scheduling bits (7) */
+    MI3PT_OPT_TOP_PACKETS = 4, /* kernel variants 6 / 8: node packets staged in LDS per wave */
+    MI3PT_OPT_TRI_PAIR = 5,    /* a triangle step tests two parked triangles of a lane that has two (1) */
+    MI3PT_OPT_JOB_REVERSE = 6, /* the launch's jobs bottom band first (1) */
+    MI3PT_OPT_JOB_GROUP = 7,   /* tiles per job group; 0 frame-major, -1 the library's choice (-1) */
+    MI3PT_OPT_JOB_CHUNK = 8,   /* job tickets per draw while the queue is long (4) */
+    MI3PT_OPT_BATCH_LIMIT = 9, /* upper bound of frames per launch, process-wide (256) */
+    MI3PT_OPT_BATCH = 10,      /* frames per launch on one GPU; x nranks for a rank of a tile split (64); 1 = no batching */
+    MI3PT_OPT_WAVES_PER_CU = 11, /* resident one-wave workgroups per compute unit (16) */
+    MI3PT_OPT_CULL = 12,       /* 0: `auto` stops at variant 7 */
+    MI3PT_OPT_WIDE = 13,       /* 0: `auto` stops at variant 9 */
+    MI3PT_OPT_GATE = 14,       /* launches wait for their predecessor's drain mark (1; 0 when a profiler is attached) */
+    MI3PT_OPT_SLOT_SETS = 15,  /* sets of per-frame radiance slots, 2 or 3; before mi3pt_resize (2) */
+    MI3PT_OPT_PIPELINE = 16    /* = mi3pt_set_pipelining */
+} mi3pt_option;
+int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option /* mi3pt_option */, int value);
+int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option /* mi3pt_option */, int *value);
 /* The variant a raytrace submit would run right now: the selected one, or its fall-back when the
  * uploaded scene does not admit it (tests use it to make sure nothing fell back silently). */
 int mi3pt_debug_active_variant(mi3pt_ctx *ctx, int *variant);

@@ -1,3 +1,5 @@
+# (needs the EXPERIMENT build: make -C webgpu-pathtracer_amd/csrc experiments; MI3PT_LIBRARY=webgpu-pathtracer_amd/libmi3pt_exp.so
+#  MI3PT_FORCE_SLOW_SLAB=1 python profiles/check_slow_slab.py -- the release library has no such switch)
 import sys, os, time
 sys.path.insert(0,'webgpu-pathtracer_amd/py'); sys.path.insert(0,'tests')
 import ptcommon as pc

@@ -1,6 +1,9 @@
 #!/bin/bash
 # One bench line (dragon + demo, no counter passes, no CPU baseline) per knob setting.
 # usage: bash profiles/knob_sweep2.sh "<ENV=val ...>" "<ENV=val ...>" ...      -> gpurun_out/knob_sweep2.log
+# (needs the EXPERIMENT build of the library, which maps MI3PT_<NAME> variables onto mi3pt_debug_set_option:
+#  make -C webgpu-pathtracer_amd/csrc experiments; the release library reads no such variable)
+export MI3PT_LIBRARY=${MI3PT_LIBRARY:-${GRAFT_REPO_ROOT:-/root/repo}/webgpu-pathtracer_amd/libmi3pt_exp.so}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 mkdir -p gpurun_out

@@ -1,6 +1,9 @@
 #!/bin/bash
 # One bench line of ONE rank of an N-way tile split (bench.py --tile R/N, the driver's arguments) per knob setting.
 # usage: TILE=0/8 bash profiles/knob_sweep3.sh "<ENV=val ...>" ...      -> gpurun_out/knob_sweep3.log
+# (needs the EXPERIMENT build of the library, which maps MI3PT_<NAME> variables onto mi3pt_debug_set_option:
+#  make -C webgpu-pathtracer_amd/csrc experiments; the release library reads no such variable)
+export MI3PT_LIBRARY=${MI3PT_LIBRARY:-${GRAFT_REPO_ROOT:-/root/repo}/webgpu-pathtracer_amd/libmi3pt_exp.so}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 mkdir -p gpurun_out

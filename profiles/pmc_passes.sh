@@ -1,8 +1,9 @@
 #!/bin/bash
 # Collects PMC counters for the dominant kernel in separate passes (never combined with trace
 # domains other than --kernel-trace), with the same job bench.py times: `bench.py --inner-pmc`
-# (one launch at a time, no launch gate -- see bench.py inner_pmc: counter collection serialises
-# kernels in interception order, which deadlocked gated, overlapping launches intermittently).
+# (one launch at a time; the library switches its launch gate off by itself when a profiler is attached --
+# mi3pt_create: counter collection serialises kernels in interception order, which deadlocked gated,
+# overlapping launches intermittently).
 # bench.py runs these three passes itself after its timed job (roofline.pmc_counters); this script
 # keeps the raw per-dispatch CSVs for cross-checking.  TA_* / TCP_* / GRBM_* passes are left out:
 # on this pool they aborted or hung rocprofv3 (round 1).
@@ -10,7 +11,7 @@
 set -u
 OUT=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-cd /tmp && export TMPDIR=/tmp MI3PT_GATE=0
+cd /tmp && export TMPDIR=/tmp
 i=0
 while read -r counters; do
   i=$((i+1))

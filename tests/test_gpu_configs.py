@@ -197,7 +197,11 @@ def test_config2_demo_1080p_64spp(gpu_ctx, demo, env):
     ctx.resize(w, h)
     ref, cref = _render_spp(ctx, demo, w, h, spp, variant=2)
     got, cgot = _render_spp(ctx, demo, w, h, spp)
+    assert ctx.active_variant() == 10          # the shipped choice for this scene: its walks are short and meet the floor's thin leaves often
     _same_job(got, cgot, ref, cref, spp * w * h)
+    for v in (11, 12):
+        a, ca = _render_spp(ctx, demo, w, h, spp, variant=v)
+        _same_job(a, ca, ref, cref, spp * w * h)
     ctx.resize(64, 64)
 
 
@@ -210,8 +214,13 @@ def test_config3_dragon_class_1080p_256spp(gpu_ctx, dragon, env):
     ctx.resize(w, h)
     ref, cref = _render_spp(ctx, dragon, w, h, spp, variant=2)
     got, cgot = _render_spp(ctx, dragon, w, h, spp)
+    assert ctx.active_variant() == 12          # the shipped choice for this scene: filtered slab test, one-axis culling condition
     _same_job(got, cgot, ref, cref, spp * w * h)
     assert cgot["tri_tests"] <= cref["tri_tests"]
+    for v in (10, 11):                         # ... and the two wide walks `auto` did not pick, on a shorter job
+        a, ca = _render_spp(ctx, dragon, w, h, 16, variant=v)
+        b, cb = _render_spp(ctx, dragon, w, h, 16)
+        _same_job(a, ca, b, cb, 16 * w * h)
     ctx.resize(64, 64)
 
 
@@ -235,7 +244,7 @@ def test_config4_dragon_dof_4k_1024spp_one_rank_of_4(gpu_ctx, dragon, env):
 
 def test_config5_forest_4k_4096spp_one_rank_of_8(gpu_ctx, forest, env):
     """Config 5 at its stated 4096 spp, for one rank of the 8-way split: sixteen 256-frame launches of
-    the shipped walk (4-ary packets) against the binary culling walk; the per-pixel kernel, which
+    the shipped walk (4-ary packets, filtered slab test) against the binary culling walk; the per-pixel kernel, which
     the three-frame test above holds both to, would take a minute for this many frames."""
     w, h, spp = 3840, 2160, 4096
     ctx = gpu_ctx
@@ -243,8 +252,8 @@ def test_config5_forest_4k_4096spp_one_rank_of_8(gpu_ctx, forest, env):
     ctx.set_tile(3, 8, 8)
     ctx.resize(w, h)
     ref, cref = _render_spp(ctx, forest, w, h, spp, variant=9)
-    got, cgot = _render_spp(ctx, forest, w, h, spp, variant=10)
-    assert ctx.active_variant() == 10
+    got, cgot = _render_spp(ctx, forest, w, h, spp)
+    assert ctx.active_variant() == 11          # the shipped choice for this scene: filtered slab test, three-axis culling condition
     _same_job(got, cgot, ref, cref, spp * w * ctx.local_rows)
     ctx.set_tile(0, 1, 8)
     ctx.resize(64, 64)

@@ -745,19 +745,20 @@ def test_batch_capacity_and_launch_statistics(gpu_ctx, demo, env):
 
 @pytest.mark.parametrize("chunk,group", [(1, 0), (3, -1), (7, 100), (4, 3599), (2, 3600)])
 def test_job_order_and_ticket_chunks_lose_and_repeat_nothing(gpu_ctx, demo, env, chunk, group, monkeypatch):
-    """The persistent kernel draws its (frame slot, tile) jobs MI3PT_JOB_CHUNK tickets per atomic
+    """The persistent kernel draws its (frame slot, tile) jobs MI3PT_OPT_JOB_CHUNK tickets per atomic
     while the queue is long and singly near its end (640x360 x 16 frames: 57 600 jobs on 3 600
     waves, so the chunked and the single regime both occur), and orders them in groups of
-    MI3PT_JOB_GROUP tiles (0: frame-major; -1: the library's choice; 100: groups that are not
+    MI3PT_OPT_JOB_GROUP tiles (0: frame-major; -1: the library's choice; 100: groups that are not
     whole tile rows, with a shorter last group; 3599: a last group of one tile; 3600 = every
     tile: frame-major again).  Whatever the setting: every pixel of every frame exactly once,
     image bit-identical to the context with the defaults."""
     w, h, frames = 640, 360, 16
     mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
     images = []
-    monkeypatch.setenv("MI3PT_JOB_CHUNK", str(chunk))
-    monkeypatch.setenv("MI3PT_JOB_GROUP", str(group))
     own = capi.Context(0)
+    own.set_option(capi.OPT_JOB_CHUNK, chunk)
+    own.set_option(capi.OPT_JOB_GROUP, group)
+    assert (own.get_option(capi.OPT_JOB_CHUNK), own.get_option(capi.OPT_JOB_GROUP)) == (chunk, group)
     try:
         for ctx in (gpu_ctx, own):
             pc.upload_scene(ctx, demo, env)

@@ -76,6 +76,31 @@ def test_library_exports_every_declared_symbol(built):
     assert "orc_" not in out                    # no oracle / CPU render path inside the product
 
 
+def test_release_library_reads_no_knobs(built):
+    """The release object reads no MI3PT_* environment variable (round-2 finding: an environment variable could void
+    the bit-exactness guarantee of a drop-in library): no knob name is in the binary, and the only environment names it
+    knows are the profiler's (the launch gate switches itself off under rocprofv3 --pmc).  The scheduling options are
+    an explicit call, mi3pt_debug_set_option; the two switches that change what is computed exist only in the
+    -DMI3PT_EXPERIMENTS build (make -C csrc experiments)."""
+    blob = open(capi.LIB_PATH, "rb").read()
+    src = open(os.path.join(ROOT, "webgpu-pathtracer_amd", "csrc", "pt_context.hip")).read()
+    knobs = set(re.findall(r'"(MI3PT_[A-Z_]+)"', src))
+    assert {"MI3PT_CULL_SCALE", "MI3PT_FORCE_SLOW_SLAB", "MI3PT_GATE", "MI3PT_BATCH", "MI3PT_JOB_CHUNK"} <= knobs
+    for k in sorted(knobs):
+        assert k.encode() + b"\0" not in blob, f"{k} is in the release library"
+    # every getenv of an MI3PT_ name sits inside an #ifdef MI3PT_EXPERIMENTS block
+    depth, guarded = 0, []
+    for line in src.split("\n"):
+        t = line.strip()
+        if t.startswith("#ifdef MI3PT_EXPERIMENTS"):
+            depth += 1
+        elif t.startswith("#endif") and depth:
+            depth -= 1
+        if "getenv" in line and "MI3PT_" in line or ("getenv(eo.name)" in line):
+            guarded.append(depth > 0)
+    assert guarded and all(guarded)
+
+
 def test_product_sources_do_not_reference_the_oracle():
     for base, _, files in os.walk(os.path.join(ROOT, "webgpu-pathtracer_amd")):
         for f in files:

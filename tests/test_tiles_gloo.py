@@ -58,8 +58,7 @@ def _gpu_worker(rank, world, port, w, h, block, frames, outq):
     """The same flow with the DEVICE path doing the rendering: every rank owns a context on the
     one GPU of the box with its tile set, accumulates into a torch tensor bound as the
     accumulation image (bench.py's arrangement), and the tensors are gathered over gloo."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      MI3PT_BATCH="4")          # 4 x world frames per launch: the 20 frames take several launches
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
     for p in (os.path.join(root, "webgpu-pathtracer_amd", "py"), here):
@@ -72,6 +71,7 @@ def _gpu_worker(rank, world, port, w, h, block, frames, outq):
     sc = scenes.demo_scene()
     sc.build_bvh(nthreads=2)
     ctx = capi.Context(0)
+    ctx.set_option(capi.OPT_BATCH, 4)         # 4 x world frames per launch: the 20 frames take several launches
     pc.upload_scene(ctx, sc, scenes.synthetic_env())
     ctx.set_tile(rank, world, block)
     ctx.resize(w, h)

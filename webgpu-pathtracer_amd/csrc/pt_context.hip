@@ -17,6 +17,7 @@
 #include <cstring>
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 static thread_local std::string g_last_error;
@@ -58,6 +59,12 @@ struct mi3pt_ctx {
     float cull_ka = 0.0f, cull_kb = 0.0f;   // scene constants of the distance bound
     // wide (4-ary) packets for kernel variant 10, built with the cull analysis
     bool wide_enabled = true;       // MI3PT_WIDE=0: variant 0 stops at 9
+#ifdef MI3PT_EXPERIMENTS
+    bool exp_force_slow_slab = false;
+    double exp_cull_scale = 1.0;
+#endif
+    int auto_wide_variant = 10;     // which of the wide walks (10 exact slab test, 11 filtered, 12 filtered + one-axis culling
+                                    // condition) `auto` resolves to for this scene: prepare_cull's walk statistics
     bool wide_ok = false;
     void *d_wide = nullptr;
     size_t nwide = 0;
@@ -179,6 +186,7 @@ static int require_ctx(mi3pt_ctx *ctx)
 }
 
 static int require_idle(mi3pt_ctx *ctx);      // require_ctx + flush of the deferred frame queue (below)
+static int batch_limit(const mi3pt_ctx *ctx, int nranks);
 static int flush_pending(mi3pt_ctx *ctx);
 static int settle_canvas(mi3pt_ctx *ctx);
 static int check_scene(const mi3pt_ctx *ctx);
@@ -206,6 +214,19 @@ extern "C" int mi3pt_device_name(int device, char *name, size_t capacity)
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     std::snprintf(name, capacity, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     return MI3PT_OK;
+}
+
+// A profiler that collects hardware counters is attached to this process (rocprofv3 / rocprofiler-sdk preload their
+// tool library and announce themselves in the environment).  See mi3pt_create: the launch gate.
+static bool profiler_attached()
+{
+    extern char **environ;
+    for (char **e = environ; e && *e; e++)
+        if (std::strncmp(*e, "ROCPROF", 7) == 0 || std::strncmp(*e, "ROCP_", 5) == 0) return true;
+    for (const char *name : { "LD_PRELOAD", "HSA_TOOLS_LIB" })
+        if (const char *v = std::getenv(name))
+            if (std::strstr(v, "rocprof") || std::strstr(v, "rocprofiler")) return true;
+    return false;
 }
 
 extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
@@ -243,7 +264,6 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
         CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     }
     ctx->stream = ctx->own_stream;
-    if (const char *e = std::getenv("MI3PT_PIPELINE")) ctx->pipeline = std::atoi(e) != 0;
     for (int k = 0; k < 2; k++) {
         // lowest priority: the persistent raytrace waves must never starve the (tiny, ordered)
         // accumulate kernels on the main stream, which gate the batch after next
@@ -254,29 +274,12 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
         CREATE_TRY(hipEventCreateWithFlags(&ctx->rt_done[k], hipEventDisableTiming));
     }
     for (int k = 0; k < 3; k++) CREATE_TRY(hipEventCreateWithFlags(&ctx->acc_done[k], hipEventDisableTiming));
-    if (const char *e = std::getenv("MI3PT_SLOT_SETS")) ctx->slot_sets = std::atoi(e) == 3 ? 3 : 2;
     CREATE_TRY(hipEventCreateWithFlags(&ctx->main_mark, hipEventDisableTiming));
     for (int k = 0; k < 2; k++)
         for (int j = 0; j < 2; j++) CREATE_TRY(hipEventCreate(&ctx->ev_rt[k][j]));
     for (int p = 0; p < 3; p++)
         for (int k = 0; k < 2; k++) CREATE_TRY(hipEventCreate(&ctx->ev[p][k]));
     CREATE_TRY(hipEventCreate(&ctx->ev_span_start));
-    if (const char *e = std::getenv("MI3PT_WALK_MIN")) ctx->walk_min = std::atoi(e);
-    if (const char *e = std::getenv("MI3PT_BATCH_LIMIT")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) BATCH_LIMIT = v; }
-    if (const char *e = std::getenv("MI3PT_BATCH")) ctx->batch_max = std::atoi(e);
-    if (ctx->batch_max < 1) ctx->batch_max = 1;
-    if (ctx->batch_max > BATCH_LIMIT) ctx->batch_max = BATCH_LIMIT;
-    if (const char *e = std::getenv("MI3PT_WAVES_PER_CU")) ctx->waves_per_cu = std::atoi(e);
-    if (const char *e = std::getenv("MI3PT_LEAF_MIN")) ctx->leaf_min = std::atoi(e);
-    if (const char *e = std::getenv("MI3PT_SHADE_SPLIT")) ctx->shade_split = std::atoi(e);
-    if (const char *e = std::getenv("MI3PT_TAIL_POLICY")) ctx->tail_policy = std::atoi(e);
-    if (const char *e = std::getenv("MI3PT_TOP_PACKETS")) ctx->top_packets = std::atoi(e);
-    if (const char *e = std::getenv("MI3PT_CULL")) ctx->cull_enabled = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MI3PT_WIDE")) ctx->wide_enabled = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MI3PT_TRI_PAIR")) ctx->tri_pair = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MI3PT_JOB_REVERSE")) ctx->job_reverse = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MI3PT_JOB_GROUP")) ctx->job_group = std::atoi(e);
-    if (const char *e = std::getenv("MI3PT_JOB_CHUNK")) { ctx->job_chunk = std::atoi(e); if (ctx->job_chunk < 1 || ctx->job_chunk > 64) ctx->job_chunk = 1; }
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
     CREATE_TRY(hipMalloc(&ctx->d_env, env_bytes));
@@ -286,10 +289,14 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     CREATE_TRY(hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream));     // self-cleaning afterwards
     // a word the command processor can poll (hipStreamWaitValue32) and a running kernel can write;
     // optional: without it launches simply queue behind each other
-    const char *gate = std::getenv("MI3PT_GATE");                      // experiment knob: 0 = no gating
-    if (!(gate && gate[0] == '0') && hipExtMallocWithFlags((void **)&ctx->d_drain_flag, 8, hipMallocSignalMemory) == hipSuccess) {
+    // Under a counter-collecting profiler the gate is off from the start: rocprofv3 --pmc serialises kernels in the order
+    // it intercepts them on the two internal queues, which need not be the order they were enqueued in, and a launch that
+    // is held until its predecessor announces its drain can then end up in FRONT of that predecessor -- a deadlock (seen
+    // as counter passes that never finish, and as a mi3pt_destroy that never returns).  Ungated launches simply queue
+    // behind each other: same bits, tails not overlapped.
+    if (hipExtMallocWithFlags((void **)&ctx->d_drain_flag, 8, hipMallocSignalMemory) == hipSuccess) {
         CREATE_TRY(hipMemsetAsync(ctx->d_drain_flag, 0, 8, ctx->stream));
-        ctx->gate_enabled = true;
+        ctx->gate_enabled = !profiler_attached();
     } else {
         (void)hipGetLastError();
         ctx->d_drain_flag = nullptr;
@@ -298,6 +305,25 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     CREATE_TRY(hipMemsetAsync(ctx->d_cdf, 0, env_bytes, ctx->stream));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
 #undef CREATE_TRY
+#ifdef MI3PT_EXPERIMENTS
+    // Experiment build only (make -C csrc experiments -> libmi3pt_exp.so; profiles/*.sh): the scheduling options, and two
+    // switches that are NOT options because they change what is computed, from the environment.  The release library
+    // reads no MI3PT_* variable (tests/test_host_side.py::test_release_library_reads_no_knobs).
+    {
+        static const struct { const char *name; int opt; } env_opts[] = {
+            { "MI3PT_WALK_MIN", MI3PT_OPT_WALK_MIN }, { "MI3PT_LEAF_MIN", MI3PT_OPT_LEAF_MIN }, { "MI3PT_SHADE_SPLIT", MI3PT_OPT_SHADE_SPLIT },
+            { "MI3PT_TAIL_POLICY", MI3PT_OPT_TAIL_POLICY }, { "MI3PT_TOP_PACKETS", MI3PT_OPT_TOP_PACKETS }, { "MI3PT_TRI_PAIR", MI3PT_OPT_TRI_PAIR },
+            { "MI3PT_JOB_REVERSE", MI3PT_OPT_JOB_REVERSE }, { "MI3PT_JOB_GROUP", MI3PT_OPT_JOB_GROUP }, { "MI3PT_JOB_CHUNK", MI3PT_OPT_JOB_CHUNK },
+            { "MI3PT_BATCH_LIMIT", MI3PT_OPT_BATCH_LIMIT }, { "MI3PT_BATCH", MI3PT_OPT_BATCH }, { "MI3PT_WAVES_PER_CU", MI3PT_OPT_WAVES_PER_CU },
+            { "MI3PT_CULL", MI3PT_OPT_CULL }, { "MI3PT_WIDE", MI3PT_OPT_WIDE }, { "MI3PT_GATE", MI3PT_OPT_GATE }, { "MI3PT_SLOT_SETS", MI3PT_OPT_SLOT_SETS },
+            { "MI3PT_PIPELINE", MI3PT_OPT_PIPELINE },
+        };
+        for (const auto &eo : env_opts)
+            if (const char *e = std::getenv(eo.name)) (void)mi3pt_debug_set_option(ctx, eo.opt, std::atoi(e));
+        if (std::getenv("MI3PT_FORCE_SLOW_SLAB")) ctx->exp_force_slow_slab = true;      // plain IEEE divisions in every slab test
+        if (const char *e = std::getenv("MI3PT_CULL_SCALE")) ctx->exp_cull_scale = std::atof(e);     // < 1 VOIDS the proof of DESIGN.md 3a
+    }
+#endif
     std::memset(ctx->u_rt, 0, sizeof ctx->u_rt);
     std::memset(ctx->u_acc, 0, sizeof ctx->u_acc);
     std::memset(ctx->u_fs, 0, sizeof ctx->u_fs);
@@ -380,9 +406,92 @@ extern "C" int mi3pt_set_env_sampling(mi3pt_ctx *ctx, int enabled)
 extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
-    if (variant < 0 || variant > 10) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..10");
+    if (variant < 0 || variant > 12) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..12");
     if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
+    return MI3PT_OK;
+}
+
+static void recompute_batch_cap(mi3pt_ctx *ctx)
+{
+    if (ctx->width == 0) return;
+    ctx->batch_cap = batch_limit(ctx, ctx->nranks);
+    const size_t tex_bytes = (size_t)ctx->local_rows * ctx->width * 16;
+    size_t free_b = 0, total_b = 0;
+    if (tex_bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t per_frame = (size_t)ctx->slot_sets * tex_bytes;
+        const size_t fit = (free_b / 4) / per_frame;
+        if ((size_t)ctx->batch_cap > fit) ctx->batch_cap = fit < 1 ? 1 : (int)fit;
+    } else {
+        (void)hipGetLastError();
+    }
+}
+
+// Scheduling options (include/mi3pt.h: mi3pt_option): how the same work is cut into launches, steps and jobs.
+extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
+{
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    if (int rc = require_idle(ctx)) return rc;
+    switch (option) {
+    case MI3PT_OPT_WALK_MIN: ctx->walk_min = value; break;
+    case MI3PT_OPT_LEAF_MIN: ctx->leaf_min = value; break;
+    case MI3PT_OPT_SHADE_SPLIT: ctx->shade_split = value; break;
+    case MI3PT_OPT_TAIL_POLICY: ctx->tail_policy = value; break;
+    case MI3PT_OPT_TOP_PACKETS: ctx->top_packets = value; break;
+    case MI3PT_OPT_TRI_PAIR: ctx->tri_pair = value != 0; break;
+    case MI3PT_OPT_JOB_REVERSE: ctx->job_reverse = value != 0; break;
+    case MI3PT_OPT_JOB_GROUP: ctx->job_group = value; break;
+    case MI3PT_OPT_JOB_CHUNK: ctx->job_chunk = (value < 1 || value > 64) ? 1 : value; break;
+    case MI3PT_OPT_BATCH_LIMIT:
+        if (value < 1 || value > 4096) return pt_set_error(MI3PT_ERR_INVALID, "batch limit must be in [1, 4096]");
+        BATCH_LIMIT = value;
+        if (ctx->batch_max > BATCH_LIMIT) ctx->batch_max = BATCH_LIMIT;
+        recompute_batch_cap(ctx);
+        break;
+    case MI3PT_OPT_BATCH:
+        ctx->batch_max = value < 1 ? 1 : (value > BATCH_LIMIT ? BATCH_LIMIT : value);
+        recompute_batch_cap(ctx);
+        break;
+    case MI3PT_OPT_WAVES_PER_CU: ctx->waves_per_cu = value; break;
+    case MI3PT_OPT_CULL: ctx->cull_enabled = value != 0; break;
+    case MI3PT_OPT_WIDE: ctx->wide_enabled = value != 0; break;
+    case MI3PT_OPT_GATE: ctx->gate_enabled = value != 0 && ctx->d_drain_flag != nullptr; break;
+    case MI3PT_OPT_SLOT_SETS:
+        if (value != 2 && value != 3) return pt_set_error(MI3PT_ERR_INVALID, "slot sets: 2 or 3");
+        if (ctx->width != 0 && value != ctx->slot_sets) return pt_set_error(MI3PT_ERR_STATE, "slot sets must be chosen before mi3pt_resize");
+        ctx->slot_sets = value;
+        break;
+    case MI3PT_OPT_PIPELINE: ctx->pipeline = value != 0; break;
+    default:
+        return pt_set_error(MI3PT_ERR_INVALID, "unknown option");
+    }
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
+{
+    if (!ctx || !value) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    switch (option) {
+    case MI3PT_OPT_WALK_MIN: *value = ctx->walk_min; break;
+    case MI3PT_OPT_LEAF_MIN: *value = ctx->leaf_min; break;
+    case MI3PT_OPT_SHADE_SPLIT: *value = ctx->shade_split; break;
+    case MI3PT_OPT_TAIL_POLICY: *value = ctx->tail_policy; break;
+    case MI3PT_OPT_TOP_PACKETS: *value = ctx->top_packets; break;
+    case MI3PT_OPT_TRI_PAIR: *value = ctx->tri_pair ? 1 : 0; break;
+    case MI3PT_OPT_JOB_REVERSE: *value = ctx->job_reverse ? 1 : 0; break;
+    case MI3PT_OPT_JOB_GROUP: *value = ctx->job_group; break;
+    case MI3PT_OPT_JOB_CHUNK: *value = ctx->job_chunk; break;
+    case MI3PT_OPT_BATCH_LIMIT: *value = BATCH_LIMIT; break;
+    case MI3PT_OPT_BATCH: *value = ctx->batch_max; break;
+    case MI3PT_OPT_WAVES_PER_CU: *value = ctx->waves_per_cu; break;
+    case MI3PT_OPT_CULL: *value = ctx->cull_enabled ? 1 : 0; break;
+    case MI3PT_OPT_WIDE: *value = ctx->wide_enabled ? 1 : 0; break;
+    case MI3PT_OPT_GATE: *value = ctx->gate_enabled ? 1 : 0; break;
+    case MI3PT_OPT_SLOT_SETS: *value = ctx->slot_sets; break;
+    case MI3PT_OPT_PIPELINE: *value = ctx->pipeline ? 1 : 0; break;
+    default:
+        return pt_set_error(MI3PT_ERR_INVALID, "unknown option");
+    }
     return MI3PT_OK;
 }
 
@@ -758,15 +867,7 @@ extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
     ctx->nblocks = nblocks;
     // batch depth: the limit for this tile split, capped so that the slot sets together take
     // at most a quarter of the memory that is free now (slots are allocated when first needed)
-    ctx->batch_cap = batch_limit(ctx, nranks);
-    size_t free_b = 0, total_b = 0;
-    if (tex_bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const size_t per_frame = (size_t)ctx->slot_sets * tex_bytes;
-        const size_t fit = (free_b / 4) / per_frame;
-        if ((size_t)ctx->batch_cap > fit) ctx->batch_cap = fit < 1 ? 1 : (int)fit;
-    } else {
-        (void)hipGetLastError();
-    }
+    recompute_batch_cap(ctx);
     return zero_textures(ctx);
 }
 
@@ -819,7 +920,9 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.root_ref = ctx->root_ref;
     s.flags = ctx->scene_flags;
     s.cull_ka = ctx->cull_ka; s.cull_kb = ctx->cull_kb;
-    if (std::getenv("MI3PT_FORCE_SLOW_SLAB")) s.flags = 0;     // experiment knob: plain IEEE divisions
+#ifdef MI3PT_EXPERIMENTS
+    if (ctx->exp_force_slow_slab) s.flags = 0;
+#endif
     s.env_w = MI3PT_ENV_WIDTH; s.env_h = MI3PT_ENV_HEIGHT;
     return s;
 }
@@ -946,7 +1049,7 @@ static inline uint32_t round_up_16(float f)
 static int prepare_cull(mi3pt_ctx *ctx)
 {
     if (!ctx->cull_dirty) return MI3PT_OK;
-    const bool wanted = ctx->variant == 9 || ctx->variant == 10 || (ctx->variant == 0 && ctx->cull_enabled);
+    const bool wanted = (ctx->variant >= 9 && ctx->variant <= 12) || (ctx->variant == 0 && ctx->cull_enabled);
     if (!wanted || ctx->layout_active || !ctx->cull_stack_ok || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
         return MI3PT_OK;       // stays dirty: pick_variant falls back to the reference-counter walk
     if (int rc = flush_pending(ctx)) return rc;
@@ -1063,7 +1166,9 @@ static int prepare_cull(mi3pt_ctx *ctx)
     // handful of fp32 roundings the kernel adds when it forms delta from them)
     {
         double scale = 1.0;
-        if (const char *e = std::getenv("MI3PT_CULL_SCALE")) scale = std::atof(e);     // EXPERIMENT ONLY: < 1 voids the proof
+#ifdef MI3PT_EXPERIMENTS
+        scale = ctx->exp_cull_scale;
+#endif
         const double ka = u * inv_eps * 1.001 * scale, kb = 1.65 * lmax * u * inv_eps * 1.001 * scale;
         ctx->cull_ka = std::nextafter((float)ka, inf);
         ctx->cull_kb = std::nextafter((float)kb, inf);
@@ -1180,6 +1285,48 @@ static int prepare_cull(mi3pt_ctx *ctx)
             ctx->wide_ok = true;
         }
     }
+    // ---- which wide walk `auto` means for this scene (variants 10 / 11 / 12 render the same bits; this is speed only).
+    // The filtered slab test (11, 12) saves ~45 of a wide step's ~290 vector instructions, but a box that is thin on an
+    // axis and entered through that face -- the two triangles of a floor, axis-aligned quads -- has a zero-length
+    // approximate interval and always takes the exact test on top: ~30 more instructions for the whole wave.  Estimate
+    // of such encounters per wide step: the surface-area share of the thin leaves (the chance that a ray through the
+    // root box meets the leaf's box) over the depth of the 4-ary tree.  Measured: demo scene 0.33 -> 10 is 1.5 % faster
+    // than 11; dragon-class 0.15 -> 11 is 2-3 % faster than 10 (profiles/r03_a_slab_filter_ab.log).
+    // The one-axis culling condition (12) is one operation per child instead of four but skips less; it is chosen when
+    // the margins it inflates are negligible anyway: 95th percentile of the leaves' W times k_a times 16 below 2^-10
+    // (dragon-class: 4e-4, +1.4 %; the 10 M-triangle forest: 0.5 -- there it doubles the boxes tested).
+    ctx->auto_wide_variant = 10;
+    if (ctx->wide_ok) {
+        const uint8_t *r0 = src;
+        double ext0[3], diag = 0.0;
+        for (int k = 0; k < 3; k++) { ext0[k] = (double)ldf(r0, 16 + 4 * k) - ldf(r0, 4 * k); diag += ext0[k] * ext0[k]; }
+        diag = std::sqrt(diag);
+        const double area0 = ext0[0] * ext0[1] + ext0[0] * ext0[2] + ext0[1] * ext0[2];
+        const double thin = std::ldexp(diag, -20);
+        double thin_share = 0.0;
+        std::vector<float> ws;
+        ws.reserve(nt);
+        for (size_t i = 0; i < n; i++) {
+            if (!is_leaf(i)) continue;
+            const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+            const double x = (double)ldf(r, 16) - ldf(r, 0), y = (double)ldf(r, 20) - ldf(r, 4), z = (double)ldf(r, 24) - ldf(r, 8);
+            if ((x <= thin || y <= thin || z <= thin) && area0 > 0.0) {
+                const double a = (x * y + x * z + y * z) / area0;
+                if (a == a) thin_share += a < 1.0 ? a : 1.0;
+            }
+            if (wmax[i] < inf) ws.push_back(wmax[i]);
+        }
+        const double depth = std::log((double)(ctx->nwide > 4 ? ctx->nwide : 4)) / std::log(4.0);
+        const double thin_per_step = thin_share / depth;
+        double w95 = __builtin_inf();
+        if (!ws.empty()) {
+            const size_t k95 = (ws.size() - 1) * 95 / 100;
+            std::nth_element(ws.begin(), ws.begin() + (std::ptrdiff_t)k95, ws.end());
+            w95 = ws[k95];
+        }
+        const double margin = w95 * u * inv_eps * 16.0;
+        if (thin_per_step < 0.25) ctx->auto_wide_variant = margin < std::ldexp(1.0, -10) ? 12 : 11;
+    }
     ctx->cull_ok = true;
     ctx->cull_dirty = false;
     ctx->main_dirty = true;
@@ -1209,8 +1356,8 @@ static int pick_variant(const mi3pt_ctx *ctx)
     // auto: the wide walk pays once the tree no longer sits in L1 / L2 (demo scene, 2 k nodes: binary packets 10.4, wide
     // packets 10.2 Grays/s; dragon-class 8.5 -> 8.6; 10 M-triangle forest 24 -> 21 ms per frame)
     if (ctx->variant == 0)
-        return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? 10 : 9) : (defer_ok ? 7 : 4);
-    if (ctx->variant == 10 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);
+        return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? ctx->auto_wide_variant : 9) : (defer_ok ? 7 : 4);
+    if (ctx->variant >= 10 && ctx->variant <= 12 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);
     if (ctx->variant == 9 && !cull_ok) return defer_ok ? 7 : 4;
     if ((ctx->variant == 7 || ctx->variant == 8) && !defer_ok) return ctx->variant == 8 ? 6 : 4;
     return ctx->variant;

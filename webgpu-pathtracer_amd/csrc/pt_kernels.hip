@@ -214,6 +214,48 @@ PT_DEV bool ray_aabb_fast_t(const f3 &o, const f3 &d, const RayPre &p, float mnx
     return !(tmin > tmax) && (tmax >= fmaxf(0.0f, tmin));
 }
 
+// ---------------------------------------------------------------------------------
+// Filtered slab test (the WIDE walk's fast path): decide with approximate quotients, run the exact
+// test only where the approximation cannot decide.
+//
+// q0 = RN(n * y), y = RN(1/d), is div_pre()'s first operation.  With r = n/d (real): y = (1/d)(1+e1),
+// q0 = r (1+e1)(1+e2), q1 = RN(n/d) = r (1+e3), |e_i| <= u = 2^-24, so |q0 - q1| <= eps |q1| with
+// eps = 3.01 u; q0 and q1 have the same sign and q0 == 0 exactly when q1 == 0 (n == 0: the guards
+// that admit a ray and a box to the fast path exclude under- and overflow of n * y).  x -> x +- eps |x|
+// are increasing maps and min / max commute with increasing maps, so the same bound carries over to
+// any min / max combination of the six quotients (constants such as +-PT_INF are their own images):
+//     |tmin~ - tmin| <= eps |tmin|,   |tmax~ - tmax| <= eps |tmax|,   sign(tmax~) == sign(tmax)
+// for tmin~ = max3 of the per-axis minima and tmax~ = min(PT_INF, per-axis maxima) of the q0's.
+// The reference's predicate (raytrace.wgsl:145-151) is  !(tmin > tmax) && tmax >= max(0, tmin),  which
+// without NaNs (none on this path) is  tmin <= tmax && tmax >= 0;  clamping tmin at -PT_INF from below
+// cannot change it (a tmin below -PT_INF lies below every tmax that is >= 0).  With D~ = RN(tmin~ - tmax~)
+// and M = max(|tmin~|, |tmax~|):
+//     |(tmin~ - tmax~) - (tmin - tmax)| <= eps (|tmin| + |tmax|) <= 2 eps / (1 - eps) M  <  6.03 u M,
+// so once |D~| > 2^-21 M (= 8 u M; the fma that forms |D~| - 2^-21 M rounds a positive real to a value
+// >= 0 and D~ itself carries one rounding) the sign of tmin - tmax is the sign of D~, and the predicate
+// is  D~ < 0 && tmax~ >= 0  bit for bit.  Otherwise the box is UNDECIDED (slab_margin() <= 0) and the
+// caller runs ray_aabb_fast() on it.  profiles/slab_filter_proof.hip replays this against the exact test.
+// The per-axis entry distances are handed out for the culling bound and the sort keys, which only
+// need them to within the 4.01 u the proof of DESIGN.md 3a budgets (here: 3.01 u).
+// ---------------------------------------------------------------------------------
+#define PT_SLAB_BAND 4.76837158203125e-07f      // 2^-21
+PT_DEV void slab_q0(const f3 &o, const RayPre &p, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                    f3 &tnear, float &tfar)
+{
+    const float ax = (mnx - o.x) * p.ix, bx = (mxx - o.x) * p.ix;
+    const float ay = (mny - o.y) * p.iy, by = (mxy - o.y) * p.iy;
+    const float az = (mnz - o.z) * p.iz, bz = (mxz - o.z) * p.iz;
+    tnear = F3(fminf(ax, bx), fminf(ay, by), fminf(az, bz));
+    tfar = fminf(fminf(fminf(PT_INF, fmaxf(ax, bx)), fmaxf(ay, by)), fmaxf(az, bz));
+}
+// > 0: the approximate quantities decide the box;  <= 0 (or NaN): undecided
+PT_DEV float slab_margin(float tmin, float tfar)
+{
+    return fmaf(-PT_SLAB_BAND, fmaxf(fabsf(tmin), fabsf(tfar)), fabsf(tmin - tfar));
+}
+// the predicate for a decided box
+PT_DEV bool slab_hit(float tmin, float tfar) { return fmaxf(tmin - tfar, -tfar) <= 0.0f; }
+
 // raytrace.wgsl:78-116 -- Moller-Trumbore, two-sided.  Returns hit and (t, u, v);
 // position and normal are formed once, for the closest hit, by finish_hit().
 PT_DEV bool ray_triangle(const f3 &o, const f3 &d, const f3 &a, const f3 &b, const f3 &c,
@@ -765,10 +807,11 @@ PT_DEV void write_pixel(const RtLaunch &L, uint32_t gx, uint32_t gy, uint32_t ly
 }
 
 // unfused store of one finished (pixel, frame slot): texel index within the slot's image
-template <bool F32_STORAGE = false>
+// (the storage format -- fp32, or the reference's rgba16float, renderer.ts:102 -- is a wave-uniform choice: one scalar
+// branch per store, in the tuned instantiation too)
 PT_DEV void write_radiance(const RtLaunch &L, uint32_t texel, uint32_t slot, f3 color)
 {
-    const int f16 = F32_STORAGE ? 0 : L.store_f16;
+    const int f16 = L.store_f16;
     L.radiance[(size_t)slot * L.slot_pixels + texel] =
         make_float4(store_round(color.x, f16), store_round(color.y, f16), store_round(color.z, f16), 1.0f);
 }
@@ -982,7 +1025,6 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
 #ifndef PT_SM_MIN_WAVES
 #define PT_SM_MIN_WAVES 4
 #endif
-
 // TOPLDS = true additionally stages the first PT_SM_TOP_PACKETS node packets in LDS (kernel
 // variant 6).  Measured on MI355X (round 1): no gain -- the kernel is
 // VALU-issue-bound and the top of the tree is L1-resident anyway, while the second load path
@@ -1004,7 +1046,16 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
 // WIDE (kernel variant 10, needs CULL): the walk runs on 4-ary "wide packets" (pt_kernels.h) -- up
 // to four child boxes per node step, half as many dependent round trips per ray.  The leaves reached
 // are exactly the reference's (monotone slab test under nesting).
-template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false, bool WIDE = false, bool SPF1 = false, bool DIAG = true>
+//
+// FILT (WIDE only): the filtered slab test -- approximate quotients decide, the exact test runs for a box whose interval
+// ends lie within 2^-21 of each other (slab_q0).  The context chooses it per scene (SceneRefs::slab_filter): boxes that
+// are flat on an axis and hit through that face (the two triangles of a floor, axis-aligned quads) ALWAYS land in the
+// exact test, so a scene whose walks are short and meet such leaves often is faster without the filter.
+// YMAX (FILT only): the culling condition (S) of DESIGN.md 3a evaluated on the axis that sets the box's entry distance
+// only, with the largest of the three |RN(1/d_i)| -- one operation per child instead of four; it skips less, so the
+// context chooses it only for scenes whose culling margins are negligible (SceneRefs::cull_ymax).
+template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false, bool WIDE = false, bool SPF1 = false, bool DIAG = true,
+          bool FILT = false, bool YMAX = false>
 __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
 {
     // DIAG = false (the shipped walks' batched launches when no diagnostic buffer is bound): the per-wave step statistics
@@ -1015,7 +1066,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     const int k_shade_split = DIAG ? L.shade_split : PT_DEFAULT_SHADE_SPLIT, k_tail_policy = DIAG ? L.tail_policy : PT_DEFAULT_TAIL_POLICY;
     const int k_job_chunk = DIAG ? L.job_chunk : PT_DEFAULT_JOB_CHUNK;
     const bool k_tri_pair = DIAG ? L.tri_pair != 0 : true;
-    // ... as are: a scene with nodes whose root is an internal node with a guard-range box, fp32 texel storage, a
+    // ... as are: a scene with nodes whose root is an internal node with a guard-range box, a
     // resolution of ordinary magnitude, maxBounces > 0
     constexpr bool TUNED = !DIAG;
     constexpr int DEPTH = PT_SM_LDS_DEPTH;                  // LDS stack entries per lane
@@ -1226,15 +1277,19 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             // are resolved by the leaf's rank in the reference's visiting order (strict '<' there
             // keeps the first visited, raytrace.wgsl:180).
             const bool trav = mode == M_TRAV;
-            const bool has_node = trav && sp > 0, has_leaf = trav && nl > 0;
+            // (culling walks: a lane that is not walking has sp == 0 and nl == 0 -- both are zero before the first segment, a
+            // segment ends when both are zero, and the 64-entry abort, which would leave entries behind, cannot fire there --
+            // so the votes below are single comparisons, which the compiler turns into the lane mask directly; a vote on a
+            // conjunction costs two more vector instructions to re-materialise the mask)
+            const bool has_node = CULL ? sp > 0 : (trav && sp > 0), has_leaf = CULL ? nl > 0 : (trav && nl > 0);
             const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
-            const bool full = __ballot(trav && nl > lcap - (WIDE ? 4 : 2)) != 0ull;      // a node step may park two (WIDE: four) more
+            const bool full = __ballot(CULL ? nl > lcap - (WIDE ? 4 : 2) : (trav && nl > lcap - (WIDE ? 4 : 2))) != 0ull;      // a node step may park two (WIDE: four) more
             // (drain: whichever kind of step serves more lanes -- waiting for n_node == 0 would leave the lanes
             // that only have leaves idle for as long as the slowest descent takes)
             if (full || n_node == 0 || n_leaf >= k_leaf_min || (feed_empty && (k_tail_policy & 1) && n_leaf >= n_node)) {
                 // every lane with a parked leaf tests one -- or two, when it has two (L.tri_pair): the second triangle's
                 // loads are in flight with the first's, and the lane needs one triangle step less
-                const bool two = k_tri_pair && has_leaf && nl > 1;
+                const bool two = k_tri_pair && (CULL ? nl > 1 : (has_leaf && nl > 1));
                 u_tri += (uint32_t)n_leaf + (k_tri_pair ? (uint32_t)__popcll(__ballot(two)) : 0u);      // (wave-uniform count: scalar)
                 if (wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
                 if (has_leaf) {
@@ -1284,7 +1339,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (!WIDE) u_box += 2u * (uint32_t)n_node;  // proper tree: both children of every popped node are tested (WIDE: per lane)
                 if (wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
                 // (CULL) can any lane's node entries leave the LDS part of its stack in this step?  One pop, then up to two / four pushes.
-                const bool shallow = CULL && __ballot(has_node && sp > NCAP - (WIDE ? 3 : 1)) == 0ull;
+                const bool shallow = CULL && __ballot(sp > NCAP - (WIDE ? 3 : 1)) == 0ull;
                 if (WIDE) {
                   if (has_node) {
                     const uint32_t ref = shallow ? flat_pop() : cull_pop();
@@ -1293,13 +1348,39 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     uint32_t cr[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
                     const uint32_t wf = __float_as_uint(q7.z);
                     bool hit[4];
-                    f3 tn[4];
+                    float key[4];                    // entry distance of each box (approximate with FILT): sort key and culling bound
+                    f3 tn[4];                        // per-axis entry distances (!YMAX)
                     tn[0] = tn[1] = tn[2] = tn[3] = F3(-PT_INF, -PT_INF, -PT_INF);
+                    key[0] = key[1] = key[2] = key[3] = -PT_INF;
                     if (((pre.flags & 8u) | (wf & 15u)) == 0u) {
-                        hit[0] = ray_aabb_fast_t(o, d, pre, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn[0]);
-                        hit[1] = ray_aabb_fast_t(o, d, pre, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn[1]);
-                        hit[2] = ray_aabb_fast_t(o, d, pre, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tn[2]);
-                        hit[3] = ray_aabb_fast_t(o, d, pre, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tn[3]);
+                        if constexpr (FILT) {
+                            // filtered slab test (see slab_q0): one multiplication per quotient; box by box, the exact test of an
+                            // undecided box right behind its approximate one, while the box's six coordinates are still in
+                            // registers (fetching them again costs the step a second memory round trip: measured)
+#define PT_BOX(K, MNX, MNY, MNZ, MXX, MXY, MXZ)                                                              \
+                            {                                                                                \
+                                f3 a_;                                                                       \
+                                float f_;                                                                    \
+                                slab_q0(o, pre, MNX, MNY, MNZ, MXX, MXY, MXZ, a_, f_);                       \
+                                key[K] = fmaxf(fmaxf(a_.x, a_.y), a_.z);                                     \
+                                if constexpr (!YMAX) tn[K] = a_;                                             \
+                                hit[K] = slab_hit(key[K], f_);                                               \
+                                if (!(slab_margin(key[K], f_) > 0.0f))                                       \
+                                    hit[K] = ray_aabb_fast(o, d, pre, MNX, MNY, MNZ, MXX, MXY, MXZ);         \
+                            }
+                            PT_BOX(0, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y)
+                            PT_BOX(1, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w)
+                            PT_BOX(2, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y)
+                            PT_BOX(3, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w)
+#undef PT_BOX
+                        } else {
+                            hit[0] = ray_aabb_fast_t(o, d, pre, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn[0]);
+                            hit[1] = ray_aabb_fast_t(o, d, pre, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn[1]);
+                            hit[2] = ray_aabb_fast_t(o, d, pre, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tn[2]);
+                            hit[3] = ray_aabb_fast_t(o, d, pre, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tn[3]);
+#pragma unroll
+                            for (int k = 0; k < 4; k++) key[k] = fmaxf(fmaxf(tn[k].x, tn[k].y), tn[k].z);
+                        }
                     } else {
                         hit[0] = ray_aabb_pre(o, d, pre, (wf & 1u) != 0u, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
                         hit[1] = ray_aabb_pre(o, d, pre, (wf & 2u) != 0u, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
@@ -1312,15 +1393,18 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                     const uint32_t w01 = __float_as_uint(q7.x), w23 = __float_as_uint(q7.y);
                     const float wgt[4] = { __uint_as_float(w01 & 0xffff0000u), __uint_as_float(w01 << 16),
                                            __uint_as_float(w23 & 0xffff0000u), __uint_as_float(w23 << 16) };
-                    float key[4];
+                    // YMAX: (S) on the axis that sets the entry distance, with |RN(1/d_i)| replaced by the largest of the
+                    // three -- a weaker condition than (S) on that axis, hence still sufficient
+                    const float ymax = fmaxf(fmaxf(fabsf(pre.ix), fabsf(pre.iy)), fabsf(pre.iz));
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const float dk = wgt[k] * rc;
-                        const float tc = fmaxf(fmaxf(fmaf(-dk, fabsf(pre.ix), tn[k].x), fmaf(-dk, fabsf(pre.iy), tn[k].y)), fmaf(-dk, fabsf(pre.iz), tn[k].z));
+                        float tc;
+                        if constexpr (YMAX) tc = fmaf(-dk, ymax, key[k]);
+                        else tc = fmaxf(fmaxf(fmaf(-dk, fabsf(pre.ix), tn[k].x), fmaf(-dk, fabsf(pre.iy), tn[k].y)), fmaf(-dk, fabsf(pre.iz), tn[k].z));
                         // a child that is missed or skipped becomes an empty entry: the sort below then moves (key, reference)
                         // pairs only -- selects, no branches, no lane masks to swap
                         cr[k] = (hit[k] && !(tc > bt)) ? cr[k] : PT_REF_NONE;
-                        key[k] = fmaxf(fmaxf(tn[k].x, tn[k].y), tn[k].z);
                     }
                     cnt.box += (wf >> 4) & 7u;           // the packet's number of children
                     // far first, near last (popped first): sort the four entries by entry distance, descending
@@ -1582,7 +1666,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 if (ended) {
                     if constexpr (SPF1) {
                         // one sample per frame: the pixel is finished (:455, :477); incomingLight = 0 + light
-                        write_radiance<TUNED>(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
+                        write_radiance(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
                     } else {
                         incoming = incoming + light;
                         sample++;
@@ -1707,7 +1791,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 ray_color = F3(1.0f, 1.0f, 1.0f);
                 if (TUNED || un.max_bounces > 0) { need_segment = true; break; }
                 if constexpr (SPF1) {       // (max_bounces == 0: the path is over before it began)
-                    write_radiance<TUNED>(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
+                    write_radiance(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
                     break;
                 } else {
                     incoming = incoming + light;
@@ -1840,12 +1924,16 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
         const bool tuned = one && !L.wave_times && L.walk_min == PT_DEFAULT_WALK_MIN && L.leaf_min == PT_DEFAULT_LEAF_MIN &&
                            L.shade_split == PT_DEFAULT_SHADE_SPLIT && L.tail_policy == PT_DEFAULT_TAIL_POLICY &&
                            L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 &&
-                           L.scene.nnodes != 0 && (L.scene.flags & 1u) != 0u && (L.scene.root_ref & PT_REF_LEAF) == 0u && !L.store_f16 &&
+                           L.scene.nnodes != 0 && (L.scene.flags & 1u) != 0u && (L.scene.root_ref & PT_REF_LEAF) == 0u &&
                            L.scene.env_w == 1024 && L.scene.env_h == 512 &&
                            L.un.max_bounces > 0 && L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
                            L.un.res_y >= 9.5367431640625e-07f && L.un.res_y <= 1.099511627776e12f;
-        if (variant == 10) {                             // the culling walk on 4-ary wide packets
+        if (variant >= 10 && variant <= 12) {            // the culling walk on 4-ary wide packets
+            // 11 / 12: the filtered slab test (12: with the one-axis culling condition) in the shipped batched launch; the
+            // other launch flavours (fused, diagnostic, samplesPerFrame != 1) run variant 10's exact test -- same bits
             if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true, true>), grid, block, 0, s, L);
+            else if (tuned && variant == 12) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true, false, true, true>), grid, block, 0, s, L);
+            else if (tuned && variant == 11) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true, false, true, false>), grid, block, 0, s, L);
             else if (tuned) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true, false>), grid, block, 0, s, L);
             else if (one) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true>), grid, block, 0, s, L);
             else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true>), grid, block, 0, s, L);

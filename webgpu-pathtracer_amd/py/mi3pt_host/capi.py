@@ -11,13 +11,18 @@ import os
 import numpy as np
 
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-LIB_PATH = os.path.join(PKG_ROOT, "libmi3pt.so")
+# (MI3PT_LIBRARY: another build of the library -- the sweeps under profiles/ point it at the experiment build,
+# libmi3pt_exp.so, which reads its options from the environment; read here, by the Python host, not by the library)
+LIB_PATH = os.environ.get("MI3PT_LIBRARY") or os.path.join(PKG_ROOT, "libmi3pt.so")
 
 PASS_RAYTRACE, PASS_ACCUMULATE, PASS_FULLSCREEN = 0, 1, 2
 SUBMIT_RAYTRACE, SUBMIT_ACCUMULATE, SUBMIT_FULLSCREEN = 1, 2, 4
 TEX_OUTPUT, TEX_ACCUMULATION, TEX_CANVAS = 0, 1, 2
 STORAGE_F32, STORAGE_F16 = 0, 1
 PRESENT_EXACT, PRESENT_LATEST = 0, 1
+# mi3pt_option (include/mi3pt.h): scheduling options; none changes a bit of any image
+(OPT_WALK_MIN, OPT_LEAF_MIN, OPT_SHADE_SPLIT, OPT_TAIL_POLICY, OPT_TOP_PACKETS, OPT_TRI_PAIR, OPT_JOB_REVERSE, OPT_JOB_GROUP,
+ OPT_JOB_CHUNK, OPT_BATCH_LIMIT, OPT_BATCH, OPT_WAVES_PER_CU, OPT_CULL, OPT_WIDE, OPT_GATE, OPT_SLOT_SETS, OPT_PIPELINE) = range(17)
 COUNTER_NAMES = ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels", "reserved")
 
 # every symbol include/mi3pt.h declares; tests/test_capi_symbols.py checks the header
@@ -34,7 +39,7 @@ SYMBOLS = (
     "mi3pt_set_env_sampling", "mi3pt_debug_walk_probe", "mi3pt_device_build_bvh",
     "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_debug_active_variant", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
-    "mi3pt_host_env_cdf",
+    "mi3pt_host_env_cdf", "mi3pt_debug_set_option", "mi3pt_debug_get_option",
 )
 
 
@@ -92,6 +97,8 @@ def load_library(path=None):
     lib.mi3pt_raytrace_launch_span.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.mi3pt_batch_capacity.argtypes = [c_void_p, ctypes.POINTER(c_int)]
     lib.mi3pt_debug_active_variant.argtypes = [c_void_p, ctypes.POINTER(c_int)]
+    lib.mi3pt_debug_set_option.argtypes = [c_void_p, c_int, c_int]
+    lib.mi3pt_debug_get_option.argtypes = [c_void_p, c_int, ctypes.POINTER(c_int)]
     lib.mi3pt_debug_set_packet_layout.argtypes = [c_void_p, c_int]
     lib.mi3pt_get_counters.argtypes = [c_void_p, c_void_p]
     lib.mi3pt_reset_counters.argtypes = [c_void_p]
@@ -315,6 +322,15 @@ class Context:
 
     def set_packet_layout(self, layout):
         self._c(self.lib.mi3pt_debug_set_packet_layout(self.handle, int(layout)))
+
+    def set_option(self, option, value):
+        """Scheduling options (OPT_*): how the work is cut into launches / steps / jobs; never what is computed."""
+        self._c(self.lib.mi3pt_debug_set_option(self.handle, int(option), int(value)))
+
+    def get_option(self, option):
+        v = ctypes.c_int(0)
+        self._c(self.lib.mi3pt_debug_get_option(self.handle, int(option), ctypes.byref(v)))
+        return v.value
 
     def active_variant(self):
         v = ctypes.c_int()
