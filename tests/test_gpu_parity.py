@@ -775,3 +775,93 @@ def test_job_order_and_ticket_chunks_lose_and_repeat_nothing(gpu_ctx, demo, env,
         own.close()
     assert pc.same_bits(images[0], images[1]), pc.describe_diff(images[0], images[1])
     gpu_ctx.resize(64, 64)
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_tuned_and_diagnostic_twins_render_the_same_bits(gpu_ctx, demo, env, storage):
+    """The shipped batched launch runs a TUNED instantiation of the state-machine kernel: step statistics compiled
+    out, the step-voting options as constants, the service step's launch-invariant scalars read back from a block that
+    a setup kernel wrote (RtService), 96 vector registers / five waves per SIMD -- and its preconditions are written
+    twice, in the host's `tuned` predicate and as constants inside the kernel (round-2 advice).  Binding the
+    diagnostic buffer sends the very same job to the generic twin, which computes everything in its prologue: image and
+    every counter must agree, for each of the wide walks and for both storage formats (rgba16float is the reference's,
+    renderer.ts:102; it runs the tuned twin too)."""
+    w, h, frames = 640, 360, 24
+    mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.set_storage(capi.STORAGE_F16 if storage == "f16" else capi.STORAGE_F32)
+    ctx.resize(w, h)
+
+    def job(variant):
+        ctx.set_kernel_variant(variant)
+        ctx.reset()
+        ctx.reset_counters()
+        ctx.set_uniforms(capi.PASS_RAYTRACE, pc.rt_uniforms(demo, w, h, frame=2, bounces=6).tobytes())
+        ctx.set_uniforms(capi.PASS_ACCUMULATE, pc.acc_uniforms(w, h, 2).tobytes())
+        ctx.submit_frames(mask, frames)
+        return ctx.read_texture(capi.TEX_ACCUMULATION), ctx.counters()
+
+    try:
+        ref, cref = job(2)                      # per-pixel kernel, the WGSL control flow
+        for variant in (9, 10, 11, 12):
+            tuned, ct = job(variant)
+            ctx.enable_wave_times(True)
+            try:
+                diag, cd = job(variant)
+                stamps = ctx.wave_times()
+            finally:
+                ctx.enable_wave_times(False)
+            assert stamps[:, 2].max() > 0       # the diagnostic twin did run (it stamps its end)
+            assert pc.same_bits(tuned, diag), f"variant {variant}: " + pc.describe_diff(tuned, diag)
+            assert pc.same_bits(tuned, ref), f"variant {variant}: " + pc.describe_diff(tuned, ref)
+            # (box / triangle test counts of the culling walks are not a function of the ray alone: what is skipped depends on
+            # the closest hit found SO FAR, i.e. on when the wave ran its triangle steps, which depends on the other lanes)
+            for k in pc.PATH_COUNTERS:
+                assert ct[k] == cd[k], (variant, k, ct[k], cd[k])
+            assert ct["tri_tests"] <= cref["tri_tests"] and cd["tri_tests"] <= cref["tri_tests"]
+            for k in pc.PATH_COUNTERS:
+                assert ct[k] == cref[k], (variant, k, ct[k], cref[k])
+    finally:
+        ctx.set_kernel_variant(0)
+        ctx.set_storage(capi.STORAGE_F32)
+        ctx.resize(64, 64)
+
+
+def test_triangles_only_upload_after_the_debug_layout_restores_the_uploaded_numbering(gpu_ctx, demo, env):
+    """mi3pt_debug_set_packet_layout(1), render, set_packet_layout(0), then upload the TRIANGLES alone: the device still
+    held node packets / leaf ranks / the root reference in visiting-order numbering while the triangles were back in
+    uploaded order, so leaves referenced the wrong triangles (round-2 advice).  The upload now rebuilds the tree's side."""
+    ctx = gpu_ctx
+    w, h = 160, 96
+    mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+
+    def render(variant):
+        ctx.set_kernel_variant(variant)
+        ctx.reset()
+        for f in (2, 3):
+            pc.gpu_frame(ctx, pc.rt_uniforms(demo, w, h, frame=f, bounces=4), pc.acc_uniforms(w, h, f), mask)
+        img = ctx.read_texture(capi.TEX_ACCUMULATION)
+        ctx.set_kernel_variant(0)
+        return img
+
+    try:
+        ctx.set_packet_layout(0)
+        pc.upload_scene(ctx, demo, env)
+        ctx.set_tile(0, 1, 8)
+        ctx.resize(w, h)
+        want = render(2)
+        ctx.set_packet_layout(1)
+        pc.upload_scene(ctx, demo, env)
+        assert pc.same_bits(render(7), want)
+        ctx.set_packet_layout(0)
+        ctx.upload_triangles(demo.triangles)          # triangles only
+        for v in (2, 7, 0):
+            got = render(v)
+            assert pc.same_bits(got, want), f"variant {v}: " + pc.describe_diff(got, want)
+        assert ctx.active_variant() >= 9              # the shipped numbering is back: the culling walk is offered again
+    finally:
+        ctx.set_packet_layout(0)
+        pc.upload_scene(ctx, demo, env)
+        ctx.resize(64, 64)

@@ -76,6 +76,7 @@ struct mi3pt_ctx {
     // subtree, left subtree) and triangles in leaf-visiting order: a pure relabelling.
     int layout = 0;
     bool layout_dirty = false;      // the relabelling still has to be applied to what was uploaded
+    bool tree_proper = false;       // mi3pt_upload_bvh: every node reached once, one leaf per triangle, the 64-entry abort cannot fire
     bool layout_active = false;     // the device holds relabelled packets / triangles
     void *d_tris_perm = nullptr;    // 112-B records in the relabelled order (the uploaded order stays in d_tris)
 
@@ -106,7 +107,8 @@ struct mi3pt_ctx {
     uint32_t *d_drain_flag = nullptr;     // signal memory: sequence number of the last batched launch that started draining
     bool gate_enabled = false;            // launches wait on d_drain_flag (off when the memory or the wait is unavailable)
     uint32_t launch_seq = 0;              // sequence number of the last batched launch
-    uint32_t *d_stack_overflow = nullptr; // [2 parities][PT_MAX_RESIDENT_WAVES][32][64] overflow stack entries
+    uint32_t *d_stack_overflow = nullptr; // [2 parities][PT_MAX_RESIDENT_WAVES][SM_OVERFLOW_ENTRIES][64] overflow stack entries
+    uint8_t *d_service = nullptr;         // ring of SERVICE_SLOTS pt::RtService blocks: one per batched launch in flight (launch_batch)
     uint64_t *d_wave_times = nullptr;     // diagnostic stamps, allocated by mi3pt_debug_wave_times(enable)
     int wave_times_slots = 0;
     int nblocks = 0;
@@ -122,7 +124,7 @@ struct mi3pt_ctx {
     int shade_split = PT_DEFAULT_SHADE_SPLIT;       // MI3PT_SHADE_SPLIT: see RtLaunch::shade_split (64: while lanes walk, only the larger group is served)
     int leaf_min = PT_DEFAULT_LEAF_MIN;          // deferred-leaf walk: lanes with a parked leaf that trigger a triangle step (MI3PT_LEAF_MIN)
     int walk_min = PT_DEFAULT_WALK_MIN;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
-    int waves_per_cu = 16;      // 8 KB of LDS per one-wave workgroup, 128 VGPRs
+    int waves_per_cu = 0;       // one-wave workgroups per compute unit; 0 = what the kernel instantiation is compiled for (pt_kernels.h: 20 / 16)
     int top_packets = 64;       // MI3PT_TOP_PACKETS
 
     // Frame pipelining: raytrace kernels of consecutive frames run on two alternating
@@ -171,6 +173,11 @@ struct mi3pt_ctx {
 // Most frames one launch may cover.  A single GPU batches 16 (the drain tail of a persistent
 // launch is then ~10 % of it); a rank of an N-way tile split renders 1/N of the image per frame,
 // so it batches N times as many frames for the same amount of work per launch.
+// Blocks of launch-invariant scalars for the raytrace kernel's service step (pt::RtService), one per batched launch.  Launches
+// alternate between two streams and at most two are in flight; a slot is rewritten (in stream order, by the setup kernel of
+// launch k + SERVICE_SLOTS) on the stream launch k ran on, i.e. after it.
+static const int SERVICE_SLOTS = 8;
+static size_t service_slot_bytes() { return (pt::service_block_bytes() + 255) / 256 * 256; }
 static int BATCH_LIMIT = 256;           // (MI3PT_BATCH_LIMIT: experiment knob; a rank of an 8-way split: 256 instead of 128 frames per launch -3 % job time)
 
 static inline float ldf(const uint8_t *p, size_t off) { float f; std::memcpy(&f, p + off, 4); return f; }
@@ -285,7 +292,8 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     CREATE_TRY(hipMalloc(&ctx->d_env, env_bytes));
     CREATE_TRY(hipMalloc(&ctx->d_cdf, env_bytes));
     CREATE_TRY(hipMalloc((void **)&ctx->d_tile_counter, 256));
-    CREATE_TRY(hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * 32 * 64 * 4));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * pt::SM_OVERFLOW_ENTRIES * 64 * 4));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_service, (size_t)SERVICE_SLOTS * service_slot_bytes()));
     CREATE_TRY(hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream));     // self-cleaning afterwards
     // a word the command processor can poll (hipStreamWaitValue32) and a running kernel can write;
     // optional: without it launches simply queue behind each other
@@ -353,7 +361,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     free_textures(ctx);
     for (void *p : { ctx->d_wide, ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
-                     (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow })
+                     (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow, (void *)ctx->d_service })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
         for (int k = 0; k < 2; k++)
@@ -570,6 +578,16 @@ extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t 
     ctx->ntris = n;
     ctx->max_mat_ref = max_mat;
     ctx->cull_dirty = true;
+    if (ctx->layout_active && ctx->nnodes > 0) {
+        // The device holds node packets, leaf ranks and the root reference in the visiting-order numbering of the debug
+        // layout, while the triangles just uploaded are in uploaded order again: rebuild the tree's side from the node
+        // records, which are kept as uploaded (round-2 advice: leaves referenced the wrong triangles after a
+        // triangles-only upload that followed mi3pt_debug_set_packet_layout(ctx, 0)).
+        std::vector<uint8_t> nodes(ctx->nnodes * MI3PT_BVHNODE_STRIDE);
+        HIP_TRY(hipMemcpy(nodes.data(), ctx->d_nodes, nodes.size(), hipMemcpyDeviceToHost));
+        ctx->layout_active = false;
+        return mi3pt_upload_bvh(ctx, nodes.data(), nodes.size());
+    }
     ctx->layout_active = false;
     ctx->layout_dirty = ctx->layout != 0;
     return MI3PT_OK;
@@ -683,7 +701,7 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
     // i.e. the walk's worst-case stack occupancy (every box hit) stays below 64.
     std::vector<uint32_t> leaf_rank((size_t)(max_tri + 1 > 0 ? max_tri + 1 : 1), 0xffffffffu);
     int leaf_cap = 0;
-    bool cull_stack_ok = false;
+    bool cull_stack_ok = false, tree_proper = false;
     {
         std::vector<uint32_t> st;
         std::vector<uint8_t> seen(n, 0);
@@ -719,6 +737,7 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
         // worst case stays below 64.  LDS holds 32 entries per lane: the node stack (internal
         // nodes only in the deferred walk) from the bottom, parked leaves from the top.
         if (proper && worst < 64 && (int)worst_internal <= pt::SM_LDS_DEPTH - 4) leaf_cap = pt::SM_LDS_DEPTH - (int)worst_internal;
+        tree_proper = proper && worst < 64;
         (void)visited;      // nodes the root does not reach are never walked by the reference either
         // The culling walks push the nearer child last, so ANY child may be the one that is descended
         // first with all its internal siblings still stacked: occupancy(child) = occupancy(parent) - 1 +
@@ -750,6 +769,7 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
     if (int rc = replace_buffer(ctx, &ctx->d_leaf_rank, leaf_rank.data(), leaf_rank.size() * sizeof(uint32_t))) return rc;
     ctx->leaf_cap = leaf_cap;
     ctx->cull_stack_ok = cull_stack_ok;
+    ctx->tree_proper = tree_proper;
     ctx->nnodes = n;
     ctx->npackets = npackets;
     ctx->root_ref = ref_of(0);
@@ -945,12 +965,12 @@ static int check_scene(const mi3pt_ctx *ctx)
 // names change: every packet holds the same boxes, every leaf the same triangle, so images and
 // counters must be bit-identical to the breadth-first layout in every packet-walking kernel
 // (tests/test_gpu_parity.py::test_depth_first_relabelling_is_bit_identical).  Applied lazily
-// because it needs both uploads; needs a proper tree (leaf_cap > 0).  The distance-culling walk
+// because it needs both uploads; needs a proper tree (tree_proper).  The distance-culling walk
 // is not offered in this layout (variant 0 / 9 run 7).
 static int prepare_layout(mi3pt_ctx *ctx)
 {
     if (!ctx->layout_dirty) return MI3PT_OK;
-    if (ctx->layout == 0 || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->leaf_cap <= 0 || ctx->max_tri_ref >= (int64_t)ctx->ntris)
+    if (ctx->layout == 0 || ctx->nnodes == 0 || ctx->ntris == 0 || !ctx->tree_proper || ctx->max_tri_ref >= (int64_t)ctx->ntris)
         return MI3PT_OK;       // stays dirty; the uploaded (breadth-first) arrangement is complete by itself
     if (int rc = flush_pending(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1414,6 +1434,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.drain_seq = 0;
     L.waves_per_cu = ctx->waves_per_cu;
     L.num_cus = ctx->num_cus;
+    L.service = nullptr;          // (batched launches: a slot of the context's ring, see launch_batch)
     L.top_packets = ctx->top_packets;
     if (pick_variant(ctx) == 1) L.scene.tris = static_cast<const float4 *>(ctx->d_tris);    // uploaded records, uploaded indices
     return L;
@@ -1501,7 +1522,8 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame &first, in
     L.nframes = n;
     L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
     L.tile_counter = ctx->d_tile_counter + par * 32;
-    L.stack_overflow = ctx->d_stack_overflow + (size_t)par * pt::PT_MAX_RESIDENT_WAVES * 32 * 64;
+    L.stack_overflow = ctx->d_stack_overflow + (size_t)par * pt::PT_MAX_RESIDENT_WAVES * pt::SM_OVERFLOW_ENTRIES * 64;
+    L.service = reinterpret_cast<pt::RtService *>(ctx->d_service + (size_t)((ctx->seq - 1) % SERVICE_SLOTS) * service_slot_bytes());
     if (ctx->timing)
         if (int rc = collect_rt_time(ctx, par)) return rc;      // the launch of two batches ago
     // Hold this launch until the previous one (on the other stream) has handed out its last job:

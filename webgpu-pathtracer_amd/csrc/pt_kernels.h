@@ -9,23 +9,38 @@ namespace pt {
 // per-wave overflow-stack slices and diagnostic slots.  MI355X: 256 CUs x at most 24 waves.
 constexpr int PT_MAX_RESIDENT_WAVES = 256 * 24;
 
-// Stack entries per lane that the state-machine kernels keep in LDS ([depth][lane], 256 B per
-// entry and wave).  16 one-wave workgroups per CU x SM_LDS_DEPTH x 256 B must fit the 160 KB of LDS.
+// Stack entries per lane that the state-machine kernels keep in LDS ([depth][lane], 256 B per entry and wave).  With the
+// 1.5 KB of parked path state, 20 one-wave workgroups per CU x (SM_LDS_DEPTH x 256 B + 1536 B) must fit the 160 KB of LDS --
+// and not fill it to the last byte: with 26 entries (exactly 163 840 B) the twentieth wave was not resident and the
+// persistent grid ran with a straggler (dragon-class 15.4 instead of 16.0 Grays/s, profiles/r03_b_occupancy_ab.log).
 #ifndef PT_SM_LDS_DEPTH_VALUE
-#define PT_SM_LDS_DEPTH_VALUE 32
+#define PT_SM_LDS_DEPTH_VALUE 24
 #endif
 constexpr int SM_LDS_DEPTH = PT_SM_LDS_DEPTH_VALUE;
+// Stack entries per lane beyond the LDS part: a wave's slice of the global overflow area (the reference aborts a walk at 64
+// stacked entries, raytrace.wgsl:167-171: PT_MAX_STACK in pt_kernels.hip)
+constexpr int SM_OVERFLOW_ENTRIES = 64 - SM_LDS_DEPTH;
 // The culling walks (CULL, WIDE) visit children near first, so their stack occupancy is not the reference order's.
 // They keep a fixed leaf list of SM_CULL_LEAF_CAP entries at the top of the LDS column, node entries in the
-// SM_LDS_DEPTH - SM_CULL_LEAF_CAP slots below it, and deeper node entries (rare) in the wave's global overflow slice
-// (PT_MAX_STACK - SM_LDS_DEPTH = 32 more per lane); the context offers them only when the order-independent worst case
-// (every box hit, every child possibly first) fits: SM_CULL_STACK_MAX entries.
+// SM_LDS_DEPTH - SM_CULL_LEAF_CAP slots below it, and deeper node entries (rare) in the wave's global overflow slice;
+// the context offers them only when the order-independent worst case (every box hit, every child possibly first) fits
+// both together: SM_CULL_STACK_MAX entries.
 #ifndef PT_CULL_LEAF_CAP_VALUE
 #define PT_CULL_LEAF_CAP_VALUE 8
 #endif
 constexpr int SM_CULL_LEAF_CAP = PT_CULL_LEAF_CAP_VALUE;
-constexpr int SM_CULL_STACK_MAX = SM_LDS_DEPTH - SM_CULL_LEAF_CAP + 32;
+constexpr int SM_CULL_STACK_MAX = SM_LDS_DEPTH - SM_CULL_LEAF_CAP + SM_OVERFLOW_ENTRIES;
+// The WIDE walk parks up to four leaves per node step (its `full` rule needs LCAP - 4 >= 0 free slots to ever run one), and
+// the culling walks pop one entry and push up to three more than they popped below the leaf list.
+static_assert(SM_CULL_LEAF_CAP >= 4 && SM_LDS_DEPTH - SM_CULL_LEAF_CAP >= 3, "leaf list / node slots of the culling walks");
+static_assert(SM_LDS_DEPTH >= 8 && SM_LDS_DEPTH <= 32, "LDS stack depth");
 
+// Resident waves per SIMD the state-machine kernels are compiled for (__launch_bounds__: 5 -> at most 96 vector registers,
+// 4 -> 128) and, times four SIMDs, the one-wave workgroups per compute unit of their persistent grid: the tuned twins of
+// the shipped walks need 95-96 registers since their service step's scalars moved to memory (RtService) and run five per
+// SIMD; the diagnostic twins and the other variants keep four.
+constexpr int SM_TUNED_WAVES_PER_SIMD = 5, SM_OTHER_WAVES_PER_SIMD = 4;
+static_assert(4 * SM_TUNED_WAVES_PER_SIMD * (SM_LDS_DEPTH * 256 + 6 * 256) < 160 * 1024, "LDS: stack + parked path state of every resident wave");
 
 // per-pass counters, see mi3pt_counter in include/mi3pt.h
 enum { CNT_RAYS, CNT_BOX, CNT_TRI, CNT_HIT, CNT_MISS, CNT_OVERFLOW, CNT_PIXELS, CNT_RESERVED, CNT_COUNT };
@@ -131,6 +146,8 @@ struct Tile {
 #define PT_DEFAULT_TAIL_POLICY 7
 #define PT_DEFAULT_JOB_CHUNK 4
 
+struct RtService;      // pt_kernels.hip: the launch-invariant scalars of the state-machine kernel's service step
+
 struct RtLaunch {
     SceneRefs scene;
     RtUniforms un;
@@ -158,7 +175,10 @@ struct RtLaunch {
     int32_t top_packets;         // node packets to stage in LDS per wave (0..64)
     int32_t waves_per_cu;        // persistent kernels: resident one-wave workgroups per CU
     int32_t num_cus;             // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+    RtService *service;          // device memory for one RtService block (service_block_bytes()), or null: the tuned twin of the
+                                 // state-machine kernel reads its service step's scalars from it (launch_raytrace fills it first)
 };
+size_t service_block_bytes();
 
 void launch_raytrace(const RtLaunch &L, bool fuse_accumulate, int variant, hipStream_t s);
 void launch_accumulate_batch(const AccUniforms &acc0, const Tile &tile, const float4 *slots, size_t slot_pixels,
@@ -173,7 +193,7 @@ void launch_debug_math(int fn, const float *a, const float *b, float *out, size_
 int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, uint32_t total, uint32_t *counter, float4 *out, int waves_per_simd,
                       int lcap, int leaf_min, int num_cus, hipStream_t s);
 int raytrace_grid_blocks(const Tile &tile);
-int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu, int num_cus);
+int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu, int num_cus, bool tuned = false);
 // writes NodePacket::cull of `npackets` packets from a dense array (the context's cull analysis)
 void launch_patch_cull(float4 *packets, const uint32_t *cull, uint32_t npackets, hipStream_t s);
 

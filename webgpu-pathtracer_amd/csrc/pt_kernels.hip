@@ -1020,11 +1020,112 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
     kb = ok ? scene_kb * fmaxf(1.0f, dd) : __builtin_inff();
 }
 
+// ---------------------------------------------------------------------------------
+// The launch-invariant scalars of the state-machine kernel's SERVICE step: the camera frame, sin / cos of the environment
+// rotation, the root box, 1 / resolution, the job-decode divisors, and the launch block itself (pointers, uniforms, tile).
+// None of it is touched by node or triangle steps, yet held in scalar registers for the whole kernel it was ~70 SGPRs
+// too many: the compiler spilled them to vector-register lanes and reloaded them with v_readlane, 143 of them in the
+// service step (round 2: `SGPRs Spill: 67`).  The tuned instantiations therefore keep it in memory: k_rt_service_setup
+// computes the block once per launch -- with the very device functions the kernel used to call in its prologue, so the
+// bits are the same -- and every service step loads what it uses with scalar loads (load_const_block: s_load through a
+// constant-address-space pointer whose offset the compiler cannot see through, so the loads are not hoisted back out of
+// the loop).  The diagnostic twins compute the same block in their prologue and keep it in registers, as before.
+// ---------------------------------------------------------------------------------
+struct RtService {
+    RtLaunch L;
+    CameraFrame cf;
+    f3 cam_pos;
+    float sinr, cosr;
+    float root_mn[3], root_mx[3];
+    float inv_res_x, inv_res_y, spf_f;
+    uint32_t res_w, res_h;
+    int32_t pinhole, res_ordinary;
+    int32_t tiles_x, ntiles_frame, ntiles;
+    int32_t grp_jobs, grp_full, grp_last;
+    FastDiv dv_frame, dv_grp, dv_gs, dv_last, dv_tx;
+};
+static_assert(sizeof(RtService) % 4 == 0, "loaded as dwords");
+size_t service_block_bytes() { return sizeof(RtService); }
+
+// What the state-machine kernel's prologue computes from the launch block (per lane, identically in every lane).
+PT_DEV RtService compute_service(const RtLaunch &L, bool scene_has_nodes)
+{
+    RtService S;
+    const RtUniforms &un = L.un;
+    S.L = L;
+    S.cf = camera_frame(un);
+    S.cam_pos = F3(un.cam_pos[0], un.cam_pos[1], un.cam_pos[2]);
+    ptm::sincos(un.env_rotation, S.sinr, S.cosr);
+    float4 root0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), root1 = root0;
+    if (scene_has_nodes) { root0 = L.scene.nodes[0]; root1 = L.scene.nodes[1]; }
+    S.root_mn[0] = root0.x; S.root_mn[1] = root0.y; S.root_mn[2] = root0.z;
+    S.root_mx[0] = root1.x; S.root_mx[1] = root1.y; S.root_mx[2] = root1.z;
+    // per-pixel divisions by launch-invariant divisors: 1 / resolution once, and pixel / resolution
+    // as an exact quotient from that reciprocal (ptm::div_pre; pixel indices are 0 or >= 1, so the
+    // only proviso is a resolution of ordinary magnitude -- otherwise the plain division runs)
+    S.inv_res_x = 1.0f / un.res_x;
+    S.inv_res_y = 1.0f / un.res_y;
+    S.res_ordinary = (un.res_x >= 9.5367431640625e-07f && un.res_x <= 1.099511627776e12f &&
+                      un.res_y >= 9.5367431640625e-07f && un.res_y <= 1.099511627776e12f) ? 1 : 0;
+    S.spf_f = (float)un.samples_per_frame;
+    S.res_w = (uint32_t)un.res_x;
+    S.res_h = (uint32_t)un.res_y;
+    // thin lens off (aperture exactly 0, no -0 camera coordinate): see the camera path start
+    S.pinhole = (un.aperture == 0.0f && __float_as_uint(un.cam_pos[0]) != 0x80000000u &&
+                 __float_as_uint(un.cam_pos[1]) != 0x80000000u && __float_as_uint(un.cam_pos[2]) != 0x80000000u) ? 1 : 0;
+    S.tiles_x = (L.tile.tex_w + 7) >> 3;
+    // A launch covers L.nframes consecutive frames: job = (frame slot, 8x8 tile)
+    S.ntiles_frame = S.tiles_x * ((L.tile.local_rows + 7) >> 3);
+    S.ntiles = S.ntiles_frame * L.nframes;
+    S.grp_jobs = (L.job_group > 0 && L.job_group < S.ntiles_frame) ? L.job_group * L.nframes : 0;
+    S.grp_full = S.grp_jobs ? S.ntiles_frame / L.job_group : 0;
+    S.grp_last = S.grp_jobs ? S.ntiles_frame - S.grp_full * L.job_group : 1;       // tiles in the (shorter) last group
+    S.dv_frame = fast_div_of((uint32_t)S.ntiles_frame);
+    S.dv_grp = fast_div_of((uint32_t)(S.grp_jobs ? S.grp_jobs : 1));
+    S.dv_gs = fast_div_of((uint32_t)(L.job_group > 0 ? L.job_group : 1));
+    S.dv_last = fast_div_of((uint32_t)(S.grp_last > 0 ? S.grp_last : 1));
+    S.dv_tx = fast_div_of((uint32_t)S.tiles_x);
+    return S;
+}
+
+__global__ void __launch_bounds__(64) k_rt_service_setup(const RtLaunch L, RtService *out)
+{
+    const RtService S = compute_service(L, L.scene.nnodes != 0);
+    if (threadIdx.x == 0) *out = S;
+}
+
+// A block of launch-invariant scalars read back from memory with scalar loads.  The opaque offset (always 0) keeps the
+// compiler from hoisting the loads out of the loop they are issued in; the constant address space makes them s_load.
+template <class T>
+PT_DEV T load_const_block(const T *g)
+{
+    static_assert(sizeof(T) % 4 == 0 && __is_trivially_copyable(T), "dwords");
+    uint32_t off = 0;
+    asm volatile("" : "+s"(off));
+    typedef const __attribute__((address_space(4))) uint32_t *cptr;
+    const cptr p = (cptr)((uintptr_t)g + off);
+    uint32_t w[sizeof(T) / 4];
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; i++) w[i] = p[i];
+    T t;
+    __builtin_memcpy(&t, w, sizeof(T));
+    return t;
+}
+// The same values made wave-uniform by readfirstlane (a block computed by vector instructions: the diagnostic twins)
+template <class T>
+PT_DEV T uniform_block(const T &v)
+{
+    uint32_t w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; i++) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[i]);
+    T t;
+    __builtin_memcpy(&t, w, sizeof(T));
+    return t;
+}
+
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
 #define PT_SM_TOP_PACKETS 32       // node packets staged in LDS per wave (2 KB: 16 waves per CU still fit): the top 5 levels
-#ifndef PT_SM_MIN_WAVES
-#define PT_SM_MIN_WAVES 4
-#endif
 // TOPLDS = true additionally stages the first PT_SM_TOP_PACKETS node packets in LDS (kernel
 // variant 6).  Measured on MI355X (round 1): no gain -- the kernel is
 // VALU-issue-bound and the top of the tree is L1-resident anyway, while the second load path
@@ -1056,7 +1157,7 @@ PT_DEV void cull_setup(const f3 &d, const RayPre &pre, float scene_ka, float sce
 // context chooses it only for scenes whose culling margins are negligible (SceneRefs::cull_ymax).
 template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false, bool WIDE = false, bool SPF1 = false, bool DIAG = true,
           bool FILT = false, bool YMAX = false>
-__global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLaunch L)
+__global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_WAVES_PER_SIMD) k_raytrace_sm(const RtLaunch L)
 {
     // DIAG = false (the shipped walks' batched launches when no diagnostic buffer is bound): the per-wave step statistics
     // and stamps are compiled out -- two dozen scalar registers that the walk loop's own scalars were spilled for
@@ -1109,7 +1210,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         else stack[i * 64] = v;
     };
     const SceneRefs &sc = L.scene;
-    const RtUniforms &un = L.un;
+    (void)0;
     int sp = 0;
     int nl = 0;              // DEFER: leaves waiting in this lane's list (LDS slots DEPTH - 1, DEPTH - 2, ...)
     // Culling walks: node entries [0, NCAP) in LDS, deeper ones in the overflow slice; leaves in the LCAP slots on top.
@@ -1139,41 +1240,11 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         nl += (lf && ref != PT_REF_NONE) ? 1 : 0;
         sp += lf ? 0 : 1;
     };
-    const int tiles_x = (L.tile.tex_w + 7) >> 3;
-    // A launch covers L.nframes consecutive frames: job = (frame slot, 8x8 tile), frame-major.
-    const int ntiles_frame = tiles_x * ((L.tile.local_rows + 7) >> 3);
-    const int ntiles = ntiles_frame * L.nframes;
-    const uint32_t res_w = (uint32_t)un.res_x, res_h = (uint32_t)un.res_y;
-
-    // Launch-invariant values are computed (or loaded) by vector instructions and would sit in
-    // vector registers for the whole kernel; they are the same in every lane, so readfirstlane
-    // moves them to scalar registers and frees ~25 VGPRs for the walk.
-    auto uni = [](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
-    auto uni3 = [&](const f3 &a) { return F3(uni(a.x), uni(a.y), uni(a.z)); };
-    CameraFrame cf = camera_frame(un);
-    cf.t = uni(cf.t); cf.r = uni(cf.r); cf.w = uni3(cf.w); cf.u_dir = uni3(cf.u_dir); cf.v_dir = uni3(cf.v_dir);
-    const f3 cam_pos = F3(un.cam_pos[0], un.cam_pos[1], un.cam_pos[2]);
-    float sinr, cosr;
-    ptm::sincos(un.env_rotation, sinr, cosr);
-    sinr = uni(sinr); cosr = uni(cosr);
-    float4 root0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), root1 = root0;
-    if (TUNED || sc.nnodes != 0) { root0 = sc.nodes[0]; root1 = sc.nodes[1]; }
-    root0 = make_float4(uni(root0.x), uni(root0.y), uni(root0.z), uni(root0.w));
-    root1 = make_float4(uni(root1.x), uni(root1.y), uni(root1.z), uni(root1.w));
-    // per-pixel divisions by launch-invariant divisors: 1 / resolution once, and pixel / resolution
-    // as an exact quotient from that reciprocal (ptm::div_pre; pixel indices are 0 or >= 1, so the
-    // only proviso is a resolution of ordinary magnitude -- otherwise the plain division runs)
-    const float inv_res_x = uni(1.0f / un.res_x), inv_res_y = uni(1.0f / un.res_y);
-    const bool res_ordinary = TUNED || (un.res_x >= 9.5367431640625e-07f && un.res_x <= 1.099511627776e12f &&
-                                        un.res_y >= 9.5367431640625e-07f && un.res_y <= 1.099511627776e12f);
-    // thin lens off (aperture exactly 0, no -0 camera coordinate): see the camera path start
-    const bool pinhole = un.aperture == 0.0f && __float_as_uint(un.cam_pos[0]) != 0x80000000u &&
-                         __float_as_uint(un.cam_pos[1]) != 0x80000000u && __float_as_uint(un.cam_pos[2]) != 0x80000000u;
-    const float spf_f = (float)un.samples_per_frame;
-    auto per_sample = [&](const f3 &sum) {     // incomingLight / f32(samplesPerFrame), raytrace.wgsl:455 (x / 1 == x)
-        return un.samples_per_frame == 1 ? sum : F3(sum.x / spf_f, sum.y / spf_f, sum.z / spf_f);
-    };
-
+    // The service step's launch-invariant scalars (RtService).  Tuned instantiation: in memory, written by
+    // k_rt_service_setup before this launch; each service step loads what it uses (nothing of it lives in registers during
+    // the walk).  Otherwise: computed here, made wave-uniform by readfirstlane, kept in scalar registers.
+    RtService S0;
+    if constexpr (!TUNED) S0 = uniform_block(compute_service(L, sc.nnodes != 0));
     // diagnostic stamps (only when a buffer is bound): wall clock (100 MHz) and shader clock
     const uint64_t t_begin_rt = wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const uint64_t t_begin_clk = wave_times ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1219,32 +1290,26 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     // 36 % faster with 4 tickets per draw, the 870 k-triangle scene 2 %).  Near the end of the queue (fewer than two
     // draws per wave left) tickets are drawn singly, so that no wave sits on jobs while others run dry.
     int have = 0, have_at = 0;           // tickets in hand: have_at, have_at + 1, ... (`have` of them)
-    auto draw = [&]() {
+    auto draw = [&](const RtService &S) {
+        const int ntiles = S.ntiles;
         const int c = (ntiles - have_at > 2 * k_job_chunk * (int)gridDim.x) ? k_job_chunk : 1;
         int t = 0;
         if (lane == 0) {
-            t = (int)atomicAdd(L.tile_counter, (uint32_t)c);
+            t = (int)atomicAdd(S.L.tile_counter, (uint32_t)c);
             // When the queue is about to run dry (half a grid of jobs left: a lead of some tens of
             // microseconds over the first exiting wave, which covers the command processor's wake-up
             // and the dispatch) this launch announces its drain.  The host holds the next launch
             // back (a stream wait on this word) until then, so that launches run back to back with
             // only their tails overlapping instead of queueing for slots behind each other.
             const int drain_mark = max(ntiles - (int)(gridDim.x >> 1), 0);
-            if (t <= drain_mark && drain_mark < t + c && L.drain_flag)
-                __hip_atomic_store(L.drain_flag, L.drain_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (t <= drain_mark && drain_mark < t + c && S.L.drain_flag)
+                __hip_atomic_store(S.L.drain_flag, S.L.drain_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         have_at = __builtin_amdgcn_readfirstlane(t);
         have = c;
     };
     int cur_tile = 0, cur_used = 64, cur_fslot = 0, cur_ftile = 0;
-    const int grp_jobs = (L.job_group > 0 && L.job_group < ntiles_frame) ? L.job_group * L.nframes : 0;
-    const int grp_full = grp_jobs ? ntiles_frame / L.job_group : 0;
-    const int grp_last = grp_jobs ? ntiles_frame - grp_full * L.job_group : 1;       // tiles in the (shorter) last group
-    auto uni_div = [](FastDiv f) { f.m = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.m); f.sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.sh); return f; };
-    const FastDiv dv_frame = uni_div(fast_div_of((uint32_t)ntiles_frame)), dv_grp = uni_div(fast_div_of((uint32_t)(grp_jobs ? grp_jobs : 1)));
-    const FastDiv dv_gs = uni_div(fast_div_of((uint32_t)(L.job_group > 0 ? L.job_group : 1))), dv_last = uni_div(fast_div_of((uint32_t)(grp_last > 0 ? grp_last : 1)));
-    const FastDiv dv_tx = uni_div(fast_div_of((uint32_t)tiles_x));
-    draw();
+    if constexpr (TUNED) draw(load_const_block(L.service)); else draw(S0);
     bool feed_empty = false;
 
     for (;;) {
@@ -1599,6 +1664,28 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
         // off.  With L.shade_split > 0, and while other lanes are still walking, a step serves the
         // larger group and leaves the smaller one waiting (unless it has shade_split lanes by itself):
         // the groups alternate, each at a fuller mask.  Per-lane arithmetic is untouched: same bits.
+        // (from here on `L`, `sc`, `un` and the derived scalars are this step's view of the RtService block)
+        // (tuned: the block is loaded again at the start of each part of the step -- PT_SERVICE_PART -- so that only what
+        // that part reads is in scalar registers at a time; loaded once for the whole step, ~70 values at once, the compiler
+        // spilled half of them straight back to vector-register lanes)
+        RtService *const service_block = L.service;
+        RtService S;
+        if constexpr (TUNED) S = load_const_block(service_block); else S = S0;
+#define PT_SERVICE_PART() do { if constexpr (TUNED) S = load_const_block(service_block); } while (0)
+        const RtLaunch &L = S.L;
+        const SceneRefs &sc = L.scene;
+        const RtUniforms &un = L.un;
+        const CameraFrame &cf = S.cf;
+        const f3 &cam_pos = S.cam_pos;
+        const float &sinr = S.sinr, &cosr = S.cosr, &inv_res_x = S.inv_res_x, &inv_res_y = S.inv_res_y, &spf_f = S.spf_f;
+        const uint32_t &res_w = S.res_w, &res_h = S.res_h;
+        const int32_t &pinhole = S.pinhole, &res_ordinary_ = S.res_ordinary;
+        const int &tiles_x = S.tiles_x, &ntiles_frame = S.ntiles_frame, &ntiles = S.ntiles;
+        const int &grp_jobs = S.grp_jobs, &grp_full = S.grp_full, &grp_last = S.grp_last;
+        const FastDiv &dv_frame = S.dv_frame, &dv_grp = S.dv_grp, &dv_gs = S.dv_gs, &dv_last = S.dv_last, &dv_tx = S.dv_tx;
+        auto per_sample = [&](const f3 &sum) {     // incomingLight / f32(samplesPerFrame), raytrace.wgsl:455 (x / 1 == x)
+            return un.samples_per_frame == 1 ? sum : F3(sum.x / spf_f, sum.y / spf_f, sum.z / spf_f);
+        };
         const unsigned long long m_hit = __ballot(mode == M_SHADE && best.tri >= 0);
         const int n_hit = (int)__popcll(m_hit);
         const int n_b = (int)__popcll(__ballot((mode == M_SHADE && best.tri < 0) || mode == M_PATH || (mode == M_DEAD && !feed_empty)));
@@ -1654,6 +1741,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
 #ifdef PT_DIAG_SERVICE
             if (wave_times) st_switch(4);
 #endif
+            PT_SERVICE_PART();
             if (shade_miss) {         // :396-407
                 
                 float u, v;
@@ -1661,6 +1749,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 const f3 env = sample_env(sc.env, TUNED ? 1024 : sc.env_w, TUNED ? 512 : sc.env_h, u, v);      // (the environment texture is 1024 x 512 by the API: renderer.ts:76-85)
                 light = light + (ray_color * env) * un.env_intensity;
             }
+            PT_SERVICE_PART();
             if (shade_hit || shade_miss) {
                 mode = M_DEAD;        // until a path / segment is started below
                 if (ended) {
@@ -1685,6 +1774,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
 #ifdef PT_DIAG_SERVICE
         if (wave_times) st_switch(5);
 #endif
+        PT_SERVICE_PART();
         // refill: free lanes take new jobs
         uint32_t job_px = 0u, job_py = 0u;          // SPF1: the pixel a lane has just been given (used below, in this step)
         if (do_b) {
@@ -1712,7 +1802,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                         cur_ftile = g * L.job_group + (r - cur_fslot * gs);
                     }
                     have_at++;
-                    if (--have == 0) draw();
+                    if (--have == 0) draw(S);
                     cur_used = 0;
                 }
                 const int take = min((int)__popcll(dead), 64 - cur_used);
@@ -1752,6 +1842,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 dead = __ballot(mode == M_DEAD && !need_segment && !mine);
             }
         }
+        PT_SERVICE_PART();
         if (wave_times) st_path_lanes += (uint32_t)__popcll(__ballot(do_b && mode == M_PATH));
         if (do_b && mode == M_PATH) {
             // raytrace.wgsl:441-455: next sample's camera path, or the pixel is finished
@@ -1765,7 +1856,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 }
                 float uvx, uvy;
                 const uint32_t pxx = SPF1 ? job_px : gx, pyy = SPF1 ? job_py : gy;
-                if (res_ordinary) { uvx = div_pre((float)pxx, un.res_x, inv_res_x); uvy = div_pre((float)pyy, un.res_y, inv_res_y); }
+                if (TUNED || res_ordinary_ != 0) { uvx = div_pre((float)pxx, un.res_x, inv_res_x); uvy = div_pre((float)pyy, un.res_y, inv_res_y); }
                 else { uvx = (float)pxx / un.res_x; uvy = (float)pyy / un.res_y; }
                 const f3 dir0 = camera_direction(cf, un.aspect, uvx, uvy);
                 float jx, jy, kx, ky;
@@ -1802,6 +1893,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
 #ifdef PT_DIAG_SERVICE
         if (wave_times) st_switch(6);
 #endif
+        PT_SERVICE_PART();
         if (wave_times) st_segment_lanes += (uint32_t)__popcll(__ballot(need_segment));
         {
             const uint32_t nseg = (uint32_t)__popcll(__ballot(need_segment));
@@ -1835,7 +1927,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
                 slow_segment = (pre.flags & 8u) != 0u;
                 if (CULL) cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
                 
-                if (ray_aabb_pre(o, d, pre, !TUNED && (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
+                if (ray_aabb_pre(o, d, pre, !TUNED && (sc.flags & 1u) == 0u, S.root_mn[0], S.root_mn[1], S.root_mn[2], S.root_mx[0], S.root_mx[1], S.root_mx[2])) {
                     if (!TUNED && DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
                         stack[(DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu;
                         sp = 0; nl = 1;
@@ -1848,6 +1940,7 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
             }
         }
         if (DIAG) u_slow += (uint32_t)__popcll(__ballot(slow_segment));
+#undef PT_SERVICE_PART
     }
 
     if (wave_times && lane == 0) {
@@ -1893,10 +1986,10 @@ __global__ void __launch_bounds__(64, PT_SM_MIN_WAVES) k_raytrace_sm(const RtLau
     }
 }
 
-int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu, int num_cus)
+int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu, int num_cus, bool tuned)
 {
     const int ntiles = raytrace_grid_blocks(tile);
-    if (waves_per_cu <= 0 || waves_per_cu > 24) waves_per_cu = 16;   // default 16: VGPR-limited, 4 waves per SIMD
+    if (waves_per_cu <= 0 || waves_per_cu > 24) waves_per_cu = 4 * (tuned ? SM_TUNED_WAVES_PER_SIMD : SM_OTHER_WAVES_PER_SIMD);
     if (num_cus <= 0) num_cus = 256;
     int resident = num_cus * waves_per_cu;                            // the device's own CU count (hipDeviceProp_t)
     if (resident > PT_MAX_RESIDENT_WAVES) resident = PT_MAX_RESIDENT_WAVES;
@@ -1916,7 +2009,6 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
     if (blocks <= 0) return;
     const dim3 block(64);
     if (variant >= 3) {
-        const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu, L.num_cus));
         // (SPF1: the shipped walks' batched launches have a specialisation for samplesPerFrame == 1, the reference's
         // default -- no per-pixel sum and sample counter to carry through the walk: five registers less)
         const bool one = L.un.samples_per_frame == 1 && !fuse && L.un.max_bounces < 65536 && L.nframes <= 65535;
@@ -1926,8 +2018,11 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
                            L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 &&
                            L.scene.nnodes != 0 && (L.scene.flags & 1u) != 0u && (L.scene.root_ref & PT_REF_LEAF) == 0u &&
                            L.scene.env_w == 1024 && L.scene.env_h == 512 &&
-                           L.un.max_bounces > 0 && L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
+                           L.service != nullptr && L.un.max_bounces > 0 && L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
                            L.un.res_y >= 9.5367431640625e-07f && L.un.res_y <= 1.099511627776e12f;
+        const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu, L.num_cus, tuned && variant >= 9 && variant <= 12));
+        // (the tuned twins read their service step's scalars from L.service: filled here, in stream order, by one wave)
+        if (tuned && (variant >= 9 && variant <= 12)) hipLaunchKernelGGL(k_rt_service_setup, dim3(1), dim3(64), 0, s, L, L.service);
         if (variant >= 10 && variant <= 12) {            // the culling walk on 4-ary wide packets
             // 11 / 12: the filtered slab test (12: with the one-axis culling condition) in the shipped batched launch; the
             // other launch flavours (fused, diagnostic, samplesPerFrame != 1) run variant 10's exact test -- same bits
