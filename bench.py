@@ -23,17 +23,25 @@ N=8: 3840x4320) so that every GPU always renders 1920x1080 pixels per frame.
 
 Prints ONE JSON line on rank 0: metric Mrays/s (rays = raySceneIntersect calls, counted exactly
 by the kernel), plus
-  roofline     : the dominant kernel (the persistent raytrace kernel) against the HBM peak --
-                 `traffic` = HBM-side bytes per launch from rocprofv3 PMC passes of THIS command
-                 line (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md), run
-                 as child processes after the timed job; `achieved` = traffic / the kernel's
-                 average launch duration (HIP event pairs on the stream each launch ran on);
-                 `frac` = achieved / 8 TB/s.  The kernel is NOT HBM-bound:
-                 `real_bound`, `valu_issue_frac` and `lane_utilisation` (SQ counters, one more
-                 pass) say what it is bound by; the algorithmic byte rate SURVEY.md 8(d) defines
-                 is kept beside it as `algorithmic_GBps` (it is served by L1/L2 and may exceed the
-                 HBM peak -- it is not a roofline fraction).
-  cpu_baseline : the CPU oracle timed on a bounded sample of the same workload (rank 0, N = 1).
+  roofline     : the dominant kernel (the persistent raytrace kernel) against the roof that binds it.
+                 It is NOT HBM-bound on this workload (the 181 MB scene sits in the 256 MiB Infinity
+                 Cache; the algorithmic byte rate SURVEY.md 8(d) defines exceeds the HBM peak): what
+                 it runs out of is vector-ALU lane-operations -- `bound: "valu"`, `achieved` = VALU
+                 lane-operations per second (SQ_INSTS_VALU x 64 x lane utilisation / kernel time),
+                 `peak` = CUs x 4 SIMDs x 2.4 GHz / 2 x 64 lanes, `frac` = achieved / peak =
+                 valu_issue_frac x lane_utilisation.  The memory side is reported beside it:
+                 `traffic` = HBM-side bytes per launch from rocprofv3 PMC passes of THIS command line
+                 (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md), `hbm` =
+                 traffic / kernel time against 8 TB/s, `l2` = (TCC_HIT + TCC_MISS) x 128 B / kernel
+                 time against the guide's 34.5 TB/s, `algorithmic_GBps` as SURVEY.md defines it.
+                 Kernel time = the launches' exclusive share of the GPU clock (`kernel_ms_exclusive`:
+                 consecutive launches overlap at their tails), from HIP event pairs on the streams
+                 the launches ran on.
+  forest       : the same measurement for BASELINE.json's config 5 scene (10 M triangles, 2.08 GB:
+                 the only one larger than the Infinity Cache, i.e. the one where HBM can bind), at
+                 1920x1080 so that it fits the default run.
+  cpu_baseline : the CPU oracle timed on a bounded sample of the same workload (rank 0, N = 1),
+                 with its thread scaling.
 The oracle is only ever the baseline / checker here, never the thing measured as `value`.
 """
 import argparse
@@ -58,11 +66,18 @@ SHADER_CLOCK_HZ = 2.4e9         # peak engine clock used for the VALU issue rate
 BLOCK_ROWS = int(os.environ.get("MI3PT_BENCH_BLOCK_ROWS", "8"))     # rows per block of the tile split (experiment knob)
 BOUNCES = 8
 FRAMES_PER_STEP = 16            # one step = one batch = one launch of the persistent kernel (single GPU)
+L2_PEAK_GBS = 34500.0           # same guide: L2 (8 x 4 MiB), aggregate
 KERNEL_NEEDLE = "k_raytrace_sm"
 # counter groups of the PMC passes: one rocprofv3 run each (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
               ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
-               "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"))
+               "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"),
+              ("TCC_HIT_sum", "TCC_MISS_sum"))
+# a second camera on the headline scene: the model fills the frame (the reference's camera, main.ts:83-92, sees mostly
+# floor and sky around the unit-height model: 1.86 rays per pixel, half of them single sky / floor segments)
+CLOSEUP_CAMERA = {"position": (0.55, 0.62, 1.15), "target": (0.0, 0.5, 0.0)}
+FOREST_IMAGE = (1920, 1080)     # the forest leg of the default run (config 5's scene; its own image is 3840x2160 on 8 GPUs)
+FOREST_STEPS, FOREST_WARMUP = 8, 4
 
 
 def image_size(n_gpus, scaling):
@@ -74,14 +89,25 @@ def image_size(n_gpus, scaling):
 
 def build_scene(workload):
     from mi3pt_host import scenes
-    sc = scenes.dragon_class_scene() if workload == "dragon" else scenes.demo_scene()
+    if workload == "demo":
+        sc = scenes.demo_scene()
+    elif workload == "forest":
+        sc = scenes.forest_scene()
+    else:
+        sc = scenes.dragon_class_scene()
+        if workload == "closeup":
+            sc.camera = dict(sc.camera, **CLOSEUP_CAMERA)
     sc.build_bvh()
     return sc, scenes.synthetic_env()
 
 
 def workload_name(workload, sc):
-    return ("default demo mesh (1,998 triangles) + synthetic env map" if workload == "demo"
-            else f"dragon-class procedural mesh ({len(sc.triangles)} triangles) + synthetic env map")
+    if workload == "demo":
+        return "default demo mesh (1,998 triangles) + synthetic env map"
+    if workload == "forest":
+        return f"instanced forest ({len(sc.triangles)} triangles, flattened) + synthetic env map"
+    return (f"dragon-class procedural mesh ({len(sc.triangles)} triangles) + synthetic env map"
+            + (", close-up camera (the model fills the frame)" if workload == "closeup" else ""))
 
 
 def algorithmic_bytes(c):
@@ -155,29 +181,48 @@ class Job:
             done += k
 
 
-def cpu_baseline(job, budget_s=12.0):
-    """Time the CPU oracle on interleaved 1/8 shards of the same frames until the budget is
-    used.  kind = "port": the oracle is a restatement, not the reference."""
+def cpu_baseline(job, budget_s=20.0):
+    """The CPU oracle timed on 1/16-image shards (8-row blocks dealt round robin, like the GPU tile split) of the same
+    frames, with 1, 4, 16, 64 and all hardware threads in turn, each for its share of the budget; one OpenMP team
+    per shard call (tens to hundreds of ms of work each; the team's threads are kept between calls).  `value` is the
+    best leg, `cores` its thread count: on a box whose CPU share is smaller than its processor count (a container
+    quota) more threads than the share only add contention.  kind = "port": the oracle is a restatement, not the
+    reference."""
     import pt_oracle as orc
     sc = job.sc
     osc = orc.OracleScene(sc.triangles, sc.material_bytes, sc.nodes, job.env)
-    cores = os.cpu_count() or 1
-    shards = 8
-    rays = pixels = n = 0
-    t0 = time.perf_counter()
-    while True:
-        frame = 2 + n // shards
-        _, cnt = orc.raytrace(osc, job.rt_uniforms(frame), job.width, job.height, n % shards, shards, BLOCK_ROWS)
-        rays += cnt["rays"]
-        pixels += cnt["pixels"]
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= shards * 512:
-            break
-    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{n} interleaved 1/{shards}-image shards of the same {job.width}x{job.height} {BOUNCES}-bounce "
-                      f"frames of the {job.workload} workload ({pixels} pixel jobs, {rays} rays, {dt:.1f} s, "
-                      f"OpenMP over {cores} threads; the oracle runs the reference's walk, without distance culling)"}
+    procs = max(orc.num_procs(), 1)
+    legs = sorted({t for t in (1, 4, 16, 64, procs) if t <= procs})
+    shards = 16
+    per_leg = budget_s / len(legs)
+    scaling, n = {}, 0
+    best = (0.0, 1, 0, 0, 0.0)
+    for threads in legs:
+        orc.set_num_threads(threads)
+        rays = pixels = calls = 0
+        t0 = time.perf_counter()
+        while True:
+            frame = 2 + n // shards
+            _, cnt = orc.raytrace(osc, job.rt_uniforms(frame), job.width, job.height, n % shards, shards, BLOCK_ROWS)
+            rays += cnt["rays"]
+            pixels += cnt["pixels"]
+            n += 1
+            calls += 1
+            dt = time.perf_counter() - t0
+            if dt >= per_leg:
+                break
+        rate = rays / dt / 1e6
+        scaling[str(threads)] = round(rate, 4)
+        if rate > best[0]:
+            best = (rate, threads, rays, pixels, dt)
+    orc.set_num_threads(procs)
+    rate, threads, rays, pixels, dt = best
+    return {"value": round(rate, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "thread_scaling_Mrays_per_s": scaling, "processors_visible": procs,
+            "sample": f"1/{shards}-image shards (8-row blocks, round robin) of the same {job.width}x{job.height} {BOUNCES}-bounce "
+                      f"frames of the {job.workload} workload, {per_leg:.1f} s per thread count ({', '.join(str(t) for t in legs)}); "
+                      f"best leg: {threads} threads, {pixels} pixel jobs, {rays} rays in {dt:.1f} s "
+                      "(the oracle runs the reference's walk, without distance culling)"}
 
 
 # ------------------------------------------------------------------------------------------
@@ -197,7 +242,7 @@ def inner_pmc(args):
     up in front of that predecessor: a deadlock, seen as passes that never finish.  The library
     therefore switches its launch gate off when a profiler is attached (mi3pt_create), and the
     child waits for every launch; per-launch counters are what a serialised run measures anyway."""
-    width, height = image_size(1, args.scaling)
+    width, height = FOREST_IMAGE if args.workload == "forest" else image_size(1, args.scaling)
     if args.image:
         width, height = (int(v) for v in args.image.lower().split("x"))
     job = Job(args.workload, width, height, variant=args.variant)
@@ -207,9 +252,12 @@ def inner_pmc(args):
     job.ctx.close()
 
 
-def collect_pmc(args, timed_launches, log):
+def collect_pmc(args, timed_launches, log, workload=None, steps=None, warmup=None, timeout=150):
     """Runs the PMC passes; returns {counter: mean per timed launch} (the last `timed_launches`
     dispatches of the raytrace kernel in each pass are the timed ones) or {} when unavailable."""
+    workload = workload or args.workload
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof) or timed_launches <= 0:
         return {}
@@ -220,12 +268,12 @@ def collect_pmc(args, timed_launches, log):
         for i, counters in enumerate(PMC_PASSES):
             d = os.path.join(base, f"pass{i}")
             cmd = [rocprof, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--",
-                   sys.executable, os.path.abspath(__file__), "--inner-pmc", "--steps", str(args.steps), "--warmup", str(args.warmup),
-                   "--workload", args.workload, "--scaling", args.scaling, "--variant", str(args.variant)]
-            if args.image:
+                   sys.executable, os.path.abspath(__file__), "--inner-pmc", "--steps", str(steps), "--warmup", str(warmup),
+                   "--workload", workload, "--scaling", args.scaling, "--variant", str(args.variant)]
+            if args.image and workload == args.workload:
                 cmd += ["--image", args.image]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
             except (subprocess.TimeoutExpired, OSError) as e:
                 log.append(f"pmc pass {counters}: {type(e).__name__}")
                 break                   # a pass that had to be killed: start nothing else on this GPU
@@ -262,49 +310,73 @@ def traffic_from_file(key):
 
 
 def roofline_block(m, pmc, source, num_cus):
-    """m: measurements of the timed run (see measure()); pmc: counter means per timed launch."""
+    """m: measurements of the timed run (see measure()); pmc: counter means per timed launch.
+    Rates are per launch over the launches' exclusive share of the GPU clock (kernel_ms_exclusive = span from the
+    first launch's start to the last one's end / launches: consecutive launches overlap at their tails, so the
+    sum of their own durations, kernel_ms, counts the overlap twice)."""
     kernel_ms = m["kernel_ms"]
+    t_ms = m["kernel_ms_exclusive"] if m["kernel_ms_exclusive"] > 0 else kernel_ms
+    t_s = t_ms * 1e-3
     alg_per_launch = algorithmic_bytes(m["counters"]) / max(m["launches"], 1)
-    alg_gbps = alg_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+    alg_gbps = alg_per_launch / t_s / 1e9 if t_s > 0 else None
     traffic = None
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
-    achieved = traffic / (kernel_ms * 1e-3) / 1e9 if traffic is not None and kernel_ms > 0 else None
+    hbm = traffic / t_s / 1e9 if traffic is not None and t_s > 0 else None
+    lane_peak = num_cus * 4 * SHADER_CLOCK_HZ / 2.0 * 64.0          # VALU lane-operations per second, all SIMDs
+    issue_frac = lane_util = lane_rate = None
+    if "SQ_INSTS_VALU" in pmc and t_s > 0:
+        issue_frac = pmc["SQ_INSTS_VALU"] / t_s / (lane_peak / 64.0)
+        if pmc.get("SQ_ACTIVE_INST_VALU"):
+            lane_util = pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
+            lane_rate = pmc["SQ_INSTS_VALU"] * 64.0 * lane_util / t_s
     block = {
-        "bound": "hbm", "achieved": round(achieved, 1) if achieved is not None else None, "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved is not None else None,
+        # the roof that binds (see real_bound): vector-ALU lane-operations
+        "bound": "valu", "achieved": round(lane_rate / 1e12, 3) if lane_rate is not None else None,
+        "peak": round(lane_peak / 1e12, 3), "unit": "Tlane-op/s",
+        "frac": round(lane_rate / lane_peak, 4) if lane_rate is not None else None,
+        "frac_rule": "SQ_INSTS_VALU x 64 x lane_utilisation / kernel time / (CUs x 4 SIMDs x 2.4 GHz / 2 x 64 lanes) = valu_issue_frac x lane_utilisation",
         "traffic": traffic, "traffic_source": source,
         "traffic_rule": "(2 x FETCH_SIZE + WRITE_SIZE) KB per launch, separate rocprofv3 --pmc passes, mean over the timed launches "
                         "(MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B); L2-to-fabric bytes, Infinity-Cache hits included",
+        "hbm": {"achieved": round(hbm, 1) if hbm is not None else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(hbm / HBM_PEAK_GBS, 4) if hbm is not None else None,
+                "peak_achievable": HBM_ACHIEVABLE_GBS,
+                "frac_of_achievable": round(hbm / HBM_ACHIEVABLE_GBS, 4) if hbm is not None else None},
         "kernel": m["kernel"], "kernel_ms": round(kernel_ms, 4), "kernel_ms_exclusive": round(m["kernel_ms_exclusive"], 4),
         "launches_timed": m["launches"], "frames_per_launch": m["frames_per_launch"],
         "kernel_ms_all_launches": round(m["kernel_ms_all"], 4), "launches_all": m["launches_all"],
-        "peak_achievable": HBM_ACHIEVABLE_GBS,
-        "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4) if achieved is not None else None,
         # what SURVEY.md 8(d) calls the achieved figure: bytes the algorithm touches (in the reference's layouts, from the
         # kernel's own counters) per second.  Served by L1 / L2 / Infinity Cache: not comparable with an HBM peak.
         "algorithmic_bytes_per_launch": int(alg_per_launch),
         "algorithmic_GBps": round(alg_gbps, 1) if alg_gbps is not None else None,
+        "traffic_over_algorithmic": round(traffic / alg_per_launch, 3) if traffic is not None and alg_per_launch > 0 else None,
         "bytes_per_ray": round(algorithmic_bytes(m["counters"]) / max(m["counters"]["rays"], 1), 1),
         "box_tests_per_ray": round(m["counters"]["box_tests"] / max(m["counters"]["rays"], 1), 2),
         "tri_tests_per_ray": round(m["counters"]["tri_tests"] / max(m["counters"]["rays"], 1), 2),
     }
-    if "SQ_INSTS_VALU" in pmc and kernel_ms > 0:
-        issue_peak = num_cus * 4 * SHADER_CLOCK_HZ / 2.0          # wave64 VALU instructions per second, all SIMDs
-        block["valu_issue_frac"] = round(pmc["SQ_INSTS_VALU"] / (kernel_ms * 1e-3) / issue_peak, 4)
+    if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc and t_s > 0:
+        req = pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]
+        l2 = req * 128.0 / t_s / 1e9
+        block["l2"] = {"achieved": round(l2, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2 / L2_PEAK_GBS, 4),
+                       "hit_rate": round(pmc["TCC_HIT_sum"] / req, 4) if req > 0 else None,
+                       "rule": "(TCC_HIT_sum + TCC_MISS_sum) x 128 B per launch / kernel time; hit rate = TCC_HIT / (TCC_HIT + TCC_MISS)"}
+    if issue_frac is not None:
+        block["valu_issue_frac"] = round(issue_frac, 4)
         block["valu_insts_per_launch"] = int(pmc["SQ_INSTS_VALU"])
-        if pmc.get("SQ_ACTIVE_INST_VALU"):
-            block["lane_utilisation"] = round(pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]), 4)
+        if lane_util is not None:
+            block["lane_utilisation"] = round(lane_util, 4)
         if pmc.get("SQ_WAVE_CYCLES"):
             wc = pmc["SQ_WAVE_CYCLES"]
             block["wave_cycles"] = {"issuing": round(pmc.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3),
                                     "waiting_for_memory": round(pmc.get("SQ_WAIT_ANY", 0.0) / wc, 3),
                                     "issue_stalled": round(pmc.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3)}
         block["pmc_counters"] = {k: round(v, 1) for k, v in sorted(pmc.items())}
-        block["real_bound"] = ("per-wave latency: each step is a dependent chain of one LDS and one L2 / fabric round trip (a divergent "
-                               "64- or 128-B packet gather) and a few hundred instructions that a single wave issues at one per 4 cycles, "
-                               "with 4 waves per SIMD (128 VGPRs) to overlap them; VALU issue x lane utilisation is the fraction of the "
-                               "machine's lane-op rate in use")
+        block["real_bound"] = ("vector-ALU lane-operations, reached through per-wave latency: each step is a dependent chain of one LDS and "
+                               "one L2 / fabric round trip (a divergent 128-B packet gather) and a few hundred instructions that a single "
+                               "wave issues at one per 4 cycles, with 5 waves per SIMD (96 VGPRs) to overlap them; frac = VALU issue x lane "
+                               "utilisation is the fraction of the machine's lane-op rate in use; HBM-side traffic and L2 requests are "
+                               "reported beside it (hbm, l2) and are not what the kernel runs out of on a scene that fits the Infinity Cache")
     return block
 
 
@@ -313,12 +385,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)      # x 16 frames = 256 spp (BASELINE.json configs[2])
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="dragon", choices=["demo", "dragon"])
+    ap.add_argument("--workload", default="dragon", choices=["demo", "dragon", "closeup", "forest"])
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (children of this process)")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary (demo scene) measurement")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (demo scene, close-up camera)")
+    ap.add_argument("--no-forest", action="store_true", help="skip the forest leg (config 5's scene: ~1 min of scene build, render and counter passes)")
     ap.add_argument("--image", default=None, help="WxH override (experiments only)")
     ap.add_argument("--tile", default=None, help="R/N: render only rank R's share of an N-way tile split on this one GPU, no gather "
                                                  "(experiments only: profiles/scaling_model.py predicts the multi-GPU curve from it)")
@@ -365,9 +438,10 @@ def main():
         dist.barrier()
     capi.load_library()
 
-    width, height = image_size(world, args.scaling)
+    base_width, base_height = FOREST_IMAGE if args.workload == "forest" else image_size(world, args.scaling)
     if args.image:
-        width, height = (int(v) for v in args.image.lower().split("x"))
+        base_width, base_height = (int(v) for v in args.image.lower().split("x"))
+    width, height = base_width, base_height
     red_dev = "cpu" if rehearsal else "cuda"
 
     def sync_all():
@@ -375,9 +449,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(workload, steps, warmup, gather):
+    def measure(workload, steps, warmup, gather, size=None):
         """The timed job for one workload: `warmup` untimed steps, then EXACTLY `steps` steps of 16 frames
         (+ the one gather when N > 1) between barrier + synchronize on both sides."""
+        width, height = size or (base_width, base_height)
         stream = torch.cuda.Stream()       # the context's main stream
         tile_rank, tile_world = (int(v) for v in args.tile.split("/")) if args.tile else (rank, world)
         job = Job(workload, width, height, tile_rank, tile_world, local_rank, args.variant, stream.cuda_stream)
@@ -440,10 +515,13 @@ def main():
              # (the warm-up's launches can be shorter: W steps need not be a whole number of launches)
              "kernel_ms_all": (launch_ms_total + warm_ms) / max(launches + warm_launches, 1), "launches_all": int(launches + warm_launches),
              "frames_per_launch": round(launch_frames / max(launches, 1), 2),
-             "kernel": (lambda v: {10: "k_raytrace_sm<false,false,true,true,true,true,false>", 9: "k_raytrace_sm<false,false,true,true,false,true,false>"}
+             "variant": ctx.active_variant(),
+             "kernel": (lambda v: {12: "k_raytrace_sm<false,false,true,true,true,true,false,true,true>", 11: "k_raytrace_sm<false,false,true,true,true,true,false,true,false>",
+                                   10: "k_raytrace_sm<false,false,true,true,true,true,false>", 9: "k_raytrace_sm<false,false,true,true,false,true,false>"}
                         .get(v, f"raytrace kernel variant {v}") + " (persistent raytrace kernel: per-lane state machine, deferred-leaf walk"
-                        + (" with exact-image distance culling" if v >= 9 else "") + (" on 4-ary wide packets" if v == 10 else "")
-                        + ("; one-sample-per-frame specialisation" if v >= 9 else "") + "; batched frames)")(ctx.active_variant())}
+                        + (" with exact-image distance culling" if v >= 9 else "") + (" on 4-ary wide packets" if v >= 10 else "")
+                        + (", filtered slab test" if v >= 11 else "") + (", one-axis culling condition" if v == 12 else "")
+                        + ("; one-sample-per-frame specialisation, five waves per SIMD" if v >= 9 else "") + "; batched frames)")(ctx.active_variant())}
         ctx.bind_accumulation(None, 0)
         return m
 
@@ -472,15 +550,28 @@ def main():
         }
     job.ctx.close()
 
-    # ---- secondary workload (N = 1): BASELINE.json configs[1], the default demo mesh
-    if world == 1 and args.workload != "demo" and not args.no_also and not args.tile:
-        a = measure("demo", args.steps, args.warmup, gather=False)
-        out["also"] = {"demo": {"value": round(a["total"]["rays"] / a["elapsed"] / 1e6, 3), "unit": "Mrays/s",
-                                "ms_per_step": round(a["elapsed"] * 1e3 / max(args.steps, 1), 4),
-                                "workload": workload_name("demo", a["job"].sc) + f", {width}x{height}, {BOUNCES} bounces",
-                                "kernel_ms": round(a["kernel_ms"], 4), "frames_per_launch": a["frames_per_launch"],
-                                "box_tests_per_ray": round(a["counters"]["box_tests"] / max(a["counters"]["rays"], 1), 2)}}
-        a["job"].ctx.close()
+    # ---- secondary workloads (N = 1): BASELINE.json configs[1], the default demo mesh; and the headline scene seen from
+    # close up (the model fills the frame: deep walks on every pixel, next to the sky-and-floor-dominated stated view)
+    if world == 1 and args.workload == "dragon" and not args.no_also and not args.tile:
+        out["also"] = {}
+        for name in ("demo", "closeup"):
+            a = measure(name, args.steps, args.warmup, gather=False)
+            c = a["counters"]
+            out["also"][name] = {"value": round(a["total"]["rays"] / a["elapsed"] / 1e6, 3), "unit": "Mrays/s",
+                                 "ms_per_step": round(a["elapsed"] * 1e3 / max(args.steps, 1), 4),
+                                 "workload": workload_name(name, a["job"].sc) + f", {width}x{height}, {BOUNCES} bounces",
+                                 "kernel_ms": round(a["kernel_ms"], 4), "frames_per_launch": a["frames_per_launch"], "variant": a["variant"],
+                                 "rays_per_pixel": round(c["rays"] / max(c["pixels"], 1), 2),
+                                 "box_tests_per_ray": round(c["box_tests"] / max(c["rays"], 1), 2),
+                                 "tri_tests_per_ray": round(c["tri_tests"] / max(c["rays"], 1), 2)}
+            a["job"].ctx.close()
+
+    # ---- the forest leg (N = 1): config 5's scene -- 10 M triangles, 2.08 GB, the only one larger than the 256 MiB
+    # Infinity Cache, i.e. the one on which "HBM GB/s against peak" is the question -- at 1920x1080, with its own counter passes
+    forest = None
+    if world == 1 and args.workload == "dragon" and not args.no_forest and not args.tile and not args.image:
+        forest = measure("forest", FOREST_STEPS, FOREST_WARMUP, gather=False, size=FOREST_IMAGE)
+        forest["job"].ctx.close()
 
     if rank == 0:
         # ---- roofline: counter passes of this very command line (children; the timed job is over)
@@ -503,6 +594,30 @@ def main():
         out["roofline"] = roofline_block(m, pmc, source, capi_num_cus())
         if log:
             out["roofline"]["pmc_log"] = log
+        if forest is not None:
+            flog, fpmc, fsource = [], {}, None
+            if not args.no_pmc and not under_profiler():
+                try:
+                    fpmc = collect_pmc(args, forest["launches"], flog, workload="forest", steps=FOREST_STEPS, warmup=FOREST_WARMUP, timeout=240)
+                except Exception as e:          # noqa: BLE001
+                    flog.append(f"pmc: {type(e).__name__}: {e}")
+                if fpmc:
+                    fsource = "live: rocprofv3 --pmc child runs (bench.py --inner-pmc --workload forest), mean over the timed launches"
+            if "FETCH_SIZE" not in fpmc or "WRITE_SIZE" not in fpmc:
+                e = traffic_from_file({"workload": "forest", "image": list(FOREST_IMAGE), "frames_per_launch": forest["frames_per_launch"],
+                                       "variant": args.variant, "n_gpus": 1})
+                if e:
+                    fpmc = dict(e["counters"])
+                    fsource = "profiles/traffic.json entry for this launch shape (" + e.get("source", "") + ")"
+            fj = forest["job"]
+            out["forest"] = {"value": round(forest["total"]["rays"] / forest["elapsed"] / 1e6, 3), "unit": "Mrays/s",
+                             "ms_per_step": round(forest["elapsed"] * 1e3 / FOREST_STEPS, 4), "steps": FOREST_STEPS, "warmup": FOREST_WARMUP,
+                             "workload": workload_name("forest", fj.sc) + f", {FOREST_IMAGE[0]}x{FOREST_IMAGE[1]}, {BOUNCES} bounces "
+                                         "(BASELINE.json config 5's scene; its own image, 3840x2160 on 8 GPUs, is a parity-test case)",
+                             "scene_bytes": int(len(fj.sc.triangles) * 112 + len(fj.sc.nodes) * 48),
+                             "roofline": roofline_block(forest, fpmc, fsource, capi_num_cus())}
+            if flog:
+                out["forest"]["roofline"]["pmc_log"] = flog
         if args.tile:
             out["config"]["parallelism"] = f"EXPERIMENT: rank {args.tile} of a tile split rendered alone on one GPU, no gather"
         if world == 1 and not args.no_cpu_baseline and not args.tile:

@@ -467,6 +467,11 @@ int orc_tile_local_rows(int tex_h, int rank, int nranks, int block_rows)
     return n;
 }
 
+/* Thread control for the timing harness (bench.py cpu_baseline: the thread-scaling figures). */
+void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_max_threads(void) { return omp_get_max_threads(); }
+int orc_num_procs(void) { return omp_get_num_procs(); }
+
 /*
  * The raytrace pass.  `out` is this rank's compact image: local_rows x tex_w RGBA
  * floats (local_rows = orc_tile_local_rows(tex_h, ...); rank 0 of 1 => the whole

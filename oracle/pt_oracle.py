@@ -89,6 +89,20 @@ def tile_local_rows(h, rank, nranks, block_rows):
     return lib().orc_tile_local_rows(h, rank, nranks, block_rows)
 
 
+def set_num_threads(n):
+    """OpenMP threads of the following passes (bench.py's thread-scaling baseline)."""
+    lib().orc_set_num_threads(int(n))
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
+def num_procs():
+    """Processors OpenMP sees (its affinity mask; a CPU quota imposed from outside is not visible here)."""
+    return int(lib().orc_num_procs())
+
+
 def raytrace(scene, uniforms96, tex_w, tex_h, rank=0, nranks=1, block_rows=8, store_f16=False, out=None):
     """One raytrace pass.  Returns (image[local_rows, tex_w, 4], counters dict)."""
     rows = tile_local_rows(tex_h, rank, nranks, block_rows)

@@ -24,7 +24,7 @@ def test_single_gpu_line():
     the ~870k-triangle scene the target is quoted on; the roofline fraction comes from counter passes
     of this very command line and is a fraction; the launch statistics are consistent with the wall clock."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+                       capture_output=True, text=True, timeout=1100, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r.stdout)
     assert j["metric"] == "Mrays/s" and j["unit"] == "Mrays/s" and j["higher_is_better"] is True
@@ -34,7 +34,8 @@ def test_single_gpu_line():
     assert j["config"]["triangles"] > 800_000 and "dragon-class" in j["config"]["workload"] and j["config"]["frames_per_step"] == 16
     assert j["value"] > 1000 and abs(j["value"] - j["config"]["rays_per_step"] / j["ms_per_step"] / 1e3) / j["value"] < 0.01
     roof = j["roofline"]
-    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    # the roof that binds: vector-ALU lane-operations (round-2 verdict: not "hbm" for a scene that fits the Infinity Cache)
+    assert roof["bound"] == "valu" and roof["unit"] == "Tlane-op/s" and abs(roof["peak"] - 78.643) < 0.01
     assert roof["kernel_ms"] > 0 and roof["launches_timed"] == 5 and roof["frames_per_launch"] == 64.0
     # the non-overlapped kernel time per frame cannot exceed the wall clock per frame
     assert roof["kernel_ms_exclusive"] / 4 <= j["ms_per_step"] * 1.02          # (one launch per four steps)
@@ -42,14 +43,29 @@ def test_single_gpu_line():
     # the average over every launch of the process (what `rocprofv3 --stats` averages): the warm-up's 80 frames are a
     # 64- and a 16-frame launch
     assert roof["launches_all"] == 7 and 0 < roof["kernel_ms_all_launches"] < roof["kernel_ms"]
-    # measured by this run (rocprofv3 is on the box): HBM-side traffic, a real fraction, the issue figures
-    assert roof["traffic"] is not None and roof["traffic"] > 0, roof.get("pmc_log")
-    assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # measured by this run (rocprofv3 is on the box): the issue figures, HBM-side traffic, L2 requests -- all fractions
+    assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 2e-3
     assert 0 < roof["valu_issue_frac"] < 1 and 0 < roof["lane_utilisation"] <= 1
+    assert abs(roof["frac"] - roof["valu_issue_frac"] * roof["lane_utilisation"]) < 2e-3
+    assert roof["traffic"] is not None and roof["traffic"] > 0, roof.get("pmc_log")
+    assert roof["hbm"]["peak"] == 8000.0 and 0 < roof["hbm"]["frac"] <= 1
+    assert abs(roof["hbm"]["achieved"] - roof["traffic"] / (roof["kernel_ms_exclusive"] * 1e-3) / 1e9) / roof["hbm"]["achieved"] < 1e-3
+    assert 0 < roof["l2"]["frac"] <= 1 and 0 < roof["l2"]["hit_rate"] < 1
     assert roof["algorithmic_GBps"] > 0 and roof["box_tests_per_ray"] > 1
     assert j["also"]["demo"]["value"] > 1000
+    # the same scene from close up: every pixel's walk goes deep into the 870 k-triangle tree (the stated view is dominated
+    # by sky and floor segments: 16 box tests per ray there, ~65 here)
+    close = j["also"]["closeup"]
+    assert close["value"] > 1000 and close["rays_per_pixel"] > 2.0 and close["box_tests_per_ray"] > 2 * roof["box_tests_per_ray"]
+    # config 5's scene, the one larger than the Infinity Cache: its own counter passes
+    forest = j["forest"]
+    assert forest["value"] > 100 and forest["scene_bytes"] > 1.5e9 and "forest" in forest["workload"]
+    fr = forest["roofline"]
+    assert fr["traffic"] is not None and fr["traffic"] > 0, fr.get("pmc_log")
+    assert 0 < fr["hbm"]["frac"] <= 1 and 0 < fr["frac"] <= 1 and 0 < fr["l2"]["hit_rate"] < 1
     cpu = j["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "Mrays/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert "1" in cpu["thread_scaling_Mrays_per_s"] and cpu["value"] == max(cpu["thread_scaling_Mrays_per_s"].values())
 
 
 @pytest.mark.parametrize("scaling,image", [("strong", [1920, 1080]), ("weak", [1920, 2160])])
