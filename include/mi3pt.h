@@ -129,6 +129,24 @@ int mi3pt_device_name(int device, char *name, size_t capacity);
  * destroy waits for submitted work first (renderer.ts:418-429). ---- */
 int mi3pt_create(int device, mi3pt_ctx **out_ctx);
 int mi3pt_destroy(mi3pt_ctx *ctx);
+/* Renderer.create() over several GPUs of one node (the reference knows one adapter and one device, renderer.ts:491-533;
+ * SURVEY.md 8e): the returned handle is used with the SAME entry points as a single-device context and renders the
+ * same bits.  Behind it: one member context per listed device -- member i renders tile i of n (block_rows-row blocks
+ * dealt round robin), every upload is replicated, nothing is exchanged per frame -- and a presenting context on
+ * devices[0] that holds the whole image.  Reading the accumulation image or the canvas GATHERS: one strided
+ * device-to-device copy per member (peer DMA over xGMI), de-interleaved on the way; no host staging, no collective
+ * library.  Differences from a single context, all following from "the image is whole only after the gather":
+ *   - mi3pt_read_texture / mi3pt_write_texture move WHOLE images (height x width), whatever the split;
+ *   - the fullscreen pass runs on the gathered image, so a group always presents lazily: a FULLSCREEN submit is
+ *     remembered and performed when the canvas is read (MI3PT_PRESENT_LATEST whatever mi3pt_set_present_mode says);
+ *   - mi3pt_set_tile, mi3pt_set_stream and mi3pt_bind_accumulation are refused (MI3PT_ERR_STATE);
+ *   - counters are the members' sums, pass times the slowest member's; the debug probes address member 0.
+ * A device may be listed more than once (several members on one GPU: how the tests run it on a one-GPU box). */
+int mi3pt_create_group(const int *devices, int ndevices, int block_rows, mi3pt_ctx **out_ctx);
+/* Members of a group handle (1 for a plain context) and the member contexts themselves (index -1: the presenting
+ * context), e.g. for per-device launch statistics.  They belong to the group: never destroy or resize them. */
+int mi3pt_group_size(mi3pt_ctx *ctx, int *members);
+int mi3pt_group_member(mi3pt_ctx *ctx, int index, mi3pt_ctx **member);
 
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
  * context's own; NULL restores the internal stream. */

@@ -76,6 +76,7 @@ struct mi3pt_ctx {
     // subtree, left subtree) and triangles in leaf-visiting order: a pure relabelling.
     int layout = 0;
     bool layout_dirty = false;      // the relabelling still has to be applied to what was uploaded
+    struct GroupState *group = nullptr;   // mi3pt_create_group: this handle fans every call out to member contexts (end of this file)
     bool tree_proper = false;       // mi3pt_upload_bvh: every node reached once, one leaf per triangle, the 64-entry abort cannot fire
     bool layout_active = false;     // the device holds relabelled packets / triangles
     void *d_tris_perm = nullptr;    // 112-B records in the relabelled order (the uploaded order stays in d_tris)
@@ -193,6 +194,37 @@ static int require_ctx(mi3pt_ctx *ctx)
 }
 
 static int require_idle(mi3pt_ctx *ctx);      // require_ctx + flush of the deferred frame queue (below)
+
+// ---- device groups (mi3pt_create_group; implementation at the end of this file).  A group handle is an mi3pt_ctx whose
+// `group` member is set: every entry point below first hands such a handle to its group_* counterpart.
+struct GroupState;
+#define PT_GROUP(ctx, call) do { if ((ctx) && (ctx)->group) return (call); } while (0)
+static mi3pt_ctx *group_member0(mi3pt_ctx *g);
+static int group_destroy(mi3pt_ctx *g);
+static int group_resize(mi3pt_ctx *g, int width, int height);
+static int group_reset(mi3pt_ctx *g);
+static int group_set_uniforms(mi3pt_ctx *g, int pass, const void *bytes, size_t nbytes);
+static int group_submit_frames(mi3pt_ctx *g, unsigned pass_mask, uint32_t count);
+static int group_flush(mi3pt_ctx *g);
+static int group_sync(mi3pt_ctx *g);
+static int group_read_texture(mi3pt_ctx *g, int which, float *dst, size_t nfloats);
+static int group_write_texture(mi3pt_ctx *g, int which, const float *src, size_t nfloats);
+static int group_read_canvas(mi3pt_ctx *g, uint8_t *dst, size_t nbytes);
+static int group_accumulation_ptr(mi3pt_ctx *g, void **dev_ptr, size_t *nbytes);
+static int group_pass_time(mi3pt_ctx *g, int pass, float *us);
+static int group_launch_stats(mi3pt_ctx *g, int reset, double *total_ms, uint64_t *launches, uint64_t *frames);
+static int group_launch_span(mi3pt_ctx *g, double *span_ms);
+static int group_counters(mi3pt_ctx *g, uint64_t *out);
+static int group_unsupported(const char *what);
+// one call applied to every member (and, where marked, to the presenting context too)
+#define PT_GROUP_ALL(ctx, with_present, ...)                                                                              \
+    do {                                                                                                                  \
+        if ((ctx) && (ctx)->group) {                                                                                      \
+            auto fn_ = [&](mi3pt_ctx *m) -> int { return __VA_ARGS__; };                                                  \
+            return group_each((ctx), (with_present), fn_);                                                                \
+        }                                                                                                                 \
+    } while (0)
+template <class F> static int group_each(mi3pt_ctx *g, bool with_present, F fn);
 static int batch_limit(const mi3pt_ctx *ctx, int nranks);
 static int flush_pending(mi3pt_ctx *ctx);
 static int settle_canvas(mi3pt_ctx *ctx);
@@ -354,6 +386,7 @@ static void free_textures(mi3pt_ctx *ctx)
 
 extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
 {
+    PT_GROUP(ctx, group_destroy(ctx));
     if (!ctx) return MI3PT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -384,6 +417,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
 
 extern "C" int mi3pt_set_stream(mi3pt_ctx *ctx, void *hip_stream)
 {
+    PT_GROUP(ctx, group_unsupported("mi3pt_set_stream: a device group runs on its members' own streams"));
     if (int rc = require_idle(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
@@ -394,6 +428,7 @@ extern "C" int mi3pt_set_stream(mi3pt_ctx *ctx, void *hip_stream)
 
 extern "C" int mi3pt_set_storage(mi3pt_ctx *ctx, int storage)
 {
+    PT_GROUP_ALL(ctx, true, mi3pt_set_storage(m, storage));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     if (storage != MI3PT_STORAGE_F32 && storage != MI3PT_STORAGE_F16)
         return pt_set_error(MI3PT_ERR_INVALID, "storage must be MI3PT_STORAGE_F32 or MI3PT_STORAGE_F16");
@@ -404,6 +439,7 @@ extern "C" int mi3pt_set_storage(mi3pt_ctx *ctx, int storage)
 
 extern "C" int mi3pt_set_env_sampling(mi3pt_ctx *ctx, int enabled)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_set_env_sampling(m, enabled));
     if (int rc = require_idle(ctx)) return rc;
     if (enabled && !ctx->d_cdf)
         return pt_set_error(MI3PT_ERR_STATE, "environment CDF texture has not been uploaded (mi3pt_upload_environment_cdf)");
@@ -413,6 +449,7 @@ extern "C" int mi3pt_set_env_sampling(mi3pt_ctx *ctx, int enabled)
 
 extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_set_kernel_variant(m, variant));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     if (variant < 0 || variant > 12) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..12");
     if (int rc = require_idle(ctx)) return rc;
@@ -438,6 +475,7 @@ static void recompute_batch_cap(mi3pt_ctx *ctx)
 // Scheduling options (include/mi3pt.h: mi3pt_option): how the same work is cut into launches, steps and jobs.
 extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_debug_set_option(m, option, value));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     if (int rc = require_idle(ctx)) return rc;
     switch (option) {
@@ -478,6 +516,7 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
 
 extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
 {
+    PT_GROUP(ctx, mi3pt_debug_get_option(group_member0(ctx), option, value));
     if (!ctx || !value) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     switch (option) {
     case MI3PT_OPT_WALK_MIN: *value = ctx->walk_min; break;
@@ -507,6 +546,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
 // selected one, or what it falls back to when the scene does not admit it.
 extern "C" int mi3pt_debug_active_variant(mi3pt_ctx *ctx, int *variant)
 {
+    PT_GROUP(ctx, mi3pt_debug_active_variant(group_member0(ctx), variant));
     if (!ctx || !variant) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (int rc = require_idle(ctx)) return rc;
     if (int rc = check_scene(ctx)) return rc;
@@ -518,6 +558,7 @@ extern "C" int mi3pt_debug_active_variant(mi3pt_ctx *ctx, int *variant)
 
 extern "C" int mi3pt_set_pipelining(mi3pt_ctx *ctx, int enabled)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_set_pipelining(m, enabled));
     if (int rc = require_idle(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->pipeline = enabled != 0;
@@ -527,6 +568,7 @@ extern "C" int mi3pt_set_pipelining(mi3pt_ctx *ctx, int enabled)
 
 extern "C" int mi3pt_set_tile(mi3pt_ctx *ctx, int rank, int nranks, int block_rows)
 {
+    PT_GROUP(ctx, group_unsupported("mi3pt_set_tile: a device group deals the image's row blocks to its members itself"));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     if (nranks <= 0 || rank < 0 || rank >= nranks || block_rows <= 0)
         return pt_set_error(MI3PT_ERR_INVALID, "bad tile: need 0 <= rank < nranks, block_rows > 0");
@@ -554,6 +596,7 @@ static int replace_buffer(mi3pt_ctx *ctx, void **dst, const void *bytes, size_t 
 
 extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_upload_triangles(m, bytes, nbytes));
     if (int rc = require_idle(ctx)) return rc;
     if (!bytes || nbytes == 0 || nbytes % MI3PT_TRIANGLE_STRIDE)
         return pt_set_error(MI3PT_ERR_INVALID, "triangle bytes must be a non-zero multiple of 112");
@@ -595,6 +638,7 @@ extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t 
 
 extern "C" int mi3pt_upload_materials(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_upload_materials(m, bytes, nbytes));
     if (int rc = require_idle(ctx)) return rc;
     if (!bytes || nbytes == 0 || nbytes % MI3PT_MATERIAL_STRIDE)
         return pt_set_error(MI3PT_ERR_INVALID, "material bytes must be a non-zero multiple of 64");
@@ -660,6 +704,7 @@ static void build_packets(const uint8_t *src, size_t n, const std::vector<uint32
 
 extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_upload_bvh(m, bytes, nbytes));
     if (int rc = require_idle(ctx)) return rc;
     if (!bytes || nbytes == 0 || nbytes % MI3PT_BVHNODE_STRIDE)
         return pt_set_error(MI3PT_ERR_INVALID, "BVH bytes must be a non-zero multiple of 48");
@@ -796,12 +841,14 @@ static int upload_env_like(mi3pt_ctx *ctx, void *dst, const float *rgba, int wid
 
 extern "C" int mi3pt_upload_environment(mi3pt_ctx *ctx, const float *rgba, int width, int height)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_upload_environment(m, rgba, width, height));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     return upload_env_like(ctx, ctx->d_env, rgba, width, height);
 }
 
 extern "C" int mi3pt_upload_environment_cdf(mi3pt_ctx *ctx, const float *rgba, int width, int height)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_upload_environment_cdf(m, rgba, width, height));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     return upload_env_like(ctx, ctx->d_cdf, rgba, width, height);
 }
@@ -846,6 +893,7 @@ static int batch_limit(const mi3pt_ctx *ctx, int nranks)
 
 extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
 {
+    PT_GROUP(ctx, group_resize(ctx, width, height));
     if (int rc = require_idle(ctx)) return rc;
     if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
         return pt_set_error(MI3PT_ERR_INVALID, "width/height must be in [1, 32768]");
@@ -893,6 +941,7 @@ extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
 
 extern "C" int mi3pt_reset(mi3pt_ctx *ctx)
 {
+    PT_GROUP(ctx, group_reset(ctx));
     if (int rc = require_idle(ctx)) return rc;
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "reset before resize");
     return zero_textures(ctx);
@@ -900,6 +949,7 @@ extern "C" int mi3pt_reset(mi3pt_ctx *ctx)
 
 extern "C" int mi3pt_set_uniforms(mi3pt_ctx *ctx, int pass, const void *bytes, size_t nbytes)
 {
+    PT_GROUP(ctx, group_set_uniforms(ctx, pass, bytes, nbytes));
     if (!ctx || !bytes) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     switch (pass) {
     case MI3PT_PASS_RAYTRACE:
@@ -1032,6 +1082,7 @@ static int prepare_layout(mi3pt_ctx *ctx)
 
 extern "C" int mi3pt_debug_set_packet_layout(mi3pt_ctx *ctx, int layout)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_debug_set_packet_layout(m, layout));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     if (layout != 0 && layout != 1) return pt_set_error(MI3PT_ERR_INVALID, "layout must be 0 (breadth-first) or 1 (visiting order)");
     if (int rc = require_idle(ctx)) return rc;
@@ -1355,6 +1406,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
 
 extern "C" int mi3pt_set_present_mode(mi3pt_ctx *ctx, int mode)
 {
+    PT_GROUP(ctx, (mode == MI3PT_PRESENT_EXACT || mode == MI3PT_PRESENT_LATEST) ? MI3PT_OK : pt_set_error(MI3PT_ERR_INVALID, "mode must be MI3PT_PRESENT_EXACT or MI3PT_PRESENT_LATEST"));      // (a group always presents lazily: see group_submit_frames)
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     if (mode != MI3PT_PRESENT_EXACT && mode != MI3PT_PRESENT_LATEST)
         return pt_set_error(MI3PT_ERR_INVALID, "mode must be MI3PT_PRESENT_EXACT or MI3PT_PRESENT_LATEST");
@@ -1630,6 +1682,7 @@ static int run_fullscreen(mi3pt_ctx *ctx)
 
 extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
 {
+    PT_GROUP(ctx, group_submit_frames(ctx, pass_mask, 1));
     if (int rc = require_ctx(ctx)) return rc;
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "submit before resize");
     if (pass_mask & ~(MI3PT_SUBMIT_RAYTRACE | MI3PT_SUBMIT_ACCUMULATE | MI3PT_SUBMIT_FULLSCREEN))
@@ -1713,6 +1766,7 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
 // current + i, and both blocks are left at current + count, ready for the next call.
 extern "C" int mi3pt_submit_frames(mi3pt_ctx *ctx, unsigned pass_mask, uint32_t count)
 {
+    PT_GROUP(ctx, group_submit_frames(ctx, pass_mask, count));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     for (uint32_t i = 0; i < count; i++) {
         if (int rc = mi3pt_submit(ctx, pass_mask)) return rc;
@@ -1731,10 +1785,15 @@ static int settle_canvas(mi3pt_ctx *ctx)
     return run_fullscreen(ctx);
 }
 
-extern "C" int mi3pt_flush(mi3pt_ctx *ctx) { return require_idle(ctx); }
+extern "C" int mi3pt_flush(mi3pt_ctx *ctx)
+{
+    PT_GROUP(ctx, group_flush(ctx));
+    return require_idle(ctx);
+}
 
 extern "C" int mi3pt_batch_capacity(mi3pt_ctx *ctx, int *frames)
 {
+    PT_GROUP(ctx, mi3pt_batch_capacity(group_member0(ctx), frames));
     if (!ctx || !frames) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "no textures before resize");
     *frames = ctx->pipeline ? ctx->batch_cap : 1;
@@ -1743,6 +1802,7 @@ extern "C" int mi3pt_batch_capacity(mi3pt_ctx *ctx, int *frames)
 
 extern "C" int mi3pt_sync(mi3pt_ctx *ctx)
 {
+    PT_GROUP(ctx, group_sync(ctx));
     if (int rc = require_idle(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MI3PT_OK;
@@ -1750,6 +1810,7 @@ extern "C" int mi3pt_sync(mi3pt_ctx *ctx)
 
 extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t nfloats)
 {
+    PT_GROUP(ctx, group_read_texture(ctx, which, dst, nfloats));
     if (int rc = require_idle(ctx)) return rc;
     if (!dst) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "read before resize");
@@ -1784,6 +1845,7 @@ extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t 
 // context for the fullscreen pass.
 extern "C" int mi3pt_write_texture(mi3pt_ctx *ctx, int which, const float *src, size_t nfloats)
 {
+    PT_GROUP(ctx, group_write_texture(ctx, which, src, nfloats));
     if (int rc = require_idle(ctx)) return rc;
     if (!src) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "write before resize");
@@ -1803,6 +1865,7 @@ extern "C" int mi3pt_write_texture(mi3pt_ctx *ctx, int which, const float *src, 
 
 extern "C" int mi3pt_read_canvas_rgba8(mi3pt_ctx *ctx, uint8_t *dst, size_t nbytes)
 {
+    PT_GROUP(ctx, group_read_canvas(ctx, dst, nbytes));
     if (int rc = require_idle(ctx)) return rc;
     if (!dst) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "read before resize");
@@ -1816,6 +1879,7 @@ extern "C" int mi3pt_read_canvas_rgba8(mi3pt_ctx *ctx, uint8_t *dst, size_t nbyt
 
 extern "C" int mi3pt_accumulation_device_ptr(mi3pt_ctx *ctx, void **dev_ptr, size_t *nbytes)
 {
+    PT_GROUP(ctx, group_accumulation_ptr(ctx, dev_ptr, nbytes));
     if (!ctx || !dev_ptr) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "no textures before resize");
     if (int rc = require_idle(ctx)) return rc;
@@ -1826,6 +1890,7 @@ extern "C" int mi3pt_accumulation_device_ptr(mi3pt_ctx *ctx, void **dev_ptr, siz
 
 extern "C" int mi3pt_bind_accumulation(mi3pt_ctx *ctx, void *dev_ptr, size_t nbytes)
 {
+    PT_GROUP(ctx, group_unsupported("mi3pt_bind_accumulation: a device group gathers into its own image (mi3pt_accumulation_device_ptr)"));
     if (int rc = require_idle(ctx)) return rc;
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "bind before resize");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1845,6 +1910,7 @@ extern "C" int mi3pt_bind_accumulation(mi3pt_ctx *ctx, void *dev_ptr, size_t nby
 
 extern "C" int mi3pt_enable_timing(mi3pt_ctx *ctx, int enabled)
 {
+    PT_GROUP_ALL(ctx, true, mi3pt_enable_timing(m, enabled));
     if (int rc = require_idle(ctx)) return rc;
     ctx->timing = enabled != 0;
     return MI3PT_OK;
@@ -1852,6 +1918,7 @@ extern "C" int mi3pt_enable_timing(mi3pt_ctx *ctx, int enabled)
 
 extern "C" int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds)
 {
+    PT_GROUP(ctx, group_pass_time(ctx, pass, microseconds));
     if (int rc = require_idle(ctx)) return rc;
     if (!microseconds || pass < 0 || pass > 2) return pt_set_error(MI3PT_ERR_INVALID, "bad argument");
     if (pass == MI3PT_PASS_RAYTRACE && !ctx->ev_recorded[0] && (ctx->ev_rt_pending[0] || ctx->ev_rt_pending[1] || ctx->rt_launches)) {
@@ -1875,6 +1942,7 @@ extern "C" int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds)
 extern "C" int mi3pt_raytrace_launch_stats(mi3pt_ctx *ctx, int reset, double *total_ms, uint64_t *launches,
                                            uint64_t *frames)
 {
+    PT_GROUP(ctx, group_launch_stats(ctx, reset, total_ms, launches, frames));
     if (int rc = require_idle(ctx)) return rc;
     if (int rc = collect_rt_time(ctx, ctx->ev_rt_newest ^ 1)) return rc;
     if (int rc = collect_rt_time(ctx, ctx->ev_rt_newest)) return rc;
@@ -1892,6 +1960,7 @@ extern "C" int mi3pt_raytrace_launch_stats(mi3pt_ctx *ctx, int reset, double *to
 // launch costs.
 extern "C" int mi3pt_raytrace_launch_span(mi3pt_ctx *ctx, double *span_ms)
 {
+    PT_GROUP(ctx, group_launch_span(ctx, span_ms));
     if (int rc = require_idle(ctx)) return rc;
     if (!span_ms) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     *span_ms = 0.0;
@@ -1908,6 +1977,7 @@ extern "C" int mi3pt_raytrace_launch_span(mi3pt_ctx *ctx, double *span_ms)
 
 extern "C" int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT])
 {
+    PT_GROUP(ctx, group_counters(ctx, out));
     if (int rc = require_idle(ctx)) return rc;
     if (!out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     for (int k = 0; k < MI3PT_CNT_COUNT; k++) out[k] = 0;
@@ -1922,6 +1992,7 @@ extern "C" int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT])
 
 extern "C" int mi3pt_reset_counters(mi3pt_ctx *ctx)
 {
+    PT_GROUP_ALL(ctx, false, mi3pt_reset_counters(m));
     if (int rc = require_idle(ctx)) return rc;
     if (ctx->nblocks == 0) return MI3PT_OK;
     HIP_TRY(hipMemsetAsync(ctx->d_block_counters, 0, 2 * (size_t)ctx->nblocks * pt::CNT_COUNT * 8, ctx->stream));
@@ -1934,6 +2005,7 @@ extern "C" int mi3pt_reset_counters(mi3pt_ctx *ctx)
 extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out, size_t capacity_slots,
                                       size_t *slots_out)
 {
+    PT_GROUP(ctx, mi3pt_debug_wave_times(group_member0(ctx), enable, out, capacity_slots, slots_out));
     if (int rc = require_idle(ctx)) return rc;
     const int slots = pt::PT_MAX_RESIDENT_WAVES;
     if (!out) {
@@ -1959,6 +2031,7 @@ extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out,
 
 extern "C" int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n, float *out)
 {
+    PT_GROUP(ctx, mi3pt_debug_intersect(group_member0(ctx), rays, n, out));
     if (int rc = require_idle(ctx)) return rc;
     if (!rays || !out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (int rc = check_scene(ctx)) return rc;
@@ -1984,6 +2057,7 @@ extern "C" int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n
 
 extern "C" int mi3pt_device_build_bvh(mi3pt_ctx *ctx, void *nodes_out, size_t nodes_capacity_bytes, size_t *nnodes_out, float *build_ms)
 {
+    PT_GROUP(ctx, mi3pt_device_build_bvh(group_member0(ctx), nodes_out, nodes_capacity_bytes, nnodes_out, build_ms));
     if (int rc = require_idle(ctx)) return rc;
     if (!nodes_out || !nnodes_out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (!ctx->d_tris || ctx->ntris == 0) return pt_set_error(MI3PT_ERR_STATE, "no triangles uploaded (mi3pt_upload_triangles)");
@@ -2000,6 +2074,7 @@ extern "C" int mi3pt_device_build_bvh(mi3pt_ctx *ctx, void *nodes_out, size_t no
 extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t n, int waves_per_simd, int repeats, int passes,
                                       float *out_tuvi, float *ms_out)
 {
+    PT_GROUP(ctx, mi3pt_debug_walk_probe(group_member0(ctx), rays, n, waves_per_simd, repeats, passes, out_tuvi, ms_out));
     if (int rc = require_idle(ctx)) return rc;
     if (passes < 1) passes = 1;
     if (!rays || !ms_out || n == 0 || n * (size_t)passes > 0x7fffffffu) return pt_set_error(MI3PT_ERR_INVALID, "bad argument");
@@ -2044,6 +2119,7 @@ extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t 
 
 extern "C" int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n)
 {
+    PT_GROUP(ctx, mi3pt_debug_math(group_member0(ctx), fn, a, b, out, n));
     if (int rc = require_idle(ctx)) return rc;
     if (!a || !out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     if (n == 0) return MI3PT_OK;
@@ -2063,5 +2139,333 @@ extern "C" int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const fl
     if (d_b) (void)hipFree(d_b);
     if (d_o) (void)hipFree(d_o);
     if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("debug_math: ") + hipGetErrorString(e));
+    return MI3PT_OK;
+}
+
+// =================================================================================================
+// Device groups: Renderer.create() over the GPUs of one node (the reference's seam is one adapter and
+// one device, renderer.ts:491-533, and one render() per frame, :366-395).
+//
+// A group handle behaves like a context: the same entry points, the same frame semantics, the same bits.  Behind it
+// stand one member context per listed device -- member i renders tile i of n (8-row blocks dealt round robin:
+// mi3pt_set_tile), the scene is replicated by every upload call, NOTHING is exchanged per frame -- and one
+// presenting context on the first device that holds the whole image.  The one exchange of a job is the GATHER: when
+// the accumulation image (or the canvas) is read, every member's HDR accumulation rows are copied into the presenting
+// context's image, de-interleaved on the way: one strided device-to-device copy per member (hipMemcpy2DAsync: peer
+// DMA over xGMI when the devices can reach each other, staged by the runtime otherwise), no host buffer, no
+// torch, no collective library -- a gather to one root is n - 1 point-to-point transfers on n - 1 distinct links.  The
+// fullscreen pass (the de-noise looks 6 rows up and down, so it cannot run per tile) runs on the gathered image; a
+// group therefore always presents lazily -- a FULLSCREEN submit is remembered and performed when the canvas is read
+// (MI3PT_PRESENT_LATEST; drawing the canvas from every frame would put a gather into every frame).
+// A group may list one device several times (tests: two members on the one GPU of the box).
+// =================================================================================================
+struct GroupState {
+    std::vector<mi3pt_ctx *> members;
+    mi3pt_ctx *present = nullptr;
+    int block_rows = 8;
+    int width = 0, height = 0;
+    bool gathered = false;        // the presenting context holds the members' current accumulation images
+    bool want_present = false;    // a fullscreen pass has been submitted since the canvas was last drawn
+};
+
+template <class F>
+static int group_each(mi3pt_ctx *g, bool with_present, F fn)
+{
+    for (mi3pt_ctx *m : g->group->members)
+        if (int rc = fn(m)) return rc;
+    if (with_present)
+        if (int rc = fn(g->group->present)) return rc;
+    return MI3PT_OK;
+}
+
+static mi3pt_ctx *group_member0(mi3pt_ctx *g) { return g->group->members[0]; }
+static int group_unsupported(const char *what) { return pt_set_error(MI3PT_ERR_STATE, what); }
+
+extern "C" int mi3pt_create_group(const int *devices, int ndevices, int block_rows, mi3pt_ctx **out_ctx)
+{
+    if (!devices || !out_ctx || ndevices < 1 || ndevices > 64) return pt_set_error(MI3PT_ERR_INVALID, "mi3pt_create_group: 1..64 devices");
+    if (block_rows < 1 || block_rows > 4096) return pt_set_error(MI3PT_ERR_INVALID, "mi3pt_create_group: block_rows must be in [1, 4096]");
+    *out_ctx = nullptr;
+    mi3pt_ctx *g = new (std::nothrow) mi3pt_ctx();
+    GroupState *gs = new (std::nothrow) GroupState();
+    if (!g || !gs) { delete g; delete gs; return pt_set_error(MI3PT_ERR_HIP, "out of host memory"); }
+    g->group = gs;
+    g->device = devices[0];
+    gs->block_rows = block_rows;
+    int rc = MI3PT_OK;
+    for (int i = 0; i < ndevices && rc == MI3PT_OK; i++) {
+        mi3pt_ctx *m = nullptr;
+        rc = mi3pt_create(devices[i], &m);
+        if (rc == MI3PT_OK) {
+            gs->members.push_back(m);
+            rc = mi3pt_set_tile(m, i, ndevices, block_rows);
+        }
+    }
+    if (rc == MI3PT_OK) rc = mi3pt_create(devices[0], &gs->present);
+    if (rc == MI3PT_OK) rc = mi3pt_set_present_mode(gs->present, MI3PT_PRESENT_EXACT);
+    if (rc == MI3PT_OK) {
+        // let the first device's copy engines reach the others' memory (where the hardware cannot, the runtime stages the copies)
+        if (hipSetDevice(devices[0]) == hipSuccess) {
+            for (int i = 1; i < ndevices; i++) {
+                int can = 0;
+                if (devices[i] != devices[0] && hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(devices[i], 0);
+                (void)hipGetLastError();      // (already enabled: not an error here)
+            }
+        }
+        *out_ctx = g;
+        return MI3PT_OK;
+    }
+    const std::string msg = g_last_error;
+    group_destroy(g);
+    return pt_set_error(rc, msg);
+}
+
+extern "C" int mi3pt_group_size(mi3pt_ctx *ctx, int *members)
+{
+    if (!ctx || !members) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    *members = ctx->group ? (int)ctx->group->members.size() : 1;
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_group_member(mi3pt_ctx *ctx, int index, mi3pt_ctx **member)
+{
+    if (!ctx || !member) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (!ctx->group) { if (index != 0) return pt_set_error(MI3PT_ERR_INVALID, "not a group: the only member is index 0"); *member = ctx; return MI3PT_OK; }
+    if (index == -1) { *member = ctx->group->present; return MI3PT_OK; }
+    if (index < 0 || (size_t)index >= ctx->group->members.size()) return pt_set_error(MI3PT_ERR_INVALID, "member index out of range");
+    *member = ctx->group->members[(size_t)index];
+    return MI3PT_OK;
+}
+
+static int group_destroy(mi3pt_ctx *g)
+{
+    GroupState *gs = g->group;
+    int rc = MI3PT_OK;
+    for (mi3pt_ctx *m : gs->members)
+        if (m) { const int r = mi3pt_destroy(m); if (r && !rc) rc = r; }
+    if (gs->present) { const int r = mi3pt_destroy(gs->present); if (r && !rc) rc = r; }
+    delete gs;
+    g->group = nullptr;
+    delete g;
+    return rc;
+}
+
+static int group_resize(mi3pt_ctx *g, int width, int height)
+{
+    GroupState *gs = g->group;
+    gs->width = gs->height = 0;
+    if (int rc = group_each(g, true, [&](mi3pt_ctx *m) { return mi3pt_resize(m, width, height); })) return rc;
+    gs->width = width;
+    gs->height = height;
+    g->width = width; g->height = height;
+    gs->gathered = true;          // every image is zero
+    gs->want_present = false;
+    return MI3PT_OK;
+}
+
+static int group_reset(mi3pt_ctx *g)
+{
+    GroupState *gs = g->group;
+    if (int rc = group_each(g, true, [&](mi3pt_ctx *m) { return mi3pt_reset(m); })) return rc;
+    gs->gathered = true;
+    gs->want_present = false;
+    return MI3PT_OK;
+}
+
+static int group_set_uniforms(mi3pt_ctx *g, int pass, const void *bytes, size_t nbytes)
+{
+    if (pass == MI3PT_PASS_FULLSCREEN) return mi3pt_set_uniforms(g->group->present, pass, bytes, nbytes);
+    return group_each(g, false, [&](mi3pt_ctx *m) { return mi3pt_set_uniforms(m, pass, bytes, nbytes); });
+}
+
+static int group_submit_frames(mi3pt_ctx *g, unsigned pass_mask, uint32_t count)
+{
+    GroupState *gs = g->group;
+    if (gs->width == 0) return pt_set_error(MI3PT_ERR_STATE, "submit before resize");
+    const unsigned sample = pass_mask & (MI3PT_SUBMIT_RAYTRACE | MI3PT_SUBMIT_ACCUMULATE);
+    if (sample) {
+        if (int rc = group_each(g, false, [&](mi3pt_ctx *m) { return count == 1 ? mi3pt_submit(m, sample) : mi3pt_submit_frames(m, sample, count); })) return rc;
+        if (sample & MI3PT_SUBMIT_ACCUMULATE) gs->gathered = false;
+    }
+    if (pass_mask & MI3PT_SUBMIT_FULLSCREEN) gs->want_present = true;      // performed when the canvas is read (see the header of this section)
+    return MI3PT_OK;
+}
+
+static int group_flush(mi3pt_ctx *g) { return group_each(g, false, [&](mi3pt_ctx *m) { return mi3pt_flush(m); }); }
+
+static int group_sync(mi3pt_ctx *g)
+{
+    // launch everything that is queued on every member first, THEN wait: the members run side by side
+    if (int rc = group_flush(g)) return rc;
+    return group_each(g, true, [&](mi3pt_ctx *m) { return mi3pt_sync(m); });
+}
+
+// The one exchange: members' accumulation rows -> the presenting context's whole image.
+static int group_gather(mi3pt_ctx *g)
+{
+    GroupState *gs = g->group;
+    if (gs->width == 0) return pt_set_error(MI3PT_ERR_STATE, "read before resize");
+    if (gs->gathered) return MI3PT_OK;
+    if (int rc = group_sync(g)) return rc;
+    mi3pt_ctx *p = gs->present;
+    if (int rc = require_idle(p)) return rc;
+    const int n = (int)gs->members.size(), br = gs->block_rows, W = gs->width, H = gs->height;
+    const size_t row_bytes = (size_t)W * 16, block_bytes = row_bytes * (size_t)br;
+    uint8_t *dst = reinterpret_cast<uint8_t *>(p->d_accum);
+    for (int i = 0; i < n; i++) {
+        const mi3pt_ctx *m = gs->members[(size_t)i];
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(m->d_accum);
+        const int rows = m->local_rows;
+        const int full = rows / br, tail = rows - full * br;      // whole blocks, rows of a last partial block (the image's bottom edge)
+        if (full > 0)
+            HIP_TRY(hipMemcpy2DAsync(dst + (size_t)i * block_bytes, (size_t)n * block_bytes, src, block_bytes, block_bytes, (size_t)full,
+                                     hipMemcpyDeviceToDevice, p->stream));
+        if (tail > 0) {
+            const size_t grow = ((size_t)full * (size_t)n + (size_t)i) * (size_t)br;      // global row of the partial block
+            if ((int)grow + tail > H) return pt_set_error(MI3PT_ERR_STATE, "gather: tile geometry mismatch");
+            HIP_TRY(hipMemcpyAsync(dst + grow * row_bytes, src + (size_t)full * block_bytes, (size_t)tail * row_bytes, hipMemcpyDeviceToDevice, p->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->output_is_accum = true;      // like the copy-back of accumulate.ts:171-175
+    p->main_dirty = true;
+    p->accum_version++;
+    gs->gathered = true;
+    return MI3PT_OK;
+}
+
+static int group_draw_canvas(mi3pt_ctx *g)
+{
+    GroupState *gs = g->group;
+    if (int rc = group_gather(g)) return rc;
+    if (gs->want_present) {
+        if (int rc = mi3pt_submit(gs->present, MI3PT_SUBMIT_FULLSCREEN)) return rc;
+        gs->want_present = false;
+    }
+    return MI3PT_OK;
+}
+
+static int group_read_texture(mi3pt_ctx *g, int which, float *dst, size_t nfloats)
+{
+    GroupState *gs = g->group;
+    if (!dst) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (gs->width == 0) return pt_set_error(MI3PT_ERR_STATE, "read before resize");
+    const size_t need = (size_t)gs->width * gs->height * 4;
+    if (nfloats != need) return pt_set_error(MI3PT_ERR_INVALID, "destination size does not match the texture (a group reads whole images)");
+    if (which == MI3PT_TEX_ACCUMULATION) {
+        if (int rc = group_gather(g)) return rc;
+        return mi3pt_read_texture(gs->present, which, dst, nfloats);
+    }
+    if (which == MI3PT_TEX_CANVAS) {
+        if (int rc = group_draw_canvas(g)) return rc;
+        return mi3pt_read_texture(gs->present, which, dst, nfloats);
+    }
+    if (which != MI3PT_TEX_OUTPUT) return pt_set_error(MI3PT_ERR_INVALID, "unknown texture");
+    // the last frame's radiance: not part of any exchange -- read member by member and de-interleaved on the host
+    const int n = (int)gs->members.size(), br = gs->block_rows;
+    const size_t row = (size_t)gs->width * 4;
+    std::vector<float> part;
+    for (int i = 0; i < n; i++) {
+        mi3pt_ctx *m = gs->members[(size_t)i];
+        part.resize((size_t)m->local_rows * row);
+        if (int rc = mi3pt_read_texture(m, which, part.data(), part.size())) return rc;
+        for (int ly = 0; ly < m->local_rows; ly++) {
+            const size_t gy = ((size_t)(ly / br) * (size_t)n + (size_t)i) * (size_t)br + (size_t)(ly % br);
+            std::memcpy(dst + gy * row, part.data() + (size_t)ly * row, row * 4);
+        }
+    }
+    return MI3PT_OK;
+}
+
+static int group_write_texture(mi3pt_ctx *g, int which, const float *src, size_t nfloats)
+{
+    GroupState *gs = g->group;
+    if (!src) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (gs->width == 0) return pt_set_error(MI3PT_ERR_STATE, "write before resize");
+    if (nfloats != (size_t)gs->width * gs->height * 4) return pt_set_error(MI3PT_ERR_INVALID, "source size does not match the texture (a group writes whole images)");
+    const int n = (int)gs->members.size(), br = gs->block_rows;
+    const size_t row = (size_t)gs->width * 4;
+    std::vector<float> part;
+    for (int i = 0; i < n; i++) {
+        mi3pt_ctx *m = gs->members[(size_t)i];
+        part.resize((size_t)m->local_rows * row);
+        for (int ly = 0; ly < m->local_rows; ly++) {
+            const size_t gy = ((size_t)(ly / br) * (size_t)n + (size_t)i) * (size_t)br + (size_t)(ly % br);
+            std::memcpy(part.data() + (size_t)ly * row, src + gy * row, row * 4);
+        }
+        if (int rc = mi3pt_write_texture(m, which, part.data(), part.size())) return rc;
+    }
+    gs->gathered = false;
+    return MI3PT_OK;
+}
+
+static int group_read_canvas(mi3pt_ctx *g, uint8_t *dst, size_t nbytes)
+{
+    if (int rc = group_draw_canvas(g)) return rc;
+    return mi3pt_read_canvas_rgba8(g->group->present, dst, nbytes);
+}
+
+static int group_accumulation_ptr(mi3pt_ctx *g, void **dev_ptr, size_t *nbytes)
+{
+    if (int rc = group_gather(g)) return rc;
+    return mi3pt_accumulation_device_ptr(g->group->present, dev_ptr, nbytes);
+}
+
+// per-pass GPU time: the passes of the members run side by side -> the slowest member's; the fullscreen pass: the presenting context's
+static int group_pass_time(mi3pt_ctx *g, int pass, float *us)
+{
+    if (!us) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    if (pass == MI3PT_PASS_FULLSCREEN) return mi3pt_pass_time_us(g->group->present, pass, us);
+    float worst = 0.0f;
+    for (mi3pt_ctx *m : g->group->members) {
+        float t = 0.0f;
+        if (int rc = mi3pt_pass_time_us(m, pass, &t)) return rc;
+        if (t > worst) worst = t;
+    }
+    *us = worst;
+    return MI3PT_OK;
+}
+
+static int group_launch_stats(mi3pt_ctx *g, int reset, double *total_ms, uint64_t *launches, uint64_t *frames)
+{
+    double worst = 0.0;
+    uint64_t l0 = 0, f0 = 0;
+    bool first = true;
+    for (mi3pt_ctx *m : g->group->members) {
+        double t = 0.0;
+        uint64_t l = 0, f = 0;
+        if (int rc = mi3pt_raytrace_launch_stats(m, reset, &t, &l, &f)) return rc;
+        if (t > worst) worst = t;
+        if (first) { l0 = l; f0 = f; first = false; }
+    }
+    if (total_ms) *total_ms = worst;
+    if (launches) *launches = l0;
+    if (frames) *frames = f0;
+    return MI3PT_OK;
+}
+
+static int group_launch_span(mi3pt_ctx *g, double *span_ms)
+{
+    if (!span_ms) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    double worst = 0.0;
+    for (mi3pt_ctx *m : g->group->members) {
+        double t = 0.0;
+        if (int rc = mi3pt_raytrace_launch_span(m, &t)) return rc;
+        if (t > worst) worst = t;
+    }
+    *span_ms = worst;
+    return MI3PT_OK;
+}
+
+static int group_counters(mi3pt_ctx *g, uint64_t *out)
+{
+    if (!out) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
+    for (int k = 0; k < MI3PT_CNT_COUNT; k++) out[k] = 0;
+    for (mi3pt_ctx *m : g->group->members) {
+        uint64_t c[MI3PT_CNT_COUNT];
+        if (int rc = mi3pt_get_counters(m, c)) return rc;
+        for (int k = 0; k < MI3PT_CNT_COUNT; k++) out[k] += c[k];
+    }
     return MI3PT_OK;
 }

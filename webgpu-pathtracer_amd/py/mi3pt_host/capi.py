@@ -40,6 +40,7 @@ SYMBOLS = (
     "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_debug_active_variant", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf", "mi3pt_debug_set_option", "mi3pt_debug_get_option",
+    "mi3pt_create_group", "mi3pt_group_size", "mi3pt_group_member",
 )
 
 
@@ -97,6 +98,9 @@ def load_library(path=None):
     lib.mi3pt_raytrace_launch_span.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.mi3pt_batch_capacity.argtypes = [c_void_p, ctypes.POINTER(c_int)]
     lib.mi3pt_debug_active_variant.argtypes = [c_void_p, ctypes.POINTER(c_int)]
+    lib.mi3pt_create_group.argtypes = [ctypes.POINTER(c_int), c_int, c_int, ctypes.POINTER(c_void_p)]
+    lib.mi3pt_group_size.argtypes = [c_void_p, ctypes.POINTER(c_int)]
+    lib.mi3pt_group_member.argtypes = [c_void_p, c_int, ctypes.POINTER(c_void_p)]
     lib.mi3pt_debug_set_option.argtypes = [c_void_p, c_int, c_int]
     lib.mi3pt_debug_get_option.argtypes = [c_void_p, c_int, ctypes.POINTER(c_int)]
     lib.mi3pt_debug_set_packet_layout.argtypes = [c_void_p, c_int]
@@ -183,10 +187,18 @@ def host_env_cdf(rgba):
 class Context:
     """One mi3pt_ctx: a HIP device + stream + the path tracer's device resources."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None, block_rows=8):
+        """device: one GPU.  devices = [d0, d1, ...]: a device group (mi3pt_create_group) -- the same methods, whole
+        images in and out, the image's 8-row blocks dealt to one member context per listed device."""
         self.lib = load_library()
         handle = ctypes.c_void_p()
-        _check(self.lib, self.lib.mi3pt_create(device, ctypes.byref(handle)))
+        self.group_size = 1
+        if devices is not None:
+            arr = (ctypes.c_int * len(devices))(*devices)
+            _check(self.lib, self.lib.mi3pt_create_group(arr, len(devices), block_rows, ctypes.byref(handle)))
+            self.group_size = len(devices)
+        else:
+            _check(self.lib, self.lib.mi3pt_create(device, ctypes.byref(handle)))
         self.handle = handle
         self.width = self.height = 0
         self.local_rows = 0
@@ -194,9 +206,21 @@ class Context:
         self._next_tile = (0, 1, 8)
 
     def close(self):
-        if self.handle:
+        if self.handle and not getattr(self, "_borrowed", False):
             self.lib.mi3pt_destroy(self.handle)
-            self.handle = None
+        self.handle = None
+
+    def member(self, index):
+        """A member context of a device group (index -1: the presenting context), owned by the group."""
+        h = ctypes.c_void_p()
+        self._c(self.lib.mi3pt_group_member(self.handle, index, ctypes.byref(h)))
+        m = Context.__new__(Context)
+        m.lib, m.handle, m._borrowed, m.group_size = self.lib, h, True, 1
+        m.width, m.height = self.width, self.height
+        n = self.group_size
+        m._tile = m._next_tile = (0, 1, 8) if index < 0 or n == 1 else (index, n, self._tile[2])
+        m.local_rows = tile_local_rows(self.height, *m._tile) if self.height else 0
+        return m
 
     def __enter__(self):
         return self
