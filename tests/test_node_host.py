@@ -67,6 +67,26 @@ def test_render_loop_under_node_matches_golden(built, env, tmp_path):
 
 
 @pytest.mark.gpu
+def test_render_loop_under_node_on_a_device_group(built, env, tmp_path):
+    """Renderer.create({ devices: [0, 0, 0] }): the reference-shaped loop (renderer.ts:366-395) drives a device group
+    from Node -- three member contexts (all on the one GPU of the box), tiles dealt in 8-row blocks, one gather when
+    the images are read -- and ends with the golden image and canvas, like the single-device loop."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "demo_frames.npz"))
+    env_path = tmp_path / "env.f32"
+    env_path.write_bytes(env.tobytes())
+    out = str(tmp_path / "demo")
+    r = _node([os.path.join(JS, "tools", "render_demo.js"), "--env", str(env_path), "--width", "64", "--height", "64",
+               "--frames", "3", "--bounces", "4", "--out", out, "--devices", "0,0,0"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    summary = json.loads(r.stdout.strip().splitlines()[-1])
+    assert summary["status"] == "idle" and summary["frame"] == 4 and summary["counters"]["pixels"] == 3 * 64 * 64
+    acc = np.frombuffer(open(out + ".acc.f32", "rb").read(), np.float32).reshape(64, 64, 4)
+    assert pc.same_bits(acc[..., :3], gold["64_acc3_image"]), pc.describe_diff(acc[..., :3], gold["64_acc3_image"])
+    canvas = np.frombuffer(open(out + ".canvas.rgba8", "rb").read(), np.uint8).reshape(64, 64, 4)
+    assert np.array_equal(canvas, gold["64_acc3_canvas_rgba8"])
+
+
+@pytest.mark.gpu
 def test_render_loop_throughput_under_node(built, env, tmp_path):
     """The drop-in loop at speed: Renderer.render() driven like src/renderer.ts:366-395 / src/main.ts:387-400
     at 1920x1080, 8 bounces.  With the headless default (the canvas drawn once per launched batch) and with

@@ -180,6 +180,40 @@ napi_value Create(napi_env env, napi_callback_info info)
     return ext;
 }
 
+// createGroup(devices: number[], blockRows = 8): Renderer.create({ devices }) -- mi3pt_create_group; the handle goes through
+// the same functions as a single-device one
+napi_value CreateGroup(napi_env env, napi_callback_info info)
+{
+    Args a;
+    if (!get_args(env, info, a, 1)) return nullptr;
+    bool is_array = false;
+    uint32_t n = 0;
+    if (napi_is_array(env, a.v[0], &is_array) != napi_ok || !is_array || napi_get_array_length(env, a.v[0], &n) != napi_ok || n < 1 || n > 64) {
+        napi_throw_type_error(env, nullptr, "createGroup: an array of 1..64 device indices");
+        return nullptr;
+    }
+    int devices[64];
+    for (uint32_t i = 0; i < n; i++) {
+        napi_value e;
+        int32_t d = 0;
+        if (napi_get_element(env, a.v[0], i, &e) != napi_ok || !get_i32(env, e, &d)) return nullptr;
+        devices[i] = d;
+    }
+    int32_t block_rows = 8;
+    if (a.n >= 2 && !get_i32(env, a.v[1], &block_rows)) return nullptr;
+    mi3pt_ctx *ctx = nullptr;
+    MI3PT_TRY(mi3pt_create_group(devices, (int)n, block_rows, &ctx));
+    mi3pt_ctx **slot = new mi3pt_ctx *(ctx);
+    napi_value ext;
+    if (napi_create_external(env, slot, finalize_ctx, nullptr, &ext) != napi_ok) {
+        mi3pt_destroy(ctx);
+        delete slot;
+        napi_throw_error(env, nullptr, "napi_create_external failed");
+        return nullptr;
+    }
+    return ext;
+}
+
 napi_value Destroy(napi_env env, napi_callback_info info)
 {
     Args a;
@@ -508,7 +542,7 @@ napi_value Init(napi_env env, napi_value exports)
 {
     struct { const char *name; napi_callback fn; } fns[] = {
         { "abiVersion", AbiVersion }, { "deviceCount", DeviceCount }, { "deviceName", DeviceName },
-        { "tileLocalRows", TileLocalRows }, { "create", Create }, { "destroy", Destroy },
+        { "tileLocalRows", TileLocalRows }, { "create", Create }, { "createGroup", CreateGroup }, { "destroy", Destroy },
         { "setStorage", SetStorage }, { "setKernelVariant", SetKernelVariant }, { "setTile", SetTile },
         { "uploadTriangles", UploadTriangles }, { "uploadMaterials", UploadMaterials }, { "uploadBvh", UploadBvh },
         { "uploadEnvironment", UploadEnvironment }, { "uploadEnvironmentCdf", UploadEnvironmentCdf },

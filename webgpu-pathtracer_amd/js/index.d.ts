@@ -85,6 +85,10 @@ export interface RendererOptions {
   deviceBvh?: boolean;
   /** multi-GPU tile split: this process renders rows (y / blockRows) % nranks == rank */
   tile?: { rank: number; nranks: number; blockRows: number };
+  /** a device group inside this one process (mi3pt_create_group): the image's blockRows-row blocks are dealt to one
+   *  member context per listed GPU; render(), the read-backs and the events are unchanged and move whole images */
+  devices?: number[];
+  blockRows?: number;
 }
 /** src/renderer.ts:20-468 */
 export class Renderer {

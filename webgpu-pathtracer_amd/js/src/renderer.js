@@ -63,9 +63,20 @@ class Renderer {
     return { supported: true, info: { description: native.deviceName(0), vendor: 'amd', architecture: 'gfx950' } };
   }
 
+  // options.device: one GPU (default 0).  options.devices = [0, 1, ...]: a device group (mi3pt_create_group) -- the
+  // image's 8-row blocks are dealt to one member context per listed GPU, the scene is replicated, nothing is
+  // exchanged per frame, and reading the accumulation image or the canvas gathers the members' rows with peer
+  // copies; the loop below (renderer.ts:366-395) and every read-back stay the same and move whole images.
   static async create(options) {
     const native = loadNative();
     const opts = options || {};
+    if (Array.isArray(opts.devices)) {
+      if (opts.tile) throw new Error('Renderer.create: `devices` and `tile` exclude each other (a device group deals the tiles itself)');
+      const handle = native.createGroup(opts.devices, opts.blockRows || 8);      // throws "HIP device not found."
+      const r = new Renderer({ native, handle, options: opts, tile: { rank: 0, nranks: 1, blockRows: opts.blockRows || 8 } });
+      r.devices = opts.devices.slice();
+      return r;
+    }
     const handle = native.create(opts.device || 0);      // throws "HIP device not found." (renderer.ts:514-516)
     const tile = opts.tile || { rank: 0, nranks: 1, blockRows: 8 };
     native.setTile(handle, tile.rank, tile.nranks, tile.blockRows);

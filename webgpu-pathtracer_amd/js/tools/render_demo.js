@@ -4,6 +4,7 @@
 //   node render_demo.js --env env.f32 --width 64 --height 64 --frames 3 --bounces 4 --out prefix
 //   --hdr file.hdr     a Radiance map (1024x512) instead of raw float texels (main.ts:41-46)
 //   --model file.glb   replace the default meshes by a loaded model (.glb/.gltf/.obj), main.ts:251-279
+//   --devices 0,1,2    a device group: Renderer.create({ devices: [0, 1, 2] }) -- the same loop on several GPUs
 // Writes <prefix>.acc.f32 (accumulation, RGBA float), <prefix>.canvas.rgba8 and prints a
 // JSON summary.  Needs a HIP device.
 const fs = require('fs');
@@ -26,7 +27,9 @@ async function main() {
   }
   const diag = await pt.Renderer.diagnostic();
   if (!diag.supported) throw new Error('HIP device not found.');
-  const renderer = await pt.Renderer.create({ enableTimestampQuery: true });
+  const devices = arg('devices', null);
+  const renderer = await pt.Renderer.create(devices ? { enableTimestampQuery: true, devices: devices.split(',').map((d) => parseInt(d, 10)) }
+    : { enableTimestampQuery: true });
   const { scene, camera } = buildDefaultScene(envData);
   if (arg('hdr', null)) scene.environment = new pt.RGBELoader().setDataType(pt.FloatType).load(arg('hdr'));
   const modelPath = arg('model', null);
