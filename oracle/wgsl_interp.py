@@ -186,6 +186,8 @@ def _scalar_bin(op, a, b):
     if op in ("<<", ">>"):
         ka = kind(a)
         s = int(b)
+        if ka in "ui":
+            s %= 32      # WGSL "Bit Expressions": a concrete 32-bit operand is shifted by e2 modulo the bit width
         if ka == "u":
             return _u32(int(a) << s) if op == "<<" else _u32(int(a) >> s)
         if ka == "i":
