@@ -201,7 +201,7 @@ int mi3pt_sync(mi3pt_ctx *ctx);   /* queue.onSubmittedWorkDone(), renderer.ts:42
 int mi3pt_set_present_mode(mi3pt_ctx *ctx, int mode /* mi3pt_present_mode */);
 /* RAYTRACE|ACCUMULATE submits may be queued inside the library and launched together (up to
  * 64 consecutive frames whose uniforms differ only in `frame` -- 64 x nranks for a rank of a tile
- * split, at most 256, less when memory is short -- run as one kernel + one ordered
+ * split, at most 512, less when memory is short -- run as one kernel + one ordered
  * accumulate).  Every call that observes or changes device state launches the queue first;
  * mi3pt_flush does only that, without waiting -- use it before synchronising the stream
  * yourself (e.g. torch.cuda.synchronize()). */
@@ -285,7 +285,7 @@ typedef enum mi3pt_option {
     MI3PT_OPT_JOB_REVERSE = 6, /* the launch's jobs bottom band first (1) */
     MI3PT_OPT_JOB_GROUP = 7,   /* tiles per job group; 0 frame-major, -1 the library's choice (-1) */
     MI3PT_OPT_JOB_CHUNK = 8,   /* job tickets per draw while the queue is long (4) */
-    MI3PT_OPT_BATCH_LIMIT = 9, /* upper bound of frames per launch, process-wide (256) */
+    MI3PT_OPT_BATCH_LIMIT = 9, /* upper bound of frames per launch, process-wide (512) */
     MI3PT_OPT_BATCH = 10,      /* frames per launch on one GPU; x nranks for a rank of a tile split (64); 1 = no batching */
     MI3PT_OPT_WAVES_PER_CU = 11, /* resident one-wave workgroups per compute unit (0 = what the kernel is compiled for: 20 for the shipped batched launch, 16 otherwise) */
     MI3PT_OPT_CULL = 12,       /* 0: `auto` stops at variant 7 */

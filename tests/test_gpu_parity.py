@@ -722,7 +722,7 @@ def test_batch_capacity_and_launch_statistics(gpu_ctx, demo, env):
     w, h = 640, 360
     ctx = gpu_ctx
     pc.upload_scene(ctx, demo, env)
-    for nranks, want in ((1, 64), (2, 128), (8, 256), (16, 256)):
+    for nranks, want in ((1, 64), (2, 128), (4, 256), (8, 512), (16, 512)):
         ctx.set_tile(0, nranks, 8)
         ctx.resize(w, h)
         assert ctx.batch_capacity() == want

@@ -179,7 +179,7 @@ struct mi3pt_ctx {
 // launch k + SERVICE_SLOTS) on the stream launch k ran on, i.e. after it.
 static const int SERVICE_SLOTS = 8;
 static size_t service_slot_bytes() { return (pt::service_block_bytes() + 255) / 256 * 256; }
-static int BATCH_LIMIT = 256;           // (MI3PT_BATCH_LIMIT: experiment knob; a rank of an 8-way split: 256 instead of 128 frames per launch -3 % job time)
+static int BATCH_LIMIT = 512;           // (MI3PT_OPT_BATCH_LIMIT; a rank of an 8-way split: its 320-frame job as ONE launch of 512-frame capacity instead of 256 + 64: 11.16 instead of 11.62 ms, profiles/r03_d_job_split.log)
 
 static inline float ldf(const uint8_t *p, size_t off) { float f; std::memcpy(&f, p + off, 4); return f; }
 static inline int32_t ldi(const uint8_t *p, size_t off) { int32_t v; std::memcpy(&v, p + off, 4); return v; }
@@ -1541,6 +1541,18 @@ static int ensure_slots(mi3pt_ctx *ctx, int par /* slot set */, int n)
     if (ctx->d_slots[par]) (void)hipFree(ctx->d_slots[par]);
     ctx->d_slots[par] = fresh;
     ctx->slots_alloc[par] = want;
+    // a caller that batches deeply will need the other set(s) at the same depth with its very next launch: allocate them
+    // now, outside its steady state (the allocation of a gigabyte took ~0.4 ms of a 12 ms job otherwise)
+    if (want == ctx->batch_cap && want > 8) {
+        for (int other = 0; other < ctx->slot_sets; other++) {
+            if (other == par || ctx->slots_alloc[other] >= want) continue;
+            float4 *more = nullptr;
+            if (hipMalloc((void **)&more, tex_bytes ? tex_bytes * (size_t)want : 16) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (ctx->d_slots[other]) (void)hipFree(ctx->d_slots[other]);
+            ctx->d_slots[other] = more;
+            ctx->slots_alloc[other] = want;
+        }
+    }
     return MI3PT_OK;
 }
 
