@@ -23,6 +23,7 @@ echo "cull probe done"
 python profiles/wave_timeline.py 1920x1080 16 > $OUT/${TAG}_wave_timeline_demo.log 2>&1
 WORKLOAD=dragon python profiles/wave_timeline.py 1920x1080 16 > $OUT/${TAG}_wave_timeline_dragon.log 2>&1
 WORKLOAD=dragon TILE=0/8 python profiles/wave_timeline.py 1920x1080 20 > $OUT/${TAG}_wave_timeline_dragon_rank0of8_20frames.log 2>&1
+WORKLOAD=forest python profiles/wave_timeline.py 1920x1080 16 > $OUT/${TAG}_wave_timeline_forest.log 2>&1
 python profiles/fullscreen_time.py > $OUT/${TAG}_fullscreen_time.log 2>&1
 python -c "
 import sys; sys.path.insert(0, 'webgpu-pathtracer_amd/py')
@@ -31,16 +32,21 @@ scenes.synthetic_env().tofile('/tmp/env.f32')"
 node webgpu-pathtracer_amd/js/tools/bench_render_loop.js --env /tmp/env.f32 --frames 64 > $OUT/${TAG}_node_render_loop.json 2>&1
 echo "timelines + loop bench done"
 bash profiles/rocprof_stats.sh $TAG
-python bench.py > $OUT/${TAG}_dragon_1080p_bench.json 2> $OUT/${TAG}_dragon_bench.err
+python bench.py --no-forest > $OUT/${TAG}_dragon_1080p_bench.json 2> $OUT/${TAG}_dragon_bench.err
 echo "bench (default args) done: $(cut -c1-120 $OUT/${TAG}_dragon_1080p_bench.json)"
-sleep 45
+sleep 30
 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_dragon_1080p_bench_driver_args.json 2>/dev/null
 echo "bench (driver args) done: $(cut -c1-120 $OUT/${TAG}_dragon_1080p_bench_driver_args.json)"
-sleep 45
-python bench.py --workload demo > $OUT/${TAG}_demo_1080p_bench.json 2>/dev/null
+sleep 30
+python bench.py --workload demo --no-forest > $OUT/${TAG}_demo_1080p_bench.json 2>/dev/null
 echo "bench (demo) done: $(cut -c1-120 $OUT/${TAG}_demo_1080p_bench.json)"
 STEPS=20; WARM=5
 bash profiles/pmc_passes.sh gpurun_out/${TAG}_pmc_dragon --steps $STEPS --warmup $WARM
 python profiles/pmc_summary.py $OUT/${TAG}_pmc_dragon k_raytrace $((STEPS / 4)) > $OUT/${TAG}_dragon_pmc_per_launch.txt
 rm -rf $OUT/${TAG}_pmc_dragon $OUT/${TAG}_pmc_dragon.pass*.log
 echo "pmc passes done: $(grep -c . $OUT/${TAG}_dragon_pmc_per_launch.txt) counters"
+# config 5's scene (the one larger than the Infinity Cache): the forest leg of bench.py, 1920x1080, 8 steps = two 64-frame launches
+bash profiles/pmc_passes.sh gpurun_out/${TAG}_pmc_forest --workload forest --steps 8 --warmup 4
+python profiles/pmc_summary.py $OUT/${TAG}_pmc_forest k_raytrace 2 > $OUT/${TAG}_forest_pmc_per_launch.txt
+rm -rf $OUT/${TAG}_pmc_forest $OUT/${TAG}_pmc_forest.pass*.log
+echo "forest pmc passes done: $(grep -c . $OUT/${TAG}_forest_pmc_per_launch.txt) counters"

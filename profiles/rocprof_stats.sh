@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 for A in "" "--steps 20 --warmup 5"; do
   S=$(echo "$A" | tr -d ' -' ); S=${S:-default}
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_$S -- python3 $ROOT/bench.py --no-cpu-baseline --no-also $A > $OUT/${TAG}_bench_under_rocprof_$S.json 2> $OUT/${TAG}_stats_$S.err)
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_$S -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --no-forest $A > $OUT/${TAG}_bench_under_rocprof_$S.json 2> $OUT/${TAG}_stats_$S.err)
   cp $(ls $OUT/${TAG}_stats_$S/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_dragon_1080p_kernel_stats_$S.csv
   cp $(ls $OUT/${TAG}_stats_$S/*/*_kernel_trace.csv | head -1) $OUT/${TAG}_dragon_1080p_kernel_trace_$S.csv
   rm -rf $OUT/${TAG}_stats_$S

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-wave lifetime and step statistics of the persistent raytrace kernel.
 
-usage: [WORKLOAD=dragon] [TILE=R/N] [VARIANT=v] python profiles/wave_timeline.py [WxH] [frames_per_launch]
+usage: [WORKLOAD=dragon|forest] [TILE=R/N] [VARIANT=v] python profiles/wave_timeline.py [WxH] [frames_per_launch]
 Renders one launch of `frames_per_launch` batched frames (default 16; 1 = a single frame) of
 the demo (or dragon-class) scene at 8 bounces and prints when the resident waves begin, see the
 work queue run empty, and end (100 MHz wall clock), the shader clock they averaged, and how
@@ -19,7 +19,7 @@ from mi3pt_host import capi, scenes  # noqa: E402
 
 w, h = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1920x1080").split("x"))
 nframes = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-sc = scenes.dragon_class_scene() if os.environ.get("WORKLOAD") == "dragon" else scenes.demo_scene()
+sc = {"dragon": scenes.dragon_class_scene, "forest": scenes.forest_scene}.get(os.environ.get("WORKLOAD"), scenes.demo_scene)()
 sc.build_bvh()
 env = scenes.synthetic_env()
 ctx = capi.Context(0)

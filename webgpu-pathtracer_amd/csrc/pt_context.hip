@@ -177,6 +177,7 @@ struct mi3pt_ctx {
 // Blocks of launch-invariant scalars for the raytrace kernel's service step (pt::RtService), one per batched launch.  Launches
 // alternate between two streams and at most two are in flight; a slot is rewritten (in stream order, by the setup kernel of
 // launch k + SERVICE_SLOTS) on the stream launch k ran on, i.e. after it.
+static_assert(MI3PT_ENV_WIDTH == pt::ENV_W && MI3PT_ENV_HEIGHT == pt::ENV_H, "the tuned kernels' environment size is the API's");
 static const int SERVICE_SLOTS = 8;
 static size_t service_slot_bytes() { return (pt::service_block_bytes() + 255) / 256 * 256; }
 static int BATCH_LIMIT = 512;           // (MI3PT_OPT_BATCH_LIMIT; a rank of an 8-way split: its 320-frame job as ONE launch of 512-frame capacity instead of 256 + 64: 11.16 instead of 11.62 ms, profiles/r03_d_job_split.log)
@@ -1526,6 +1527,16 @@ static int ensure_slots(mi3pt_ctx *ctx, int par /* slot set */, int n)
     // once, so that a batching caller allocates once and not again in the middle of its job
     int want = n <= 1 ? 1 : (n <= 8 ? 8 : ctx->batch_cap);
     if (want > ctx->batch_cap) want = ctx->batch_cap;
+    if (want > n && tex_bytes) {
+        // the cap was computed at resize; what is free NOW decides whether the full depth (for every slot set) is taken
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t fit = (free_b / 2) / ((size_t)ctx->slot_sets * tex_bytes);
+            if ((size_t)want > fit) want = fit > (size_t)n ? (int)fit : n;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (want < n) want = n;
     float4 *fresh = nullptr;
     hipError_t e = hipMalloc((void **)&fresh, tex_bytes ? tex_bytes * (size_t)want : 16);

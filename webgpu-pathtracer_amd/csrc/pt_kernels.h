@@ -39,8 +39,16 @@ static_assert(SM_LDS_DEPTH >= 8 && SM_LDS_DEPTH <= 32, "LDS stack depth");
 // 4 -> 128) and, times four SIMDs, the one-wave workgroups per compute unit of their persistent grid: the tuned twins of
 // the shipped walks need 95-96 registers since their service step's scalars moved to memory (RtService) and run five per
 // SIMD; the diagnostic twins and the other variants keep four.
-constexpr int SM_TUNED_WAVES_PER_SIMD = 5, SM_OTHER_WAVES_PER_SIMD = 4;
+#ifndef PT_SM_TUNED_WAVES
+#define PT_SM_TUNED_WAVES 5
+#endif
+constexpr int SM_TUNED_WAVES_PER_SIMD = PT_SM_TUNED_WAVES, SM_OTHER_WAVES_PER_SIMD = 4;
 static_assert(4 * SM_TUNED_WAVES_PER_SIMD * (SM_LDS_DEPTH * 256 + 6 * 256) < 160 * 1024, "LDS: stack + parked path state of every resident wave");
+
+// The environment texture's size: fixed by the API (renderer.ts:76-85; MI3PT_ENV_WIDTH / _HEIGHT in include/mi3pt.h, tied to these
+// by a static_assert in pt_context.hip).  The tuned kernel instantiations have it as a constant; launch_raytrace sends any other size
+// to the generic twin.
+constexpr int ENV_W = 1024, ENV_H = 512;
 
 // per-pass counters, see mi3pt_counter in include/mi3pt.h
 enum { CNT_RAYS, CNT_BOX, CNT_TRI, CNT_HIT, CNT_MISS, CNT_OVERFLOW, CNT_PIXELS, CNT_RESERVED, CNT_COUNT };
@@ -140,11 +148,21 @@ struct Tile {
 };
 
 // The step-voting knobs' defaults (the context's initial values; the shipped kernels' tuned instantiation has them as constants)
+#ifndef PT_DEFAULT_WALK_MIN
 #define PT_DEFAULT_WALK_MIN 32
+#endif
+#ifndef PT_DEFAULT_LEAF_MIN
 #define PT_DEFAULT_LEAF_MIN 24
+#endif
+#ifndef PT_DEFAULT_SHADE_SPLIT
 #define PT_DEFAULT_SHADE_SPLIT 64
+#endif
+#ifndef PT_DEFAULT_TAIL_POLICY
 #define PT_DEFAULT_TAIL_POLICY 7
+#endif
+#ifndef PT_DEFAULT_JOB_CHUNK
 #define PT_DEFAULT_JOB_CHUNK 4
+#endif
 
 struct RtService;      // pt_kernels.hip: the launch-invariant scalars of the state-machine kernel's service step
 

@@ -1746,7 +1746,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 
                 float u, v;
                 env_uv_from_dir(d, sinr, cosr, u, v);
-                const f3 env = sample_env(sc.env, TUNED ? 1024 : sc.env_w, TUNED ? 512 : sc.env_h, u, v);      // (the environment texture is 1024 x 512 by the API: renderer.ts:76-85)
+                const f3 env = sample_env(sc.env, TUNED ? ENV_W : sc.env_w, TUNED ? ENV_H : sc.env_h, u, v);      // (the environment texture is 1024 x 512 by the API: renderer.ts:76-85)
                 light = light + (ray_color * env) * un.env_intensity;
             }
             PT_SERVICE_PART();
@@ -2017,7 +2017,7 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
                            L.shade_split == PT_DEFAULT_SHADE_SPLIT && L.tail_policy == PT_DEFAULT_TAIL_POLICY &&
                            L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 &&
                            L.scene.nnodes != 0 && (L.scene.flags & 1u) != 0u && (L.scene.root_ref & PT_REF_LEAF) == 0u &&
-                           L.scene.env_w == 1024 && L.scene.env_h == 512 &&
+                           L.scene.env_w == ENV_W && L.scene.env_h == ENV_H &&
                            L.service != nullptr && L.un.max_bounces > 0 && L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
                            L.un.res_y >= 9.5367431640625e-07f && L.un.res_y <= 1.099511627776e12f;
         const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu, L.num_cus, tuned && variant >= 9 && variant <= 12));
