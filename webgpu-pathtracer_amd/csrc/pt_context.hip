@@ -256,16 +256,17 @@ extern "C" int mi3pt_device_name(int device, char *name, size_t capacity)
     return MI3PT_OK;
 }
 
-// A profiler that collects hardware counters is attached to this process (rocprofv3 / rocprofiler-sdk preload their
-// tool library and announce themselves in the environment).  See mi3pt_create: the launch gate.
+// A profiler that collects HARDWARE COUNTERS is attached to this process: rocprofv3 --pmc / -i announce counter collection
+// in the environment of the program they start (ROCPROF_COUNTER_COLLECTION, ROCPROF_COUNTERS / _COUNTER_GROUPS; the older
+// rocprof: ROCP_METRICS / ROCP_INPUT).  Tracing alone (--kernel-trace, --stats) does not serialise kernels and keeps the
+// launch gate.  See mi3pt_create.
 static bool profiler_attached()
 {
-    extern char **environ;
-    for (char **e = environ; e && *e; e++)
-        if (std::strncmp(*e, "ROCPROF", 7) == 0 || std::strncmp(*e, "ROCP_", 5) == 0) return true;
-    for (const char *name : { "LD_PRELOAD", "HSA_TOOLS_LIB" })
+    auto truthy = [](const char *v) { return v && v[0] && !(v[0] == '0' && !v[1]) && std::strcmp(v, "false") != 0 && std::strcmp(v, "False") != 0; };
+    if (truthy(std::getenv("ROCPROF_COUNTER_COLLECTION"))) return true;
+    for (const char *name : { "ROCPROF_COUNTERS", "ROCPROF_COUNTER_GROUPS", "ROCPROF_EXTRA_COUNTERS_CONTENTS", "ROCP_METRICS", "ROCP_INPUT" })
         if (const char *v = std::getenv(name))
-            if (std::strstr(v, "rocprof") || std::strstr(v, "rocprofiler")) return true;
+            if (v[0]) return true;
     return false;
 }
 
@@ -330,7 +331,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     CREATE_TRY(hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream));     // self-cleaning afterwards
     // a word the command processor can poll (hipStreamWaitValue32) and a running kernel can write;
     // optional: without it launches simply queue behind each other
-    // Under a counter-collecting profiler the gate is off from the start: rocprofv3 --pmc serialises kernels in the order
+    // Under a counter-collecting profiler (not under plain tracing) the gate is off from the start: rocprofv3 --pmc serialises kernels in the order
     // it intercepts them on the two internal queues, which need not be the order they were enqueued in, and a launch that
     // is held until its predecessor announces its drain can then end up in FRONT of that predecessor -- a deadlock (seen
     // as counter passes that never finish, and as a mi3pt_destroy that never returns).  Ungated launches simply queue
@@ -1618,6 +1619,7 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame &first, in
             L.drain_seq = ++ctx->launch_seq;
         }
     }
+    pt::launch_raytrace_setup(L, false, pick_variant(ctx), rs);
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev_rt[par][0], rs));
         if (!ctx->span_started) { HIP_TRY(hipEventRecord(ctx->ev_span_start, rs)); ctx->span_started = true; }

@@ -198,6 +198,7 @@ struct RtLaunch {
 };
 size_t service_block_bytes();
 
+void launch_raytrace_setup(const RtLaunch &L, bool fuse_accumulate, int variant, hipStream_t s);    // before launch_raytrace, same stream
 void launch_raytrace(const RtLaunch &L, bool fuse_accumulate, int variant, hipStream_t s);
 void launch_accumulate_batch(const AccUniforms &acc0, const Tile &tile, const float4 *slots, size_t slot_pixels,
                              int nframes, float4 *accum, int store_f16, hipStream_t s);

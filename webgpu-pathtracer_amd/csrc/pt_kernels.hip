@@ -2003,26 +2003,46 @@ int raytrace_grid_blocks(const Tile &tile)
     return tiles_x * tiles_y;
 }
 
+// (SPF1: the shipped walks' batched launches have a specialisation for samplesPerFrame == 1, the reference's
+// default -- no per-pixel sum and sample counter to carry through the walk: five registers less)
+static bool launch_is_one_spp(const RtLaunch &L, bool fuse)
+{
+    return L.un.samples_per_frame == 1 && !fuse && L.un.max_bounces < 65536 && L.nframes <= 65535;
+}
+// The tuned twin runs when: one sample per frame, no diagnostic buffer, every step-voting option at its default (they are
+// constants there), a scene with nodes whose root is an internal node with a guard-range box, the API's environment size,
+// a resolution of ordinary magnitude, maxBounces > 0, and a service block to read (variants 9 .. 12).  The kernel's TUNED
+// constants are exactly these conditions; test_tuned_and_diagnostic_twins_render_the_same_bits holds the twins together.
+static bool launch_is_tuned(const RtLaunch &L, bool fuse, int variant)
+{
+    return variant >= 9 && variant <= 12 && launch_is_one_spp(L, fuse) && !L.wave_times && L.walk_min == PT_DEFAULT_WALK_MIN &&
+           L.leaf_min == PT_DEFAULT_LEAF_MIN && L.shade_split == PT_DEFAULT_SHADE_SPLIT && L.tail_policy == PT_DEFAULT_TAIL_POLICY &&
+           L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 &&
+           L.scene.nnodes != 0 && (L.scene.flags & 1u) != 0u && (L.scene.root_ref & PT_REF_LEAF) == 0u &&
+           L.scene.env_w == ENV_W && L.scene.env_h == ENV_H &&
+           L.service != nullptr && L.un.max_bounces > 0 && L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
+           L.un.res_y >= 9.5367431640625e-07f && L.un.res_y <= 1.099511627776e12f;
+}
+
+// The tuned twins read their service step's scalars from L.service: filled here, in stream order, by one wave.  Its own
+// call so that the caller can put its timing event between this and the raytrace kernel (the little kernel waits for the
+// first wave slot a draining predecessor frees; that wait is not the raytrace kernel's time).
+void launch_raytrace_setup(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
+{
+    if (raytrace_grid_blocks(L.tile) > 0 && launch_is_tuned(L, fuse, variant))
+        hipLaunchKernelGGL(k_rt_service_setup, dim3(1), dim3(64), 0, s, L, L.service);
+}
+
+// (the caller has called launch_raytrace_setup with the same arguments on the same stream)
 void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
 {
     const int blocks = raytrace_grid_blocks(L.tile);
     if (blocks <= 0) return;
     const dim3 block(64);
     if (variant >= 3) {
-        // (SPF1: the shipped walks' batched launches have a specialisation for samplesPerFrame == 1, the reference's
-        // default -- no per-pixel sum and sample counter to carry through the walk: five registers less)
-        const bool one = L.un.samples_per_frame == 1 && !fuse && L.un.max_bounces < 65536 && L.nframes <= 65535;
-        // the tuned twin: no diagnostic buffer and every step-voting knob at its default (baked in as constants there)
-        const bool tuned = one && !L.wave_times && L.walk_min == PT_DEFAULT_WALK_MIN && L.leaf_min == PT_DEFAULT_LEAF_MIN &&
-                           L.shade_split == PT_DEFAULT_SHADE_SPLIT && L.tail_policy == PT_DEFAULT_TAIL_POLICY &&
-                           L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 &&
-                           L.scene.nnodes != 0 && (L.scene.flags & 1u) != 0u && (L.scene.root_ref & PT_REF_LEAF) == 0u &&
-                           L.scene.env_w == ENV_W && L.scene.env_h == ENV_H &&
-                           L.service != nullptr && L.un.max_bounces > 0 && L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
-                           L.un.res_y >= 9.5367431640625e-07f && L.un.res_y <= 1.099511627776e12f;
-        const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu, L.num_cus, tuned && variant >= 9 && variant <= 12));
-        // (the tuned twins read their service step's scalars from L.service: filled here, in stream order, by one wave)
-        if (tuned && (variant >= 9 && variant <= 12)) hipLaunchKernelGGL(k_rt_service_setup, dim3(1), dim3(64), 0, s, L, L.service);
+        const bool one = launch_is_one_spp(L, fuse);
+        const bool tuned = launch_is_tuned(L, fuse, variant);
+        const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu, L.num_cus, tuned));
         if (variant >= 10 && variant <= 12) {            // the culling walk on 4-ary wide packets
             // 11 / 12: the filtered slab test (12: with the one-axis culling condition) in the shipped batched launch; the
             // other launch flavours (fused, diagnostic, samplesPerFrame != 1) run variant 10's exact test -- same bits

@@ -205,8 +205,15 @@ class Renderer:
         return {"supported": True, "info": capi.device_name(0)}
 
     @staticmethod
-    def create(device=0, options=None, tile=None):
-        ctx = capi.Context(device)          # raises "HIP device not found." without a GPU
+    def create(device=0, options=None, tile=None, devices=None):
+        """devices = [0, 1, ...]: a device group (mi3pt_create_group) -- the same Renderer on several GPUs of one
+        node: tiles dealt in 8-row blocks, the scene replicated, one gather when an image is read."""
+        if devices is not None:
+            if tile is not None:
+                raise ValueError("`devices` and `tile` exclude each other (a device group deals the tiles itself)")
+            ctx = capi.Context(devices=list(devices))
+        else:
+            ctx = capi.Context(device)          # raises "HIP device not found." without a GPU
         if tile is not None:
             ctx.set_tile(*tile)
         return Renderer(ctx, options)
