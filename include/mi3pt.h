@@ -292,7 +292,10 @@ typedef enum mi3pt_option {
     MI3PT_OPT_WIDE = 13,       /* 0: `auto` stops at variant 9 */
     MI3PT_OPT_GATE = 14,       /* launches wait for their predecessor's drain mark (1; 0 when a profiler is attached) */
     MI3PT_OPT_SLOT_SETS = 15,  /* sets of per-frame radiance slots, 2 or 3; before mi3pt_resize (2) */
-    MI3PT_OPT_PIPELINE = 16    /* = mi3pt_set_pipelining */
+    MI3PT_OPT_PIPELINE = 16,   /* = mi3pt_set_pipelining */
+    MI3PT_OPT_COST_ORDER = 17  /* a launch's jobs in the order of the tiles' measured cost, costliest first: one launch adds up the path
+                                * segments per 8x8 tile, later launches with the same uniforms run the
+                                * cheapest quarter of the tiles last (0: measured +0.3 % on one GPU, -1.6 ... -4 % for a rank of a tile split) */
 } mi3pt_option;
 int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option /* mi3pt_option */, int value);
 int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option /* mi3pt_option */, int *value);

@@ -865,3 +865,46 @@ def test_triangles_only_upload_after_the_debug_layout_restores_the_uploaded_numb
         ctx.set_packet_layout(0)
         pc.upload_scene(ctx, demo, env)
         ctx.resize(64, 64)
+
+
+@pytest.mark.parametrize("tile,size", [((0, 1), (640, 360)), ((1, 3), (328, 200))])
+def test_cost_ordered_jobs_lose_and_repeat_nothing(gpu_ctx, demo, env, tile, size):
+    """MI3PT_OPT_COST_ORDER (an option; off by default -- it did not pay): the first launch for a set of uniforms adds up the
+    path segments per 8x8 tile, later launches run the cheapest quarter of the tiles last (a permutation of the tiles,
+    chunked into bands), so that a launch's last tickets are its cheapest tiles.  Whatever the order: every pixel of every frame
+    exactly once, image bit-identical to a context with the feature off -- through the measuring launch, the ordered
+    ones, a camera change (measured again, the other permutation buffer) and back."""
+    w, h = size
+    mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+    plain = capi.Context(0)
+    gpu_ctx.set_option(capi.OPT_COST_ORDER, 1)
+    assert gpu_ctx.get_option(capi.OPT_COST_ORDER) == 1 and plain.get_option(capi.OPT_COST_ORDER) == 0
+    try:
+        for ctx in (gpu_ctx, plain):
+            pc.upload_scene(ctx, demo, env)
+            ctx.set_tile(tile[0], tile[1], 8)
+            ctx.resize(w, h)
+            ctx.reset()
+            ctx.reset_counters()
+        frame, total = 2, 0
+        for cam in ((0.0, 1.0, 4.0), (0.0, 1.0, 4.0), (0.0, 1.0, 4.0), (1.5, 0.8, 3.0), (1.5, 0.8, 3.0), (0.0, 1.0, 4.0), (0.0, 1.0, 4.0)):
+            n = 24
+            imgs = []
+            for ctx in (gpu_ctx, plain):
+                kw = dict(position=cam, direction=tuple(-np.array(cam) / np.linalg.norm(cam)))
+                ctx.set_uniforms(capi.PASS_RAYTRACE, pc.rt_uniforms(demo, w, h, frame=frame, bounces=6, **kw).tobytes())
+                ctx.set_uniforms(capi.PASS_ACCUMULATE, pc.acc_uniforms(w, h, frame).tobytes())
+                ctx.submit_frames(mask, n)
+                imgs.append(ctx.read_texture(capi.TEX_ACCUMULATION))
+            frame += n
+            total += n
+            assert pc.same_bits(imgs[0], imgs[1]), f"camera {cam}, frame {frame}: " + pc.describe_diff(imgs[0], imgs[1])
+            a, b = gpu_ctx.counters(), plain.counters()
+            assert a["pixels"] == b["pixels"] == w * gpu_ctx.local_rows * total
+            for k in pc.PATH_COUNTERS:
+                assert a[k] == b[k], (k, a[k], b[k])
+    finally:
+        plain.close()
+        gpu_ctx.set_option(capi.OPT_COST_ORDER, 0)
+        gpu_ctx.set_tile(0, 1, 8)
+        gpu_ctx.resize(64, 64)

@@ -76,6 +76,20 @@ struct mi3pt_ctx {
     // subtree, left subtree) and triangles in leaf-visiting order: a pure relabelling.
     int layout = 0;
     bool layout_dirty = false;      // the relabelling still has to be applied to what was uploaded
+    // Cost order of a launch's jobs (launch_batch): one launch adds up the path segments traced per 8x8 tile (RtLaunch::tile_cost);
+    // when it has finished the tiles are sorted, costliest first, into a permutation that later launches with the same raytrace
+    // uniforms (frame aside) use as their job order (RtLaunch::tile_perm) -- their last tickets are then their cheapest tiles and
+    // the drain after the queue has run empty is short.  Two permutation buffers: a new order never overwrites the one that
+    // launches in flight may still read.  Any order renders the same bits.
+    bool cost_order = false;              // MI3PT_OPT_COST_ORDER: off -- measured ± 0 on one GPU and −1.6 … −4 % for a rank of a split (profiles/r03_h_cost_order.log)
+    int cost_state = 0;                   // 0: nothing measured for the current uniforms, 1: the measuring launch is in flight, 2: a permutation is in use
+    uint32_t *d_tile_cost = nullptr, *d_tile_perm[2] = { nullptr, nullptr };
+    size_t cost_tiles = 0;                // entries of each of the three arrays
+    int perm_cur = 0;
+    hipEvent_t cost_event = nullptr, perm_used[2] = { nullptr, nullptr };
+    bool perm_used_valid[2] = { false, false };
+    hipStream_t cost_stream = nullptr;
+    uint8_t cost_key[MI3PT_RAYTRACE_UNIFORMS_SIZE] = {};
     struct GroupState *group = nullptr;   // mi3pt_create_group: this handle fans every call out to member contexts (end of this file)
     bool tree_proper = false;       // mi3pt_upload_bvh: every node reached once, one leaf per triangle, the 64-entry abort cannot fire
     bool layout_active = false;     // the device holds relabelled packets / triangles
@@ -228,6 +242,7 @@ static int group_unsupported(const char *what);
 template <class F> static int group_each(mi3pt_ctx *g, bool with_present, F fn);
 static int batch_limit(const mi3pt_ctx *ctx, int nranks);
 static int flush_pending(mi3pt_ctx *ctx);
+static int cost_order_collect(mi3pt_ctx *ctx, bool wait);
 static int settle_canvas(mi3pt_ctx *ctx);
 static int check_scene(const mi3pt_ctx *ctx);
 static int prepare_layout(mi3pt_ctx *ctx);
@@ -321,6 +336,9 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     for (int p = 0; p < 3; p++)
         for (int k = 0; k < 2; k++) CREATE_TRY(hipEventCreate(&ctx->ev[p][k]));
     CREATE_TRY(hipEventCreate(&ctx->ev_span_start));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->cost_event, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) CREATE_TRY(hipEventCreateWithFlags(&ctx->perm_used[k], hipEventDisableTiming));
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->cost_stream, hipStreamNonBlocking));
     // environment + CDF textures exist from the start, zero filled (renderer.ts:76-85)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
     CREATE_TRY(hipMalloc(&ctx->d_env, env_bytes));
@@ -358,7 +376,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
             { "MI3PT_JOB_REVERSE", MI3PT_OPT_JOB_REVERSE }, { "MI3PT_JOB_GROUP", MI3PT_OPT_JOB_GROUP }, { "MI3PT_JOB_CHUNK", MI3PT_OPT_JOB_CHUNK },
             { "MI3PT_BATCH_LIMIT", MI3PT_OPT_BATCH_LIMIT }, { "MI3PT_BATCH", MI3PT_OPT_BATCH }, { "MI3PT_WAVES_PER_CU", MI3PT_OPT_WAVES_PER_CU },
             { "MI3PT_CULL", MI3PT_OPT_CULL }, { "MI3PT_WIDE", MI3PT_OPT_WIDE }, { "MI3PT_GATE", MI3PT_OPT_GATE }, { "MI3PT_SLOT_SETS", MI3PT_OPT_SLOT_SETS },
-            { "MI3PT_PIPELINE", MI3PT_OPT_PIPELINE },
+            { "MI3PT_PIPELINE", MI3PT_OPT_PIPELINE }, { "MI3PT_COST_ORDER", MI3PT_OPT_COST_ORDER },
         };
         for (const auto &eo : env_opts)
             if (const char *e = std::getenv(eo.name)) (void)mi3pt_debug_set_option(ctx, eo.opt, std::atoi(e));
@@ -409,6 +427,12 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
         if (ctx->acc_done[k]) (void)hipEventDestroy(ctx->acc_done[k]);
     if (ctx->main_mark) (void)hipEventDestroy(ctx->main_mark);
     if (ctx->ev_span_start) (void)hipEventDestroy(ctx->ev_span_start);
+    if (ctx->cost_event) (void)hipEventDestroy(ctx->cost_event);
+    for (int k = 0; k < 2; k++)
+        if (ctx->perm_used[k]) (void)hipEventDestroy(ctx->perm_used[k]);
+    if (ctx->cost_stream) (void)hipStreamDestroy(ctx->cost_stream);
+    for (void *q : { (void *)ctx->d_tile_cost, (void *)ctx->d_tile_perm[0], (void *)ctx->d_tile_perm[1] })
+        if (q) (void)hipFree(q);
     for (int k = 0; k < 2; k++)
         for (int j = 0; j < 2; j++)
             if (ctx->ev_rt[k][j]) (void)hipEventDestroy(ctx->ev_rt[k][j]);
@@ -510,6 +534,7 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
         ctx->slot_sets = value;
         break;
     case MI3PT_OPT_PIPELINE: ctx->pipeline = value != 0; break;
+    case MI3PT_OPT_COST_ORDER: ctx->cost_order = value != 0; ctx->cost_state = 0; break;
     default:
         return pt_set_error(MI3PT_ERR_INVALID, "unknown option");
     }
@@ -538,6 +563,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_GATE: *value = ctx->gate_enabled ? 1 : 0; break;
     case MI3PT_OPT_SLOT_SETS: *value = ctx->slot_sets; break;
     case MI3PT_OPT_PIPELINE: *value = ctx->pipeline ? 1 : 0; break;
+    case MI3PT_OPT_COST_ORDER: *value = ctx->cost_order ? 1 : 0; break;
     default:
         return pt_set_error(MI3PT_ERR_INVALID, "unknown option");
     }
@@ -623,6 +649,7 @@ extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t 
     ctx->ntris = n;
     ctx->max_mat_ref = max_mat;
     ctx->cull_dirty = true;
+    ctx->cost_state = 0;            // (the tiles' costs were measured on another scene)
     if (ctx->layout_active && ctx->nnodes > 0) {
         // The device holds node packets, leaf ranks and the root reference in the visiting-order numbering of the debug
         // layout, while the triangles just uploaded are in uploaded order again: rebuild the tree's side from the node
@@ -823,6 +850,7 @@ extern "C" int mi3pt_upload_bvh(mi3pt_ctx *ctx, const void *bytes, size_t nbytes
     ctx->scene_flags = node_box_safe(src, 0) ? 1u : 0u;
     ctx->max_tri_ref = max_tri;
     ctx->cull_dirty = true;
+    ctx->cost_state = 0;            // (the tiles' costs were measured on another scene)
     ctx->layout_active = false;
     ctx->layout_dirty = ctx->layout != 0;
     return MI3PT_OK;
@@ -1078,6 +1106,7 @@ static int prepare_layout(mi3pt_ctx *ctx)
     ctx->layout_dirty = false;
     ctx->cull_ok = false;           // the analysis below works on the uploaded numbering
     ctx->cull_dirty = true;
+    ctx->cost_state = 0;            // (the tiles' costs were measured on another scene)
     ctx->main_dirty = true;
     return MI3PT_OK;
 }
@@ -1489,6 +1518,8 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.waves_per_cu = ctx->waves_per_cu;
     L.num_cus = ctx->num_cus;
     L.service = nullptr;          // (batched launches: a slot of the context's ring, see launch_batch)
+    L.tile_cost = nullptr;        // (batched launches: launch_batch)
+    L.tile_perm = nullptr;
     L.top_packets = ctx->top_packets;
     if (pick_variant(ctx) == 1) L.scene.tris = static_cast<const float4 *>(ctx->d_tris);    // uploaded records, uploaded indices
     return L;
@@ -1568,6 +1599,78 @@ static int ensure_slots(mi3pt_ctx *ctx, int par /* slot set */, int n)
     return MI3PT_OK;
 }
 
+// The measuring launch has finished (or `wait`): build this rank's job order from the segments its tiles' paths traced, into the
+// permutation buffer that is not in use.
+static int cost_order_collect(mi3pt_ctx *ctx, bool wait)
+{
+    if (ctx->cost_state != 1) return MI3PT_OK;
+    if (!wait) {
+        const hipError_t q = hipEventQuery(ctx->cost_event);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return MI3PT_OK; }
+        if (q != hipSuccess) { (void)hipGetLastError(); ctx->cost_state = 0; return MI3PT_OK; }
+    }
+    const size_t n = ctx->cost_tiles;
+    const int target = ctx->perm_cur ^ 1;
+    ctx->cost_state = 0;        // (whatever goes wrong below: no order, measure again)
+    std::vector<uint32_t> cost(n), perm(n);
+    HIP_TRY(hipStreamWaitEvent(ctx->cost_stream, ctx->cost_event, 0));
+    HIP_TRY(hipMemcpyAsync(cost.data(), ctx->d_tile_cost, n * 4, hipMemcpyDeviceToHost, ctx->cost_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->cost_stream));
+    if (ctx->perm_used_valid[target]) HIP_TRY(hipEventSynchronize(ctx->perm_used[target]));      // (long done: two orders ago)
+    // The order: the image's tiles from the bottom row up, as without the feature (what neighbouring waves fetch stays
+    // close together: sorting ALL tiles by cost scattered them and cost 5 % -- profiles/r03_h_cost_order.log), except that
+    // the cheapest quarter of the tiles is taken out and appended: the launch's last bands are then its cheapest tiles
+    // wherever they lie in the image.
+    std::vector<uint32_t> sorted(cost);
+    const size_t q = n / 4;
+    std::nth_element(sorted.begin(), sorted.begin() + (std::ptrdiff_t)q, sorted.end());
+    const uint32_t cut = sorted[q];          // tiles cheaper than this go last (ties stay in the main part)
+    size_t at = 0;
+    for (size_t t = n; t-- > 0;) if (cost[t] >= cut) perm[at++] = (uint32_t)t;
+    for (size_t t = n; t-- > 0;) if (cost[t] < cut) perm[at++] = (uint32_t)t;
+    HIP_TRY(hipMemcpyAsync(ctx->d_tile_perm[target], perm.data(), n * 4, hipMemcpyHostToDevice, ctx->cost_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->cost_stream));
+    ctx->perm_cur = target;
+    ctx->cost_state = 2;
+    return MI3PT_OK;
+}
+
+// Sets the launch's cost-order fields; `*measuring` / `*ordered`: what to record behind the launch.
+static int cost_order_prepare(mi3pt_ctx *ctx, pt::RtLaunch &L, const uint8_t *u_rt, int variant, hipStream_t rs, bool *measuring, bool *ordered)
+{
+    *measuring = *ordered = false;
+    const size_t n = (size_t)pt::raytrace_grid_blocks(L.tile);
+    if (!ctx->cost_order || variant < 9 || variant > 12 || L.un.samples_per_frame != 1 || n < 2) return MI3PT_OK;
+    uint8_t key[MI3PT_RAYTRACE_UNIFORMS_SIZE];
+    std::memcpy(key, u_rt, sizeof key);
+    std::memset(key + 12, 0, 4);          // the frame counter
+    if (ctx->cost_tiles != n) {           // (resize / tile change: new arrays)
+        HIP_TRY(hipStreamSynchronize(ctx->rt_stream[0]));
+        HIP_TRY(hipStreamSynchronize(ctx->rt_stream[1]));
+        for (uint32_t **q : { &ctx->d_tile_cost, &ctx->d_tile_perm[0], &ctx->d_tile_perm[1] }) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+            HIP_TRY(hipMalloc((void **)q, n * 4));
+        }
+        ctx->cost_tiles = n;
+        ctx->cost_state = 0;
+        ctx->perm_used_valid[0] = ctx->perm_used_valid[1] = false;
+    }
+    if (ctx->cost_state != 0 && std::memcmp(key, ctx->cost_key, sizeof key) != 0) ctx->cost_state = 0;      // the camera moved, bounces changed ...
+    if (int rc = cost_order_collect(ctx, false)) return rc;
+    if (ctx->cost_state == 0) {
+        std::memcpy(ctx->cost_key, key, sizeof key);
+        HIP_TRY(hipMemsetAsync(ctx->d_tile_cost, 0, n * 4, rs));
+        L.tile_cost = ctx->d_tile_cost;
+        *measuring = true;
+    } else if (ctx->cost_state == 2) {
+        L.tile_perm = ctx->d_tile_perm[ctx->perm_cur];
+        L.job_reverse = 0;                // the order is the permutation's: costliest first
+        *ordered = true;
+    }
+    return MI3PT_OK;
+}
+
 // One launch: frames [first, first + n) of the queue as one raytrace kernel over (frame slot,
 // tile) jobs on this parity's side stream, then the ordered multi-frame running mean on the
 // main stream.
@@ -1600,6 +1703,8 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame &first, in
     L.tile_counter = ctx->d_tile_counter + par * 32;
     L.stack_overflow = ctx->d_stack_overflow + (size_t)par * pt::PT_MAX_RESIDENT_WAVES * pt::SM_OVERFLOW_ENTRIES * 64;
     L.service = reinterpret_cast<pt::RtService *>(ctx->d_service + (size_t)((ctx->seq - 1) % SERVICE_SLOTS) * service_slot_bytes());
+    bool cost_measuring = false, cost_ordered = false;
+    if (int rc = cost_order_prepare(ctx, L, first.u_rt, pick_variant(ctx), rs, &cost_measuring, &cost_ordered)) return rc;
     if (ctx->timing)
         if (int rc = collect_rt_time(ctx, par)) return rc;      // the launch of two batches ago
     // Hold this launch until the previous one (on the other stream) has handed out its last job:
@@ -1625,6 +1730,8 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame &first, in
         if (!ctx->span_started) { HIP_TRY(hipEventRecord(ctx->ev_span_start, rs)); ctx->span_started = true; }
     }
     pt::launch_raytrace(L, false, pick_variant(ctx), rs);
+    if (cost_measuring && launches) { HIP_TRY(hipEventRecord(ctx->cost_event, rs)); ctx->cost_state = 1; }
+    if (cost_ordered && launches) { HIP_TRY(hipEventRecord(ctx->perm_used[ctx->perm_cur], rs)); ctx->perm_used_valid[ctx->perm_cur] = true; }
     if (hipError_t e = hipGetLastError()) {
         // The kernel that would have published drain_seq never ran: publish it from the host side
         // of the stream instead, so that neither a later launch nor mi3pt_destroy waits for it.
@@ -1830,7 +1937,7 @@ extern "C" int mi3pt_sync(mi3pt_ctx *ctx)
     PT_GROUP(ctx, group_sync(ctx));
     if (int rc = require_idle(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return MI3PT_OK;
+    return cost_order_collect(ctx, false);      // (a measuring launch has finished by now: its job order is ready for the next launch)
 }
 
 extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t nfloats)

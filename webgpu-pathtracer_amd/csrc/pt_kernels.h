@@ -193,6 +193,11 @@ struct RtLaunch {
     int32_t top_packets;         // node packets to stage in LDS per wave (0..64)
     int32_t waves_per_cu;        // persistent kernels: resident one-wave workgroups per CU
     int32_t num_cus;             // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+    uint32_t *tile_cost;         // state-machine kernel, or null: [tiles of this rank's frame] path segments traced per 8x8 tile, added up by
+                                 // this launch (one atomic per finished path) -- the cost feedback behind tile_perm
+    const uint32_t *tile_perm;   // state-machine kernel, or null: position in the job order -> tile of the frame; the context sorts
+                                 // the tiles by measured cost, costliest first, so that a launch's last tickets are its cheapest
+                                 // tiles and the drain after the queue has run empty is short (any order renders the same bits)
     RtService *service;          // device memory for one RtService block (service_block_bytes()), or null: the tuned twin of the
                                  // state-machine kernel reads its service step's scalars from it (launch_raytrace fills it first)
 };

@@ -1042,7 +1042,7 @@ struct RtService {
     int32_t pinhole, res_ordinary;
     int32_t tiles_x, ntiles_frame, ntiles;
     int32_t grp_jobs, grp_full, grp_last;
-    FastDiv dv_frame, dv_grp, dv_gs, dv_last, dv_tx;
+    FastDiv dv_frame, dv_grp, dv_gs, dv_last, dv_tx, dv_w;
 };
 static_assert(sizeof(RtService) % 4 == 0, "loaded as dwords");
 size_t service_block_bytes() { return sizeof(RtService); }
@@ -1085,6 +1085,7 @@ PT_DEV RtService compute_service(const RtLaunch &L, bool scene_has_nodes)
     S.dv_gs = fast_div_of((uint32_t)(L.job_group > 0 ? L.job_group : 1));
     S.dv_last = fast_div_of((uint32_t)(S.grp_last > 0 ? S.grp_last : 1));
     S.dv_tx = fast_div_of((uint32_t)S.tiles_x);
+    S.dv_w = fast_div_of((uint32_t)(L.tile.tex_w > 0 ? L.tile.tex_w : 1));
     return S;
 }
 
@@ -1756,6 +1757,10 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     if constexpr (SPF1) {
                         // one sample per frame: the pixel is finished (:455, :477); incomingLight = 0 + light
                         write_radiance(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
+                        if (L.tile_cost) {      // a measuring launch: this path's segments go to its tile's cost
+                            const int row = fast_div((int)gx, S.dv_w), col = (int)gx - row * L.tile.tex_w;
+                            atomicAdd(L.tile_cost + ((row >> 3) * S.tiles_x + (col >> 3)), (slot & 0xffffu) + 1u);
+                        }
                     } else {
                         incoming = incoming + light;
                         sample++;
@@ -1801,6 +1806,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                         cur_fslot = last ? fast_div(r, dv_last) : fast_div(r, dv_gs);
                         cur_ftile = g * L.job_group + (r - cur_fslot * gs);
                     }
+                    if (L.tile_perm) cur_ftile = (int)L.tile_perm[cur_ftile];      // cost order (a scalar load: the position is wave-uniform)
                     have_at++;
                     if (--have == 0) draw(S);
                     cur_used = 0;
