@@ -480,13 +480,15 @@ def main():
                     dist.gather(send, gathered, dst=0)
 
         per_launch = frames_per_launch(ctx.batch_capacity())
-        job.frames(warmup * FRAMES_PER_STEP, per_launch)
-        ctx.sync()
         if send is not None and warmup > 0:
-            # warm-up of the exchange too: the first gather on a communicator sets up RCCL's
-            # point-to-point channels (tens of ms), which is not part of a steady-state job
+            # warm-up of the exchange: the first gather on a communicator sets up RCCL's point-to-point channels (tens of
+            # ms), which is not part of a steady-state job.  BEFORE the warm-up steps, so that those end right in front of
+            # the timed region: a GPU that has idled for some tens of ms runs its next 12 ms job ~1 ms slower
+            # (profiles/r03_h_first_job.log)
             exchange()
             sync_all()
+        job.frames(warmup * FRAMES_PER_STEP, per_launch)
+        ctx.sync()
         ctx.reset_counters()
         warm_ms, warm_launches, _ = ctx.raytrace_launch_stats()      # (the warm-up's launches: for the all-launch average below)
         ctx.raytrace_launch_stats(reset=True)

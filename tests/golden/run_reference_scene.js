@@ -8,6 +8,9 @@
 // GPUQueue.writeBuffer with what this repository's RaytracePass + native builder produce for the
 // same scene.
 //   node run_reference_scene.js <reference-root> <demo|model> [model-file]
+//   node run_reference_scene.js - <demo|model> [model-file]     this repository's side only (sizes and SHA-256 of its buffers):
+//                                                               what tests/golden/reference_scene_hashes.json is compared with where
+//                                                               there is no reference checkout
 const fs = require('fs');
 const path = require('path');
 const pt = require(path.join(__dirname, '..', '..', 'webgpu-pathtracer_amd', 'js'));
@@ -141,10 +144,17 @@ if (which === 'model') {
 }
 scene.needsUpdate = true;
 const mine = runMine(scene, camera);
+const sha = (b) => require('crypto').createHash('sha256').update(b).digest('hex');
+if (root === '-') {
+  console.log(JSON.stringify({ triangles: mine.triangles.length / 112, nodes: mine.nodes.length / 48, materials: mine.materials.length / 64,
+    mine: { triangles: sha(mine.triangles), materials: sha(mine.materials), nodes: sha(mine.nodes), camera: mine.camera } }));
+  process.exit(0);
+}
 scene.needsUpdate = true;
 const ref = runReference(root, scene, camera);
 const same = (a, b) => a.length === b.length && a.equals(b);
 console.log(JSON.stringify({
+  reference: { triangles: sha(ref.written.triangles), materials: sha(ref.written.materials), nodes: sha(ref.written.nodes), camera: ref.camera },
   triangles: mine.triangles.length / 112, nodes: mine.nodes.length / 48, materials: mine.materials.length / 64,
   trianglesEqual: same(mine.triangles, ref.written.triangles), materialsEqual: same(mine.materials, ref.written.materials),
   nodesEqual: same(mine.nodes, ref.written.nodes), cameraEqual: JSON.stringify(mine.camera) === JSON.stringify(ref.camera),
