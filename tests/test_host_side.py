@@ -118,6 +118,12 @@ def test_no_device_means_error_not_fallback(built):
     assert Renderer.diagnostic() == {"supported": False}
     with pytest.raises(capi.Mi3ptError):
         Renderer.create()
+    with pytest.raises(capi.Mi3ptError) as e:          # a device group fails the same way: no member can be created
+        capi.Context(devices=[0, 1])
+    assert e.value.code == 2 and "HIP device not found" in e.value.message
+    with pytest.raises(capi.Mi3ptError) as e:
+        capi.Context(devices=[])
+    assert e.value.code == 1
 
 
 def test_host_argument_validation(built):
