@@ -2450,9 +2450,15 @@ static int group_gather(mi3pt_ctx *g)
         const uint8_t *src = reinterpret_cast<const uint8_t *>(m->d_accum);
         const int rows = m->local_rows;
         const int full = rows / br, tail = rows - full * br;      // whole blocks, rows of a last partial block (the image's bottom edge)
-        if (full > 0)
-            HIP_TRY(hipMemcpy2DAsync(dst + (size_t)i * block_bytes, (size_t)n * block_bytes, src, block_bytes, block_bytes, (size_t)full,
-                                     hipMemcpyDeviceToDevice, p->stream));
+        if (full > 0 &&
+            hipMemcpy2DAsync(dst + (size_t)i * block_bytes, (size_t)n * block_bytes, src, block_bytes, block_bytes, (size_t)full,
+                             hipMemcpyDeviceToDevice, p->stream) != hipSuccess) {
+            // (no strided copy between these two devices: block by block through the runtime's peer path)
+            (void)hipGetLastError();
+            for (int b = 0; b < full; b++)
+                HIP_TRY(hipMemcpyPeerAsync(dst + ((size_t)b * (size_t)n + (size_t)i) * block_bytes, p->device, src + (size_t)b * block_bytes, m->device,
+                                           block_bytes, p->stream));
+        }
         if (tail > 0) {
             const size_t grow = ((size_t)full * (size_t)n + (size_t)i) * (size_t)br;      // global row of the partial block
             if ((int)grow + tail > H) return pt_set_error(MI3PT_ERR_STATE, "gather: tile geometry mismatch");
