@@ -50,6 +50,7 @@ struct mi3pt_ctx {
     size_t ntris = 0, nnodes = 0, nmats = 0, npackets = 0;
     uint32_t root_ref = 0;
     uint32_t scene_flags = 0;
+    bool wide_root_nested = false;  // prepare_cull: the root's box contains its children's boxes (the wide walk may skip the root test)
     int64_t max_tri_ref = -1;       // largest triangleIndex referenced by a leaf
     int64_t max_mat_ref = -1;       // largest materialIndex referenced by a triangle
     // distance-culling walk (kernel variant 9): per-child |e1||e2| bounds in the packets' `cull` field
@@ -1019,6 +1020,7 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.npackets = (uint32_t)ctx->npackets;
     s.root_ref = ctx->root_ref;
     s.flags = ctx->scene_flags;
+    if (ctx->wide_ok && ctx->wide_root_nested) s.flags |= 2u;      // (pt_kernels.h SceneRefs::flags bit 1)
     s.cull_ka = ctx->cull_ka; s.cull_kb = ctx->cull_kb;
 #ifdef MI3PT_EXPERIMENTS
     if (ctx->exp_force_slow_slab) s.flags = 0;
@@ -1385,6 +1387,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
             ctx->wide_leaf_cap = pt::SM_CULL_LEAF_CAP;
             ctx->wide_root = 0;
             ctx->wide_ok = true;
+            ctx->wide_root_nested = nested[0] != 0;
         }
     }
     // ---- which wide walk `auto` means for this scene (variants 10 / 11 / 12 render the same bits; this is speed only).

@@ -115,7 +115,8 @@ struct SceneRefs {
     int32_t env_sampling;   // 1: the reference's dormant importance-sampling lines run (per-pixel kernels only)
     uint32_t ntris, nnodes, nmats, npackets;
     uint32_t root_ref;      // reference of node 0 in packet terms
-    uint32_t flags;         // bit0: every ROOT box coordinate is 0 or within [2^-70, 2^60]
+    uint32_t flags;         // bit0: every ROOT box coordinate is 0 or within [2^-70, 2^60]; bit1 (wide packets): the root's box contains the
+                            // boxes of its children, so the wide walk may start at the root packet without testing the root's own box
     float cull_ka, cull_kb; // CULL walk: scene constants of the distance bound (pt_kernels.hip cull_setup; context: prepare_cull)
     int32_t env_w, env_h;
 };

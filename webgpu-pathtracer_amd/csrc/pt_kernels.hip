@@ -1933,7 +1933,14 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 slow_segment = (pre.flags & 8u) != 0u;
                 if (CULL) cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
                 
-                if (ray_aabb_pre(o, d, pre, !TUNED && (sc.flags & 1u) == 0u, S.root_mn[0], S.root_mn[1], S.root_mn[2], S.root_mx[0], S.root_mx[1], S.root_mx[2])) {
+                // (WIDE, root box nested: a ray that the reference's root test (raytrace.wgsl:160-164) rejects is rejected by every box of
+                // the root packet too -- the fp32 slab test is monotone under nesting, the argument of the wide collapse -- so the test
+                // is left to the first node step: bounce rays start inside the scene's box and pass it practically always, and its
+                // ~45 exact-slab instructions were paid by every segment.  Measured +1.5 % / +1.9 %.  Going further -- the root PACKET's
+                // four box tests in the segment start, from scalars of the service block: one node step less per segment, but 230
+                // more instructions in the issue-bound service step -- lost 6 %: profiles/r03_i_skip_root_ab.log)
+                const bool skip_root = WIDE && (sc.flags & 2u) != 0u;
+                if (skip_root || ray_aabb_pre(o, d, pre, !TUNED && (sc.flags & 1u) == 0u, S.root_mn[0], S.root_mn[1], S.root_mn[2], S.root_mx[0], S.root_mx[1], S.root_mx[2])) {
                     if (!TUNED && DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
                         stack[(DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu;
                         sp = 0; nl = 1;
