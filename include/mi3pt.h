@@ -91,8 +91,11 @@ typedef enum mi3pt_storage {
 /* what a submit that includes MI3PT_SUBMIT_FULLSCREEN shows (mi3pt_set_present_mode) */
 typedef enum mi3pt_present_mode {
     MI3PT_PRESENT_EXACT = 0,     /* the canvas is drawn from the running mean INCLUDING this submit's frame:
-                                    renderer.ts:379-390 as written.  The frame queue is launched first, so a
-                                    loop that presents every frame runs one raytrace launch per frame. */
+                                    renderer.ts:379-390 as written, one accumulate pass and one fullscreen pass
+                                    per presenting frame, in frame order.  The frames' raytrace passes are
+                                    launched together, up to MI3PT_OPT_PRESENT_DEPTH (16) frames at a time,
+                                    when the queue is that deep or the context is observed (read-back, sync,
+                                    flush): nothing that can be read differs from a launch per frame. */
     MI3PT_PRESENT_LATEST = 1     /* headless hosts: the frame is queued like any other; the canvas is drawn
                                     from the running mean of the batches launched so far, and only when that
                                     mean or the fullscreen uniforms changed since the last draw.  A submit
@@ -293,6 +296,8 @@ typedef enum mi3pt_option {
     MI3PT_OPT_GATE = 14,       /* launches wait for their predecessor's drain mark (1; 0 when a profiler is attached) */
     MI3PT_OPT_SLOT_SETS = 15,  /* sets of per-frame radiance slots, 2 or 3; before mi3pt_resize (2) */
     MI3PT_OPT_PIPELINE = 16,   /* = mi3pt_set_pipelining */
+    MI3PT_OPT_PRESENT_DEPTH = 18, /* MI3PT_PRESENT_EXACT: presenting frames that share one raytrace launch, >= 1 (16); each still
+                                   * gets its own accumulate and fullscreen pass, in order -- 1 = also its own launch */
     MI3PT_OPT_COST_ORDER = 17  /* a launch's jobs in the order of the tiles' measured cost, costliest first: one launch adds up the path
                                 * segments per 8x8 tile, later launches with the same uniforms run the
                                 * cheapest quarter of the tiles last (0: measured +0.3 % on one GPU, -1.6 ... -4 % for a rank of a tile split) */

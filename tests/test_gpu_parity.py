@@ -473,6 +473,40 @@ def test_fullscreen_pass(gpu_ctx, orc, demo, env, denoise, tonemapping, scaling)
     assert np.array_equal(got_8, want_8)
 
 
+@pytest.mark.parametrize("w,h", [(100, 70), (33, 17), (16, 16), (5, 3), (1, 1)])
+@pytest.mark.parametrize("scaling,res_scale", [(1.0, 1.0), (0.37, 1.0), (1.0, 0.37), (1.5, 1.0), (1.0, 3.0)])
+def test_denoise_over_written_textures(gpu_ctx, orc, w, h, scaling, res_scale):
+    """The de-noise pass reads a block's texels from an LDS copy when every tap of a wave lies inside it and from the
+    texture otherwise (pt_kernels.hip, "the de-noise pass over an LDS copy"): images smaller than the copy (repeat
+    addressing inside it), a scaling factor and resolution uniforms that push taps outside, and texels of every
+    magnitude -- noise, flat areas (equal colours: the range weight's exp(0)), zeros, 1e30 and 1e-30 (the weight's
+    argument beyond exp's underflow, and products that vanish) -- each against the oracle bit for bit
+    (fullscreen.wgsl:53-86, 109-132)."""
+    ctx = gpu_ctx
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    rng = np.random.default_rng(w * 1000 + h)
+    tex = rng.random((h, w, 4), dtype=np.float32) * np.float32(2.0)
+    tex[..., 3] = 1.0
+    tex[: h // 3] = np.float32(0.25) + rng.random((h // 3, w, 4), dtype=np.float32) * np.float32(0.05)      # smooth: weights far from 0
+    tex[h // 2:, : w // 4, :3] = 0.0
+    if h > 4 and w > 4:
+        tex[h - 2, w - 2, :3] = np.float32(1e30)
+        tex[1, 1, :3] = np.float32(1e-30)
+        tex[2, 3, 0] = np.float32(-3.0)
+    ctx.write_texture(capi.TEX_ACCUMULATION, tex)
+    f = layout.UniformBlock(layout.FULLSCREEN_UNIFORMS)
+    f.set({"resolution": [w * res_scale, h * res_scale], "aspect": w / h, "scalingFactor": scaling, "denoise": 1, "tonemapping": 1})
+    ctx.set_uniforms(capi.PASS_FULLSCREEN, f.tobytes())
+    ctx.submit(capi.SUBMIT_FULLSCREEN)
+    got_f = ctx.read_texture(capi.TEX_CANVAS)
+    got_8 = ctx.read_canvas_rgba8()
+    want_f, want_8 = orc.fullscreen(f.tobytes(), tex)
+    assert pc.same_bits(got_f, want_f), pc.describe_diff(got_f, want_f)
+    assert np.array_equal(got_8, want_8)
+    ctx.resize(64, 64)
+
+
 @pytest.mark.parametrize("nranks,block_rows", [(2, 8), (4, 8), (8, 8), (3, 5)])
 def test_tile_split_reassembles_to_whole_image(gpu_ctx, orc, demo, env, nranks, block_rows):
     """Each rank's compact rows, de-interleaved, must equal the single-GPU image
@@ -715,6 +749,64 @@ def test_present_latest_shows_every_frame_once_the_canvas_is_looked_at(gpu_ctx, 
     want_f32, want_8 = orc.fullscreen(fs.tobytes(), acc)
     assert pc.same_bits(canvases[capi.PRESENT_LATEST][1], want_f32)
     assert np.array_equal(canvases[capi.PRESENT_LATEST][0], want_8)
+    ctx.resize(64, 64)
+
+
+@pytest.mark.parametrize("depth", [5, 16, 64])
+def test_exact_presentation_shares_launches_without_a_trace(gpu_ctx, orc, demo, env, depth):
+    """MI3PT_PRESENT_EXACT draws the canvas behind every presenting frame's own accumulate pass; up to
+    MI3PT_OPT_PRESENT_DEPTH such frames share a raytrace launch.  Nothing that can be read differs from depth 1 (a
+    launch per frame): canvases and means at two read-backs (the first in the middle of a group), with the fullscreen
+    uniforms changing from frame to frame and a frame that does not present in between -- and the last canvas is the
+    oracle's (renderer.ts:379-390)."""
+    w, h, frames = 80, 56, 23
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    ctx.set_present_mode(capi.PRESENT_EXACT)
+    everything = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE | capi.SUBMIT_FULLSCREEN
+
+    def fs_of(f):
+        return pc.fs_uniforms(w, h, 1.0, f % 2, 1 + f % 2)
+
+    seen = {}
+    for d in (1, depth):
+        ctx.set_option(capi.OPT_PRESENT_DEPTH, d)
+        assert ctx.get_option(capi.OPT_PRESENT_DEPTH) == d
+        ctx.reset()
+        ctx.enable_timing(True)
+        ctx.raytrace_launch_stats(reset=True)
+        shots = []
+        for f in range(2, 2 + frames):
+            ctx.set_uniforms(capi.PASS_FULLSCREEN, fs_of(f).tobytes())
+            mask = everything if f != 11 else capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+            pc.gpu_frame(ctx, pc.rt_uniforms(demo, w, h, frame=f, bounces=4), pc.acc_uniforms(w, h, f), mask)
+            if f in (8, 11, 1 + frames):
+                shots.append((ctx.read_canvas_rgba8(), ctx.read_texture(capi.TEX_CANVAS), ctx.read_texture(capi.TEX_ACCUMULATION)))
+        seen[d] = shots
+        _, launches, nframes = ctx.raytrace_launch_stats()
+        assert nframes == frames
+        # read-backs after frames 8, 11 and 24 cut the queue: 7 + 3 + 13 frames
+        assert launches == sum(-(-n // d) for n in (7, 3, 13))
+        ctx.enable_timing(False)
+    ctx.set_option(capi.OPT_PRESENT_DEPTH, 16)
+    for a, b in zip(seen[1], seen[depth]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+    # frame 11 did not present: the canvas read behind it is frame 10's (drawn with frame 10's uniforms) ...
+    osc = pc.oracle_scene(orc, demo, env)
+    acc = np.zeros((h, w, 4), np.float32)
+    for f in range(2, 2 + frames):
+        img, _ = orc.raytrace(osc, pc.rt_uniforms(demo, w, h, frame=f, bounces=4).tobytes(), w, h)
+        acc = orc.accumulate(pc.acc_uniforms(w, h, f).tobytes(), w, h, img, acc)
+        if f == 10:
+            want10, _ = orc.fullscreen(fs_of(10).tobytes(), acc)
+    assert pc.same_bits(seen[depth][1][1], want10)
+    # ... and the last one is the last frame's
+    want_f32, want_8 = orc.fullscreen(fs_of(1 + frames).tobytes(), acc)
+    assert pc.same_bits(seen[depth][2][1], want_f32) and np.array_equal(seen[depth][2][0], want_8)
+    assert pc.same_bits(seen[depth][2][2], acc)
     ctx.resize(64, 64)
 
 

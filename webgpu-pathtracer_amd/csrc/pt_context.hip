@@ -124,6 +124,9 @@ struct mi3pt_ctx {
     bool gate_enabled = false;            // launches wait on d_drain_flag (off when the memory or the wait is unavailable)
     uint32_t launch_seq = 0;              // sequence number of the last batched launch
     uint32_t *d_stack_overflow = nullptr; // [2 parities][PT_MAX_RESIDENT_WAVES][SM_OVERFLOW_ENTRIES][64] overflow stack entries
+    void *d_fs_taps = nullptr;            // the de-noise pass's tap table (pt::launch_fullscreen), built for fs_taps_res
+    float fs_taps_res[2] = { 0.0f, 0.0f };
+    bool fs_taps_valid = false;
     uint8_t *d_service = nullptr;         // ring of SERVICE_SLOTS pt::RtService blocks: one per batched launch in flight (launch_batch)
     uint64_t *d_wave_times = nullptr;     // diagnostic stamps, allocated by mi3pt_debug_wave_times(enable)
     int wave_times_slots = 0;
@@ -157,7 +160,11 @@ struct mi3pt_ctx {
     // frames (identical uniforms except `frame`) run as ONE raytrace launch + one ordered
     // multi-frame accumulate, so the persistent kernel's drain tail is paid once per batch.
     // Anything that observes or changes device state flushes the queue first.
-    struct PendingFrame { uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE]; uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE]; };
+    struct PendingFrame {
+        uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE]; uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE];
+        bool present = false;                                   // EXACT: the canvas is drawn after this frame's mean ...
+        uint8_t u_fs[MI3PT_FULLSCREEN_UNIFORMS_SIZE] = {};      // ... with the pass's uniforms as they were at its submit
+    };
     std::vector<PendingFrame> pending;
     int batch_max = 64;                  // MI3PT_BATCH (1 = no batching); x nranks for a tile split, see batch_limit().  16 -> 32: +3 % (fewer drains), 32 -> 64: +2 %, 64 -> 128: +1 %
     // per-launch GPU time of the batched raytrace kernel (HIP events on its own stream)
@@ -170,12 +177,14 @@ struct mi3pt_ctx {
     hipEvent_t ev_span_start = nullptr;  // start of the first timed launch since the statistics were reset
     bool span_started = false;
 
-    // Presentation (mi3pt_set_present_mode).  EXACT: a submit that includes FULLSCREEN launches the
-    // queue first, so the canvas shows this very frame (the reference's renderer.ts:379-390).
+    // Presentation (mi3pt_set_present_mode).  EXACT: every submit that includes FULLSCREEN gets its own accumulate and
+    // fullscreen pass, in order, the canvas drawn from the mean up to and including that frame (the reference's
+    // renderer.ts:379-390); up to present_depth such frames share one raytrace launch (launch_batch).
     // LATEST: the frame is queued like any other and the canvas is drawn from the running mean of
     // the batches launched so far -- and only when that mean (or the fullscreen uniforms) changed
     // since the last draw; a FULLSCREEN-only submit always launches the queue and shows everything.
     int present_mode = MI3PT_PRESENT_EXACT;
+    int present_depth = 16;              // EXACT: presenting frames per raytrace launch (1 = a launch per frame)
     uint64_t accum_version = 1;          // bumped whenever d_accum (or what `output` points at) changes
     uint64_t presented_version = 0;      // accum_version the canvas was last drawn from
     bool want_present = false;           // LATEST: a requested draw is still owed to the canvas (frames were queued)
@@ -347,6 +356,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     CREATE_TRY(hipMalloc((void **)&ctx->d_tile_counter, 256));
     CREATE_TRY(hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * pt::SM_OVERFLOW_ENTRIES * 64 * 4));
     CREATE_TRY(hipMalloc((void **)&ctx->d_service, (size_t)SERVICE_SLOTS * service_slot_bytes()));
+    CREATE_TRY(hipMalloc(&ctx->d_fs_taps, pt::fullscreen_taps_bytes()));
     CREATE_TRY(hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream));     // self-cleaning afterwards
     // a word the command processor can poll (hipStreamWaitValue32) and a running kernel can write;
     // optional: without it launches simply queue behind each other
@@ -415,7 +425,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     free_textures(ctx);
     for (void *p : { ctx->d_wide, ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
-                     (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow, (void *)ctx->d_service })
+                     (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow, (void *)ctx->d_service, ctx->d_fs_taps })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
         for (int k = 0; k < 2; k++)
@@ -536,6 +546,10 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
         break;
     case MI3PT_OPT_PIPELINE: ctx->pipeline = value != 0; break;
     case MI3PT_OPT_COST_ORDER: ctx->cost_order = value != 0; ctx->cost_state = 0; break;
+    case MI3PT_OPT_PRESENT_DEPTH:
+        if (value < 1) return pt_set_error(MI3PT_ERR_INVALID, "present depth must be >= 1");
+        ctx->present_depth = value;
+        break;
     default:
         return pt_set_error(MI3PT_ERR_INVALID, "unknown option");
     }
@@ -565,6 +579,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_SLOT_SETS: *value = ctx->slot_sets; break;
     case MI3PT_OPT_PIPELINE: *value = ctx->pipeline ? 1 : 0; break;
     case MI3PT_OPT_COST_ORDER: *value = ctx->cost_order ? 1 : 0; break;
+    case MI3PT_OPT_PRESENT_DEPTH: *value = ctx->present_depth; break;
     default:
         return pt_set_error(MI3PT_ERR_INVALID, "unknown option");
     }
@@ -1677,8 +1692,11 @@ static int cost_order_prepare(mi3pt_ctx *ctx, pt::RtLaunch &L, const uint8_t *u_
 // One launch: frames [first, first + n) of the queue as one raytrace kernel over (frame slot,
 // tile) jobs on this parity's side stream, then the ordered multi-frame running mean on the
 // main stream.
-static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame &first, int n)
+static int run_fullscreen(mi3pt_ctx *ctx, const uint8_t *u_fs);
+
+static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame *frames, int n)
 {
+    const mi3pt_ctx::PendingFrame &first = frames[0];
     const pt::AccUniforms acc = acc_from(first.u_acc);
     pt::RtLaunch L = build_launch(ctx, first.u_rt, acc);
     const bool f16 = ctx->storage == MI3PT_STORAGE_F16;
@@ -1753,15 +1771,27 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame &first, in
     }
     HIP_TRY(hipEventRecord(ctx->rt_done[par], rs));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->rt_done[par], 0));
-    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1][0], ctx->stream));
-    pt::launch_accumulate_batch(acc, L.tile, L.radiance, L.slot_pixels, n, ctx->d_accum, f16, ctx->stream);
-    HIP_TRY(hipGetLastError());
-    if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[1][1], ctx->stream)); ctx->ev_recorded[1] = true; }
-    HIP_TRY(hipEventRecord(ctx->acc_done[set], ctx->stream));
-    ctx->acc_done_valid[set] = true;
+    // The ordered mean, a run of frames at a time: a run ends with a frame whose canvas is wanted (EXACT presentation) or
+    // with the launch -- all n frames in one pass unless frames present, one pass + one fullscreen pass per presenting frame.
     ctx->last_radiance = L.radiance + (size_t)(n - 1) * L.slot_pixels;
     ctx->output_is_accum = true;
-    ctx->accum_version++;
+    for (int k = 0; k < n;) {
+        int e = k;
+        while (e < n - 1 && !frames[e].present) e++;
+        const bool last_run = e == n - 1;
+        pt::AccUniforms a = acc;
+        a.frame = acc.frame + (uint32_t)k;
+        if (ctx->timing && last_run) HIP_TRY(hipEventRecord(ctx->ev[1][0], ctx->stream));
+        pt::launch_accumulate_batch(a, L.tile, L.radiance + (size_t)k * L.slot_pixels, L.slot_pixels, e - k + 1, ctx->d_accum, f16, ctx->stream);
+        HIP_TRY(hipGetLastError());
+        if (ctx->timing && last_run) { HIP_TRY(hipEventRecord(ctx->ev[1][1], ctx->stream)); ctx->ev_recorded[1] = true; }
+        ctx->accum_version++;
+        if (frames[e].present)
+            if (int rc = run_fullscreen(ctx, frames[e].u_fs)) return rc;
+        k = e + 1;
+    }
+    HIP_TRY(hipEventRecord(ctx->acc_done[set], ctx->stream));
+    ctx->acc_done_valid[set] = true;
     return MI3PT_OK;
 }
 
@@ -1776,7 +1806,7 @@ static int flush_pending(mi3pt_ctx *ctx)
     while (at < q.size()) {
         int n = (int)(q.size() - at);
         if (n > ctx->batch_cap) n = ctx->batch_cap;
-        const int rc = launch_batch(ctx, q[at], n);
+        const int rc = launch_batch(ctx, &q[at], n);
         if (rc == MI3PT_ERR_STATE && n > 1) continue;       // the slot memory shrank batch_cap: retry smaller
         if (rc != MI3PT_OK) return rc;
         at += (size_t)n;
@@ -1799,19 +1829,25 @@ static bool batch_compatible(const mi3pt_ctx::PendingFrame &last, const mi3pt_ct
     return ldu(next.u_rt, 12) == ldu(last.u_rt, 12) + 1u && ldu(next.u_acc, 8) == ldu(last.u_acc, 8) + 1u;
 }
 
-static int run_fullscreen(mi3pt_ctx *ctx)
+static int run_fullscreen(mi3pt_ctx *ctx, const uint8_t *u_fs)
 {
     pt::FsUniforms fs;
-    fs.res_x = ldf(ctx->u_fs, 0); fs.res_y = ldf(ctx->u_fs, 4); fs.aspect = ldf(ctx->u_fs, 8);
-    fs.scaling = ldf(ctx->u_fs, 12); fs.denoise = ldu(ctx->u_fs, 16); fs.tonemapping = ldu(ctx->u_fs, 20);
+    fs.res_x = ldf(u_fs, 0); fs.res_y = ldf(u_fs, 4); fs.aspect = ldf(u_fs, 8);
+    fs.scaling = ldf(u_fs, 12); fs.denoise = ldu(u_fs, 16); fs.tonemapping = ldu(u_fs, 20);
     const float4 *tex = ctx->output_is_accum ? ctx->d_accum : ctx->last_radiance;
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2][0], ctx->stream));
-    pt::launch_fullscreen(fs, tex, ctx->width, ctx->height, ctx->width, ctx->height, ctx->d_canvas,
+    // (bit patterns compared: a NaN uniform must not rebuild the table every frame, and -0 is not +0 for a quotient)
+    const bool taps_current = ctx->fs_taps_valid && std::memcmp(ctx->fs_taps_res, &fs.res_x, 4) == 0 && std::memcmp(ctx->fs_taps_res + 1, &fs.res_y, 4) == 0;
+    pt::launch_fullscreen(fs, tex, ctx->width, ctx->height, ctx->width, ctx->height, ctx->d_fs_taps, taps_current, ctx->d_canvas,
                           ctx->d_canvas8, ctx->stream);
-    HIP_TRY(hipGetLastError());
+    if (hipError_t e = hipGetLastError()) {
+        ctx->fs_taps_valid = false;
+        return pt_set_error(MI3PT_ERR_HIP, std::string("fullscreen launch: ") + hipGetErrorString(e));
+    }
+    if (fs.denoise == 1u) { ctx->fs_taps_res[0] = fs.res_x; ctx->fs_taps_res[1] = fs.res_y; ctx->fs_taps_valid = true; }
     if (ctx->timing) { HIP_TRY(hipEventRecord(ctx->ev[2][1], ctx->stream)); ctx->ev_recorded[2] = true; }
     ctx->presented_version = ctx->accum_version;
-    std::memcpy(ctx->presented_fs, ctx->u_fs, sizeof ctx->presented_fs);
+    std::memcpy(ctx->presented_fs, u_fs, sizeof ctx->presented_fs);
     return MI3PT_OK;
 }
 
@@ -1838,7 +1874,7 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
     const int variant = pick_variant(ctx);
     const bool same_region = acc.res_w == (uint32_t)ldf(ctx->u_rt, 0) && acc.res_h == (uint32_t)ldf(ctx->u_rt, 4);
     const bool lazy_present = ctx->present_mode == MI3PT_PRESENT_LATEST;
-    bool acc_done = false;
+    bool acc_done = false, drawn_with_frame = false;
 
     if (do_rt && do_acc && same_region && ctx->pipeline && variant >= 4) {
         // queued: runs with its neighbours as one batch (see flush_pending)
@@ -1848,8 +1884,15 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
         if (!ctx->pending.empty() && !batch_compatible(ctx->pending.back(), f))
             if (int rc = flush_pending(ctx)) return rc;
         if (ctx->pending.empty()) for (bool &r : ctx->ev_recorded) r = false;
+        int depth = ctx->batch_cap;
+        if (do_fs && !lazy_present) {          // EXACT: this frame's canvas is drawn behind its mean (launch_batch)
+            f.present = true;
+            std::memcpy(f.u_fs, ctx->u_fs, sizeof f.u_fs);
+            if (depth > ctx->present_depth) depth = ctx->present_depth;
+            drawn_with_frame = true;
+        }
         ctx->pending.push_back(f);
-        if ((int)ctx->pending.size() >= ctx->batch_cap || (do_fs && !lazy_present))
+        if ((int)ctx->pending.size() >= depth)
             if (int rc = flush_pending(ctx)) return rc;
         acc_done = true;
     } else {
@@ -1879,7 +1922,7 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
         ctx->main_dirty = true;
         ctx->accum_version++;
     }
-    if (do_fs) {
+    if (do_fs && !drawn_with_frame) {
         // LATEST: frames may still be queued; the canvas is drawn from what has been launched, and
         // only if that (or the pass's uniforms) changed since the last draw.  What is still queued
         // is owed: a canvas read-back (or a FULLSCREEN-only submit) draws it.
@@ -1889,7 +1932,7 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
             if (!ctx->pending.empty()) ctx->want_present = true;
             return MI3PT_OK;
         }
-        if (int rc = run_fullscreen(ctx)) return rc;
+        if (int rc = run_fullscreen(ctx, ctx->u_fs)) return rc;
         ctx->want_present = lazy_present && !ctx->pending.empty();
     }
     return MI3PT_OK;
@@ -1917,7 +1960,7 @@ static int settle_canvas(mi3pt_ctx *ctx)
 {
     if (ctx->present_mode != MI3PT_PRESENT_LATEST || !ctx->want_present || ctx->width == 0 || ctx->nranks != 1) return MI3PT_OK;
     ctx->want_present = false;
-    return run_fullscreen(ctx);
+    return run_fullscreen(ctx, ctx->u_fs);
 }
 
 extern "C" int mi3pt_flush(mi3pt_ctx *ctx)

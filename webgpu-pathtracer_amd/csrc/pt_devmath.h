@@ -158,6 +158,29 @@ PT_DEV float exp1(float x)
     return ldexp1(y, (int)k);
 }
 
+// exp1 for x <= 0 (or NaN): the same value from fewer instructions.  No overflow side; the scaling by 2^k (k in
+// [-150, 0]) is one v_ldexp_f32, which rounds a subnormal result once like ldexp1's two-step product does (f32 subnormals
+// are kept in this library's kernels); and exp1's cut to 0 below -103.97 comes by itself -- there k <= -150 and the
+// polynomial's value is <= 1, so the scaled value is at most half the smallest subnormal and rounds to 0 (a tie goes to
+// the even 0) -- once -inf is kept out of the reduction (the argument is held at -200: same k range, same 0).
+// All 2^31 + 1 non-positive inputs and every NaN compared with exp1 on the device: profiles/exp_nonpos_proof.hip.
+PT_DEV float exp1_nonpos(float x)
+{
+    const float xc = __builtin_fmaxf(x, -200.0f);
+    const float k = floorf(fmaf(1.44269504088896341f, xc, 0.5f));
+    float r = fmaf(-k, 0.693359375f, xc);
+    r = fmaf(-k, -2.12194440e-4f, r);
+    const float z = r * r;
+    float p = fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float y = fmaf(p, z, r) + 1.0f;
+    const float e = __builtin_ldexpf(y, (int)k);
+    return x != x ? x : e;
+}
+
 PT_DEV float pow1(float x, float y) { return exp1(y * log1(x)); }
 
 PT_DEV float atan1(float x)

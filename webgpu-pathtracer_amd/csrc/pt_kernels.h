@@ -210,8 +210,11 @@ void launch_accumulate_batch(const AccUniforms &acc0, const Tile &tile, const fl
                              int nframes, float4 *accum, int store_f16, hipStream_t s);
 void launch_accumulate(const AccUniforms &acc, const Tile &tile, const float4 *input, float4 *accum,
                        int store_f16, hipStream_t s);
-void launch_fullscreen(const FsUniforms &fs, const float4 *tex, int tex_w, int tex_h,
-                       int canvas_w, int canvas_h, float4 *out_f32, uint32_t *out_rgba8, hipStream_t s);
+// `taps`: fullscreen_taps_bytes() of device memory (the de-noise pass's tap table); `taps_current`: an earlier call on
+// this stream has filled it from the same fs.res_x / fs.res_y
+size_t fullscreen_taps_bytes();
+void launch_fullscreen(const FsUniforms &fs, const float4 *tex, int tex_w, int tex_h, int canvas_w, int canvas_h,
+                       void *taps, bool taps_current, float4 *out_f32, uint32_t *out_rgba8, hipStream_t s);
 void launch_debug_intersect(const SceneRefs &scene, const float *rays, size_t n, float *out, int variant,
                             hipStream_t s);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s);

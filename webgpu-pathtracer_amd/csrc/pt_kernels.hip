@@ -2204,100 +2204,224 @@ PT_DEV float4 sample_repeat(const float4 *tex, int W, int H, float u, float v)
 // fullscreen.wgsl:53-86 with sigma 5, kSigma 1, threshold 0.08 (:117-119).
 //
 // The loop bounds, the tap offsets d / size and the spatial weight
-// exp(-dot(d,d) * invSigmaQx2) * invSigmaQx2PI depend only on the tap, not on the pixel, so a
-// workgroup evaluates them once into LDS (one column of taps per thread, with the same
-// float loop `y = y + 1.0` and the same exp1) and every pixel reuses them: one exp and no
-// division per tap instead of two exps and two divisions, identical bits.
+// exp(-dot(d,d) * invSigmaQx2) * invSigmaQx2PI depend only on the tap, not on the pixel: a setup kernel evaluates them
+// once per change of the pass's uniforms (one column of taps per thread, with the same float loop `y = y + 1.0` and the
+// same exp1) into a table in device memory, and every pixel reuses them -- one exp and no division per tap instead of
+// two exps and two divisions, identical bits.  The table is read with scalar loads, a column (128 B) at a time: offsets
+// and weights are instruction operands in scalar registers, the loop over a column's taps is unrolled.
 #define PT_DN_COLS 11          // x = -radius .. radius for radius = round(kSigma * sigma) = 5
 #define PT_DN_ROWS 12
 
-struct DenoiseTaps {
-    float ox[PT_DN_COLS];                    // x / size.x
-    int count[PT_DN_COLS];                   // taps in this column
-    float oy[PT_DN_COLS][PT_DN_ROWS];        // y / size.y
-    float blur[PT_DN_COLS][PT_DN_ROWS];      // spatial weight
+struct DenoiseColumn {                     // 32 dwords
+    float ox;                              // x / size.x
+    int count;                             // taps in this column
+    float oy[PT_DN_ROWS];                  // y / size.y
+    float blur[PT_DN_ROWS];                // spatial weight
+    float pad[6];
 };
+struct DenoiseTaps {
+    DenoiseColumn col[PT_DN_COLS];
+    float ox_lo, ox_hi, oy_lo, oy_hi;      // least / greatest offsets over all taps
+    int finite;                            // are all offsets finite
+    int pad[3];
+};
+static_assert(sizeof(DenoiseColumn) == 128 && sizeof(DenoiseTaps) == PT_DN_COLS * 128 + 32, "scalar-load layout");
 
-PT_DEV void denoise_build_taps(DenoiseTaps &taps, int column, float res_x, float res_y, float sigma, float k_sigma)
+size_t fullscreen_taps_bytes() { return sizeof(DenoiseTaps); }
+
+__global__ void __launch_bounds__(64) k_fullscreen_setup(const FsUniforms fs, DenoiseTaps *__restrict__ taps)
 {
-    const float INV_PI = 0.31830988618379067153776752674503f;
-    const float radius = rintf(k_sigma * sigma);
-    const float rad_q = radius * radius;
-    const float inv_sigma_qx2 = 0.5f / (sigma * sigma);
-    const float inv_sigma_qx2pi = INV_PI * inv_sigma_qx2;
-    float x = -radius;
-    for (int c = 0; c < column; c++) x = x + 1.0f;      // the reference's float loop variable
-    int n = 0;
-    if (x <= radius) {
-        const float pt = sqrtf(rad_q - x * x);
-        for (float y = -pt; y <= pt && n < PT_DN_ROWS; y = y + 1.0f) {
-            const float dd = x * x + y * y;
-            taps.oy[column][n] = y / res_y;
-            taps.blur[column][n] = ptm::exp1(-dd * inv_sigma_qx2) * inv_sigma_qx2pi;
-            n++;
+    __shared__ float lo_s[PT_DN_COLS], hi_s[PT_DN_COLS];
+    __shared__ int fin_s[PT_DN_COLS];
+    const int column = (int)threadIdx.x;
+    if (column < PT_DN_COLS) {
+        const float sigma = 5.0f, k_sigma = 1.0f;
+        const float INV_PI = 0.31830988618379067153776752674503f;
+        const float radius = rintf(k_sigma * sigma);
+        const float rad_q = radius * radius;
+        const float inv_sigma_qx2 = 0.5f / (sigma * sigma);
+        const float inv_sigma_qx2pi = INV_PI * inv_sigma_qx2;
+        float x = -radius;
+        for (int c = 0; c < column; c++) x = x + 1.0f;      // the reference's float loop variable
+        DenoiseColumn &C = taps->col[column];
+        int n = 0;
+        float lo = 0.0f, hi = 0.0f;
+        const float ox = x / fs.res_x;
+        bool finite = fabsf(ox) < PT_INF;
+        if (x <= radius) {
+            const float pt = sqrtf(rad_q - x * x);
+            for (float y = -pt; y <= pt && n < PT_DN_ROWS; y = y + 1.0f) {
+                const float dd = x * x + y * y;
+                const float oy = y / fs.res_y;
+                C.oy[n] = oy;
+                C.blur[n] = ptm::exp1(-dd * inv_sigma_qx2) * inv_sigma_qx2pi;
+                finite = finite && fabsf(oy) < PT_INF;
+                lo = n == 0 ? oy : fminf(lo, oy);
+                hi = n == 0 ? oy : fmaxf(hi, oy);
+                n++;
+            }
         }
+        for (int k = n; k < PT_DN_ROWS; k++) { C.oy[k] = 0.0f; C.blur[k] = 0.0f; }
+        for (float &q : C.pad) q = 0.0f;
+        C.ox = ox;
+        C.count = n;
+        lo_s[column] = lo; hi_s[column] = hi; fin_s[column] = finite ? 1 : 0;
     }
-    taps.ox[column] = x / res_x;
-    taps.count[column] = n;
+    __syncthreads();
+    if (column == 0) {
+        float ox_lo = taps->col[0].ox, ox_hi = ox_lo, oy_lo = lo_s[0], oy_hi = hi_s[0];
+        int finite = fin_s[0];
+        for (int c = 1; c < PT_DN_COLS; c++) {
+            ox_lo = fminf(ox_lo, taps->col[c].ox);
+            ox_hi = fmaxf(ox_hi, taps->col[c].ox);
+            oy_lo = fminf(oy_lo, lo_s[c]);
+            oy_hi = fmaxf(oy_hi, hi_s[c]);
+            finite &= fin_s[c];                     // (fminf / fmaxf skip a NaN)
+        }
+        taps->ox_lo = ox_lo; taps->ox_hi = ox_hi; taps->oy_lo = oy_lo; taps->oy_hi = oy_hi;
+        taps->finite = finite;
+        taps->pad[0] = taps->pad[1] = taps->pad[2] = 0;
+    }
 }
 
-// sample_repeat split into its horizontal and vertical halves: all taps of a column share
-// the horizontal texel pair and weight (same arithmetic as sample_repeat, evaluated once).
-struct RepeatAxis { int a, b; float f, w0; };
+// ---- the de-noise pass over an LDS copy of the block's texels --------------------------------------------------
+// A 16 x 16 block of canvas pixels reads, tap by tap, the texels around it: 85 taps x 4 texels per pixel, every texel
+// wanted by ~ 85 pixels.  The block copies the PT_FS_TW x PT_FS_TH texels around it into LDS once (repeat addressing
+// applied by the copy).  A wave whose lanes' taps ALL lie inside the copy -- each lane checks the two extreme offsets
+// per axis: floor((c + o) * n - 0.5) is monotone in o, every step being a monotone fp32 operation, so the taps between
+// lie between -- reads from there; any other wave (a `scaling` > 1, resolution uniforms that are not the texture's,
+// NaN) reads the texture as before.  Arithmetic and its order are sample_repeat's, per channel
+//     (p00 * wx0 + p10 * fx) * wy0 + (p01 * wx0 + p11 * fx) * fy,
+// so the bits are; the horizontal half (one "row value") of a tap's lower row is the next tap's upper row whenever the
+// column's taps step by whole texels (the same expression of the same operands: evaluated once, reused).
+#define PT_FS_TW 28          // 16 pixels + 2 x (radius 5 + 1 for floor's side) texels
+#define PT_FS_TH 28
 
-PT_DEV RepeatAxis repeat_axis(float coord, int n)
+struct FsTile {
+    const float4 *lds;       // PT_FS_TW x PT_FS_TH texels, row-major
+    const float4 *tex;
+    int x0, y0;              // texel (before wrapping) of the tile's first column / row
+    int W, H;
+};
+
+// one axis of textureSample: texel index before wrapping, weights
+struct FsAxis { int i0; float f, w0; };
+
+PT_DEV float fs_texel(float coord, int n) { return floorf(coord * (float)n - 0.5f); }
+
+// GUARD = false: the caller knows the texel index to be an ordinary number (it lies inside the tile)
+template <bool GUARD>
+PT_DEV FsAxis fs_axis(float coord, int n)
 {
     const float x = coord * (float)n - 0.5f;
     float x0f = floorf(x);
-    RepeatAxis r;
+    FsAxis r;
     r.f = x - x0f;
     r.w0 = 1.0f - r.f;
-    if (!(x0f > -1.0e9f && x0f < 1.0e9f)) x0f = 0.0f;
-    const int x0 = (int)x0f;
-    r.a = wrapi(x0, n);
-    r.b = wrapi(x0 + 1, n);
+    if constexpr (GUARD)
+        if (!(x0f > -1.0e9f && x0f < 1.0e9f)) x0f = 0.0f;
+    r.i0 = (int)x0f;
     return r;
 }
 
-PT_DEV float4 sample_repeat_axes(const float4 *tex, int W, const RepeatAxis &ax, const RepeatAxis &ay)
+// p(x, row) * wx0 + p(x + 1, row) * fx from the two texels
+PT_DEV float4 fs_row_mix(const float4 &p0, const float4 &p1, const FsAxis &ax)
 {
-    const float4 p00 = tex[(size_t)ay.a * W + ax.a];
-    const float4 p10 = tex[(size_t)ay.a * W + ax.b];
-    const float4 p01 = tex[(size_t)ay.b * W + ax.a];
-    const float4 p11 = tex[(size_t)ay.b * W + ax.b];
-    float4 r;
-    r.x = (p00.x * ax.w0 + p10.x * ax.f) * ay.w0 + (p01.x * ax.w0 + p11.x * ax.f) * ay.f;
-    r.y = (p00.y * ax.w0 + p10.y * ax.f) * ay.w0 + (p01.y * ax.w0 + p11.y * ax.f) * ay.f;
-    r.z = (p00.z * ax.w0 + p10.z * ax.f) * ay.w0 + (p01.z * ax.w0 + p11.z * ax.f) * ay.f;
-    r.w = (p00.w * ax.w0 + p10.w * ax.f) * ay.w0 + (p01.w * ax.w0 + p11.w * ax.f) * ay.f;
-    return r;
+    return make_float4(p0.x * ax.w0 + p1.x * ax.f, p0.y * ax.w0 + p1.y * ax.f, p0.z * ax.w0 + p1.z * ax.f,
+                       p0.w * ax.w0 + p1.w * ax.f);
+}
+PT_DEV float4 fs_row_value_tex(const FsTile &t, const FsAxis &ax, int row)
+{
+    const size_t base = (size_t)wrapi(row, t.H) * t.W;
+    return fs_row_mix(t.tex[base + wrapi(ax.i0, t.W)], t.tex[base + wrapi(ax.i0 + 1, t.W)], ax);
+}
+// the tile's texel pair at (ax.i0, row): index into t.lds
+PT_DEV int fs_tile_index(const FsTile &t, const FsAxis &ax, int row)
+{
+    return (int)__umul24((unsigned)(row - t.y0), (unsigned)PT_FS_TW) + (ax.i0 - t.x0);
+}
+template <bool LDS>
+PT_DEV float4 fs_row_value(const FsTile &t, const FsAxis &ax, int row)
+{
+    if constexpr (LDS) {
+        const float4 *q = t.lds + fs_tile_index(t, ax, row);
+        return fs_row_mix(q[0], q[1], ax);
+    } else {
+        return fs_row_value_tex(t, ax, row);
+    }
 }
 
-PT_DEV float4 denoise(const DenoiseTaps &taps, const float4 *tex, int W, int H, float u, float v, float threshold)
+PT_DEV float4 fs_combine(const float4 &ra, const float4 &rb, const FsAxis &ay)
+{
+    return make_float4(ra.x * ay.w0 + rb.x * ay.f, ra.y * ay.w0 + rb.y * ay.f, ra.z * ay.w0 + rb.z * ay.f,
+                       ra.w * ay.w0 + rb.w * ay.f);
+}
+
+// Do all of this pixel's taps (and its centre sample) read texels of the tile?
+PT_DEV bool denoise_inside(const DenoiseTaps *taps, const FsTile &t, float u, float v)
+{
+    struct Summary { float ox_lo, ox_hi, oy_lo, oy_hi; int finite; int pad[3]; };
+    const Summary m = load_const_block(reinterpret_cast<const Summary *>(&taps->ox_lo));
+    const float xa = fminf(fs_texel(u + m.ox_lo, t.W), fs_texel(u, t.W)), xb = fmaxf(fs_texel(u + m.ox_hi, t.W), fs_texel(u, t.W));
+    const float ya = fminf(fs_texel(v + m.oy_lo, t.H), fs_texel(v, t.H)), yb = fmaxf(fs_texel(v + m.oy_hi, t.H), fs_texel(v, t.H));
+    bool ok = m.finite != 0;
+    ok = ok && xa >= (float)t.x0 && xb <= (float)(t.x0 + PT_FS_TW - 2);        // (a NaN fails the comparison)
+    ok = ok && ya >= (float)t.y0 && yb <= (float)(t.y0 + PT_FS_TH - 2);
+    return ok;
+}
+
+template <bool LDS>
+PT_DEV float4 denoise(const DenoiseTaps *taps, const FsTile &t, float u, float v, float threshold)
 {
     const float INV_SQRT_OF_2PI = 0.39894228040143267793994605993439f;
     const float inv_threshold_sqx2 = 0.5f / (threshold * threshold);
     const float inv_threshold_sqrt2pi = INV_SQRT_OF_2PI / threshold;
-    const float4 centr = sample_repeat(tex, W, H, u, v);
+    float4 centr;
+    {
+        const FsAxis ax = fs_axis<!LDS>(u, t.W), ay = fs_axis<!LDS>(v, t.H);
+        centr = fs_combine(fs_row_value<LDS>(t, ax, ay.i0), fs_row_value<LDS>(t, ax, ay.i0 + 1), ay);
+    }
     float zbuff = 0.0f;
-    float4 abuff = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;      // (the sum's fourth component is not part of the pixel: fullscreen.wgsl:121)
+#pragma unroll 1
     for (int c = 0; c < PT_DN_COLS; c++) {
-        const RepeatAxis ax = repeat_axis(u + taps.ox[c], W);
-        const int n = taps.count[c];
-        for (int j = 0; j < n; j++) {
-            const RepeatAxis ay = repeat_axis(v + taps.oy[c][j], H);
-            const float4 walk = sample_repeat_axes(tex, W, ax, ay);
+        const DenoiseColumn C = load_const_block(&taps->col[c]);
+        const FsAxis ax = fs_axis<!LDS>(u + C.ox, t.W);
+        int prev = (int)0x80000000;               // row of the previous tap (none yet)
+        float4 rb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int at = 0;                                // LDS: index of the lower row's texel pair
+        auto tap = [&](float oy, float blur) {
+            const FsAxis ay = fs_axis<!LDS>(v + oy, t.H);
+            float4 ra = rb;
+            if constexpr (LDS) {
+                if (ay.i0 - 1 != prev) {
+                    at = fs_tile_index(t, ax, ay.i0);
+                    ra = fs_row_mix(t.lds[at], t.lds[at + 1], ax);
+                }
+                at += PT_FS_TW;
+                rb = fs_row_mix(t.lds[at], t.lds[at + 1], ax);
+            } else {
+                if (ay.i0 - 1 != prev) ra = fs_row_value_tex(t, ax, ay.i0);
+                rb = fs_row_value_tex(t, ax, ay.i0 + 1);
+            }
+            prev = ay.i0;
+            const float4 walk = fs_combine(ra, rb, ay);
             const float dx = walk.x - centr.x, dy = walk.y - centr.y, dz = walk.z - centr.z, dw = walk.w - centr.w;
             const float dcdc = ((dx * dx + dy * dy) + dz * dz) + dw * dw;
-            const float delta = ptm::exp1(-dcdc * inv_threshold_sqx2) * inv_threshold_sqrt2pi * taps.blur[c][j];
+            const float delta = ptm::exp1_nonpos(-dcdc * inv_threshold_sqx2) * inv_threshold_sqrt2pi * blur;
             zbuff = zbuff + delta;
-            abuff.x = abuff.x + delta * walk.x;
-            abuff.y = abuff.y + delta * walk.y;
-            abuff.z = abuff.z + delta * walk.z;
-            abuff.w = abuff.w + delta * walk.w;
-        }
+            sx = sx + delta * walk.x;
+            sy = sy + delta * walk.y;
+            sz = sz + delta * walk.z;
+        };
+        // (written out: the offsets and weights are scalar registers, which a loop cannot index)
+#define PT_TAP(J) if (C.count > J) { tap(C.oy[J], C.blur[J]);
+        PT_TAP(0) PT_TAP(1) PT_TAP(2) PT_TAP(3) PT_TAP(4) PT_TAP(5) PT_TAP(6) PT_TAP(7) PT_TAP(8) PT_TAP(9) PT_TAP(10) PT_TAP(11)
+        }}}}}}}}}}}}
+#undef PT_TAP
+        static_assert(PT_DN_ROWS == 12, "taps written out above");
     }
-    return make_float4(abuff.x / zbuff, abuff.y / zbuff, abuff.z / zbuff, abuff.w / zbuff);
+    return make_float4(sx / zbuff, sy / zbuff, sz / zbuff, 1.0f);
 }
 
 // fullscreen.wgsl:88-103 (mat3x3f constructors are column-major)
@@ -2342,20 +2466,34 @@ PT_DEV uint32_t to_unorm8(float v)
 // is the top (framebuffer order), quad uv (0,0) sits at clip (-1,-1) = bottom left.
 __global__ void __launch_bounds__(256) k_fullscreen(const FsUniforms fs, const float4 *__restrict__ tex,
                                                     int tex_w, int tex_h, int canvas_w, int canvas_h,
+                                                    const DenoiseTaps *__restrict__ taps,
                                                     float4 *__restrict__ out_f32, uint32_t *__restrict__ out_rgba8)
 {
-    __shared__ DenoiseTaps taps;
-    if (fs.denoise == 1u) {
-        if (threadIdx.x < PT_DN_COLS) denoise_build_taps(taps, (int)threadIdx.x, fs.res_x, fs.res_y, 5.0f, 1.0f);
-        __syncthreads();
-    }
+    __shared__ float4 tile[PT_FS_TW * PT_FS_TH];
     const int px = blockIdx.x * 16 + (threadIdx.x & 15);
     const int py = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (px >= canvas_w || py >= canvas_h) return;
     const float u = (((float)px + 0.5f) / (float)canvas_w) * fs.scaling;
     const float v = (1.0f - ((float)py + 0.5f) / (float)canvas_h) * fs.scaling;
-    float4 c4 = sample_repeat(tex, tex_w, tex_h, u, v);
-    if (fs.denoise == 1u) c4 = denoise(taps, tex, tex_w, tex_h, u, v, 0.08f);
+    float4 c4;
+    if (fs.denoise == 1u) {
+        // The tile: from 6 texels left of / below the texel pair of the block's first column / last row (v runs against
+        // py).  A guess that is right for every scaling <= 1; where it is not, the wave reads the texture.
+        FsTile t;
+        t.lds = tile; t.tex = tex; t.W = tex_w; t.H = tex_h;
+        t.x0 = fs_axis<true>((((float)(blockIdx.x * 16) + 0.5f) / (float)canvas_w) * fs.scaling, tex_w).i0 - 6;
+        t.y0 = fs_axis<true>((1.0f - ((float)(blockIdx.y * 16 + 15) + 0.5f) / (float)canvas_h) * fs.scaling, tex_h).i0 - 6;
+        for (int i = (int)threadIdx.x; i < PT_FS_TW * PT_FS_TH; i += 256) {
+            const int ty = i / PT_FS_TW, tx = i - ty * PT_FS_TW;
+            tile[i] = tex[(size_t)wrapi(t.y0 + ty, tex_h) * tex_w + wrapi(t.x0 + tx, tex_w)];
+        }
+        __syncthreads();
+        if (px >= canvas_w || py >= canvas_h) return;
+        if (__builtin_amdgcn_ballot_w64(!denoise_inside(taps, t, u, v)) == 0) c4 = denoise<true>(taps, t, u, v, 0.08f);
+        else c4 = denoise<false>(taps, t, u, v, 0.08f);
+    } else {
+        if (px >= canvas_w || py >= canvas_h) return;
+        c4 = sample_repeat(tex, tex_w, tex_h, u, v);
+    }
     f3 c = F3(c4.x, c4.y, c4.z);
     if (fs.tonemapping == 1u) c = aces_tonemap(c);
     else if (fs.tonemapping == 2u) c = F3(c.x / (c.x + 1.0f), c.y / (c.y + 1.0f), c.z / (c.z + 1.0f));
@@ -2364,13 +2502,17 @@ __global__ void __launch_bounds__(256) k_fullscreen(const FsUniforms fs, const f
     if (out_rgba8) out_rgba8[i] = to_unorm8(c.x) | (to_unorm8(c.y) << 8) | (to_unorm8(c.z) << 16) | 0xff000000u;
 }
 
+// `taps`: fullscreen_taps_bytes() of device memory owned by the caller; `taps_current`: the table in it was built by an
+// earlier call on this stream from the same res_x / res_y (the setup kernel is skipped).
 void launch_fullscreen(const FsUniforms &fs, const float4 *tex, int tex_w, int tex_h, int canvas_w,
-                       int canvas_h, float4 *out_f32, uint32_t *out_rgba8, hipStream_t s)
+                       int canvas_h, void *taps, bool taps_current, float4 *out_f32, uint32_t *out_rgba8, hipStream_t s)
 {
     if (canvas_w <= 0 || canvas_h <= 0) return;
+    if (fs.denoise == 1u && !taps_current)
+        hipLaunchKernelGGL(k_fullscreen_setup, dim3(1), dim3(64), 0, s, fs, static_cast<DenoiseTaps *>(taps));
     const dim3 grid((canvas_w + 15) / 16, (canvas_h + 15) / 16), block(256);
-    hipLaunchKernelGGL(k_fullscreen, grid, block, 0, s, fs, tex, tex_w, tex_h, canvas_w, canvas_h, out_f32,
-                       out_rgba8);
+    hipLaunchKernelGGL(k_fullscreen, grid, block, 0, s, fs, tex, tex_w, tex_h, canvas_w, canvas_h,
+                       static_cast<const DenoiseTaps *>(taps), out_f32, out_rgba8);
 }
 
 // ---------------------------------------------------------------------------------
