@@ -2294,8 +2294,12 @@ __global__ void __launch_bounds__(64) k_fullscreen_setup(const FsUniforms fs, De
 //     (p00 * wx0 + p10 * fx) * wy0 + (p01 * wx0 + p11 * fx) * fy,
 // so the bits are; the horizontal half (one "row value") of a tap's lower row is the next tap's upper row whenever the
 // column's taps step by whole texels (the same expression of the same operands: evaluated once, reused).
-#define PT_FS_TW 28          // 16 pixels + 2 x (radius 5 + 1 for floor's side) texels
-#define PT_FS_TH 28
+// 16 pixels + 2 x (radius 5 + 1 for floor's side) = 28 texels, + 1 on either side: (px + 0.5) / w * w - 0.5 rounds to just
+// below px for some px and to px for others (1920: every few pixels), so the texel pairs of a block's pixels start at
+// px - 1 or at px, pixel by pixel, whatever the block's first pixel does
+#define PT_FS_TW 30
+#define PT_FS_TH 30
+#define PT_FS_MARGIN 7
 
 struct FsTile {
     const float4 *lds;       // PT_FS_TW x PT_FS_TH texels, row-major
@@ -2476,12 +2480,12 @@ __global__ void __launch_bounds__(256) k_fullscreen(const FsUniforms fs, const f
     const float v = (1.0f - ((float)py + 0.5f) / (float)canvas_h) * fs.scaling;
     float4 c4;
     if (fs.denoise == 1u) {
-        // The tile: from 6 texels left of / below the texel pair of the block's first column / last row (v runs against
+        // The tile: from PT_FS_MARGIN texels left of / below the texel pair of the block's first column / last row (v runs against
         // py).  A guess that is right for every scaling <= 1; where it is not, the wave reads the texture.
         FsTile t;
         t.lds = tile; t.tex = tex; t.W = tex_w; t.H = tex_h;
-        t.x0 = fs_axis<true>((((float)(blockIdx.x * 16) + 0.5f) / (float)canvas_w) * fs.scaling, tex_w).i0 - 6;
-        t.y0 = fs_axis<true>((1.0f - ((float)(blockIdx.y * 16 + 15) + 0.5f) / (float)canvas_h) * fs.scaling, tex_h).i0 - 6;
+        t.x0 = fs_axis<true>((((float)(blockIdx.x * 16) + 0.5f) / (float)canvas_w) * fs.scaling, tex_w).i0 - PT_FS_MARGIN;
+        t.y0 = fs_axis<true>((1.0f - ((float)(blockIdx.y * 16 + 15) + 0.5f) / (float)canvas_h) * fs.scaling, tex_h).i0 - PT_FS_MARGIN;
         for (int i = (int)threadIdx.x; i < PT_FS_TW * PT_FS_TH; i += 256) {
             const int ty = i / PT_FS_TW, tx = i - ty * PT_FS_TW;
             tile[i] = tex[(size_t)wrapi(t.y0 + ty, tex_h) * tex_w + wrapi(t.x0 + tx, tex_w)];
