@@ -12,7 +12,8 @@ the driver's 20 steps that is a 9 ms job, most of it launch ramp and drain.)
 
 Headline workload (default) = the scene BASELINE.json's target is quoted on: the dragon-class
 ~870k-triangle mesh + environment map at 1920x1080 (configs[2]); `--workload demo` is
-configs[1] (default demo mesh, 1,998 triangles) and is also measured, shorter, as `also.demo`.
+configs[1] (default demo mesh, 1,998 triangles) and is also measured, shorter, as `also.demo` -- and
+as `also.demo_presenting_every_frame` with the reference's whole render(): a de-noised, tone-mapped canvas per frame.
 
 N > 1 (launched by torch.distributed.run, one process per GPU): image tiles are dealt to the
 ranks in 8-row blocks, the scene is replicated, there is NO per-frame communication, and the job
@@ -165,17 +166,26 @@ class Job:
         u.set({"resolution": [self.width, self.height], "frame": frame, "enabled": 1})
         return u.tobytes()
 
-    def frames(self, n, per_launch, sync_each=False):
+    def frames(self, n, per_launch, sync_each=False, present=False):
         """n consecutive frames, `per_launch` per launch: one mi3pt_submit_frames call per launch
         (= that many Renderer.render() calls with only the frame counter moving), launched at
-        once, nothing waited for (sync_each: wait after every launch -- the counter passes)."""
+        once, nothing waited for (sync_each: wait after every launch -- the counter passes).
+        present: every frame also encodes the fullscreen pass (de-noise + ACES), with the reference's canvas semantics
+        (MI3PT_PRESENT_EXACT, the C ABI's default): a canvas drawn from the mean up to and including each frame."""
         capi, ctx = self.capi, self.ctx
+        mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+        if present:
+            mask |= capi.SUBMIT_FULLSCREEN
+            f = self.layout.UniformBlock(self.layout.FULLSCREEN_UNIFORMS)
+            f.set({"resolution": [self.width, self.height], "aspect": self.width / self.height, "scalingFactor": 1.0,
+                   "denoise": 1, "tonemapping": 1})
+            ctx.set_uniforms(capi.PASS_FULLSCREEN, f.tobytes())
         done = 0
         while done < n:
             k = min(per_launch, n - done)
             ctx.set_uniforms(capi.PASS_RAYTRACE, self.rt_uniforms(self.frame))
             ctx.set_uniforms(capi.PASS_ACCUMULATE, self.acc_uniforms(self.frame))
-            ctx.submit_frames(capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE, k)
+            ctx.submit_frames(mask, k)
             ctx.sync() if sync_each else ctx.flush()
             self.frame += k
             done += k
@@ -449,7 +459,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(workload, steps, warmup, gather, size=None):
+    def measure(workload, steps, warmup, gather, size=None, present=False):
         """The timed job for one workload: `warmup` untimed steps, then EXACTLY `steps` steps of 16 frames
         (+ the one gather when N > 1) between barrier + synchronize on both sides."""
         width, height = size or (base_width, base_height)
@@ -487,7 +497,7 @@ def main():
             # (profiles/r03_h_first_job.log)
             exchange()
             sync_all()
-        job.frames(warmup * FRAMES_PER_STEP, per_launch)
+        job.frames(warmup * FRAMES_PER_STEP, per_launch, present=present)
         ctx.sync()
         ctx.reset_counters()
         warm_ms, warm_launches, _ = ctx.raytrace_launch_stats()      # (the warm-up's launches: for the all-launch average below)
@@ -495,7 +505,7 @@ def main():
 
         sync_all()
         t0 = time.perf_counter()
-        job.frames(steps * FRAMES_PER_STEP, per_launch)      # ends with a flush: everything is launched, nothing waited for
+        job.frames(steps * FRAMES_PER_STEP, per_launch, present=present)      # ends with a flush: everything is launched, nothing waited for
         if send is not None:
             exchange()
         sync_all()
@@ -567,6 +577,17 @@ def main():
                                  "box_tests_per_ray": round(c["box_tests"] / max(c["rays"], 1), 2),
                                  "tri_tests_per_ray": round(c["tri_tests"] / max(c["rays"], 1), 2)}
             a["job"].ctx.close()
+        # the demo scene with the reference's whole render(): raytrace + accumulate + fullscreen (de-noise, ACES, 8-bit canvas)
+        # on every frame, canvas semantics as in renderer.ts:379-390 -- half the steps (a frame with its passes takes 2.5x as long)
+        psteps = max(args.steps // 2, 1)
+        a = measure("demo", psteps, min(args.warmup, 2), gather=False, present=True)
+        out["also"]["demo_presenting_every_frame"] = {
+            "value": round(a["total"]["rays"] / a["elapsed"] / 1e6, 3), "unit": "Mrays/s",
+            "ms_per_frame": round(a["elapsed"] * 1e3 / (psteps * FRAMES_PER_STEP), 4), "steps": psteps,
+            "workload": workload_name("demo", a["job"].sc) + f", {width}x{height}, {BOUNCES} bounces; every frame: raytrace, accumulate and "
+                        "fullscreen pass (de-noise + ACES + RGBA8 canvas), MI3PT_PRESENT_EXACT",
+            "frames_per_launch": a["frames_per_launch"]}
+        a["job"].ctx.close()
 
     # ---- the forest leg (N = 1): config 5's scene -- 10 M triangles, 2.08 GB, the only one larger than the 256 MiB
     # Infinity Cache, i.e. the one on which "HBM GB/s against peak" is the question -- at 1920x1080, with its own counter passes
