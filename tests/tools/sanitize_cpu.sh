@@ -1,0 +1,63 @@
+#!/bin/bash
+# AddressSanitizer + UndefinedBehaviorSanitizer over the CPU-side native code (no GPU sanitizer exists on this pool):
+# the host scene compile of libmi3pt.so (csrc/pt_host_scene.cpp: the reference's BVH builder and env CDF) and the CPU
+# oracle (oracle/pt_oracle.c: raytrace, accumulate, fullscreen).  Builds instrumented copies under /tmp and drives them
+# through ctypes.   usage: bash tests/tools/sanitize_cpu.sh        (about a minute; prints two "ok" lines)
+set -eu
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+W=$(mktemp -d /tmp/mi3pt_san.XXXXXX)
+trap 'rm -rf "$W"' EXIT
+SAN="-O1 -g -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer"
+cat > $W/stub.cpp <<'CPP'
+#include <string>
+#include <cstdio>
+int pt_set_error(int code, const std::string &msg) { fprintf(stderr, "(expected) error %d: %s\n", code, msg.c_str()); return code; }
+CPP
+g++ $SAN -std=c++17 -w -I$ROOT/include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ $ROOT/webgpu-pathtracer_amd/csrc/pt_host_scene.cpp $W/stub.cpp -o $W/libhost.so -lpthread
+gcc $SAN -std=c11 -ffp-contract=off -fno-fast-math -fopenmp $(grep -q -m1 fma /proc/cpuinfo && echo -mfma) -o $W/libptoracle.so $ROOT/oracle/pt_oracle.c -lm
+export LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1
+python3 - $W $ROOT <<'PY'
+import ctypes, sys
+import numpy as np
+W, ROOT = sys.argv[1:3]
+lib = ctypes.CDLL(W + "/libhost.so")
+rng = np.random.default_rng(1)
+P, S = ctypes.c_void_p, ctypes.c_size_t
+for n in (1, 2, 3, 7, 100, 5000, 200000):
+    pos = rng.standard_normal((n, 9))
+    if n > 50:
+        pos[10:20] = pos[0]          # duplicates: ties in the sort and in the SAH sweep
+    nodes = np.zeros((2 * n - 1) * 48, np.uint8)
+    nn = S()
+    for threads in (1, 8):
+        rc = lib.mi3pt_host_build_bvh_f64(pos.ctypes.data_as(P), S(n), nodes.ctypes.data_as(P), S(nodes.nbytes), ctypes.byref(nn), threads)
+        assert rc == 0 and nn.value == 2 * n - 1, (rc, nn.value)
+    tri = np.zeros((n, 28), np.float32)
+    tri[:, 0:3], tri[:, 4:7], tri[:, 8:11] = pos[:, 0:3], pos[:, 3:6], pos[:, 6:9]
+    assert lib.mi3pt_host_build_bvh(tri.ctypes.data_as(P), S(n), nodes.ctypes.data_as(P), S(nodes.nbytes), ctypes.byref(nn), 0) == 0
+for w, h in ((1, 1), (2, 1), (64, 32), (333, 77)):
+    img = rng.random((h, w, 4), dtype=np.float32) * 10
+    if w > 2:
+        img[0] = 0
+    cdf = np.zeros((h, w, 4), np.float32)
+    assert lib.mi3pt_host_env_cdf(img.ctypes.data_as(P), w, h, cdf.ctypes.data_as(P)) == 0
+assert lib.mi3pt_host_build_bvh_f64(None, S(0), None, S(0), ctypes.byref(S()), 1) != 0
+print("host scene compile under ASan + UBSan: ok")
+
+sys.path[:0] = [ROOT + "/oracle", ROOT + "/tests", ROOT + "/webgpu-pathtracer_amd/py"]
+import pt_oracle as orc
+orc.LIB_PATH = W + "/libptoracle.so"
+import ptcommon as pc
+from mi3pt_host import scenes
+sc = scenes.demo_scene()
+sc.build_bvh()
+w, h = 48, 32
+osc = pc.oracle_scene(orc, sc, scenes.synthetic_env())
+acc = np.zeros((h, w, 4), np.float32)
+for f in (2, 3):
+    img, _ = orc.raytrace(osc, pc.rt_uniforms(sc, w, h, frame=f, bounces=8).tobytes(), w, h)
+    acc = orc.accumulate(pc.acc_uniforms(w, h, f).tobytes(), w, h, img, acc)
+for scaling in (1.0, 0.5, 1.5):
+    orc.fullscreen(pc.fs_uniforms(w, h, scaling, 1, 1).tobytes(), acc)
+print("oracle (raytrace, accumulate, fullscreen) under ASan + UBSan: ok")
+PY
