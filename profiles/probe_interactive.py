@@ -4,7 +4,7 @@
   b) the same with a sync after every frame
   c) raytrace + accumulate + fullscreen per frame and a sync after every frame (what an interactive viewer does)
   d) c + the 8-bit canvas read back every frame
-usage: python profiles/probe_interactive.py [frames]"""
+usage: python profiles/probe_interactive.py [frames [waves per CU]]"""
 import os
 import sys
 import time
@@ -16,10 +16,14 @@ import ptcommon as pc  # noqa: E402
 from mi3pt_host import capi, scenes  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+waves_per_cu = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 0: the library's choice
 w, h = 1920, 1080
 sc = scenes.demo_scene()
 sc.build_bvh()
 ctx = capi.Context(0)
+if waves_per_cu:
+    ctx.set_option(capi.OPT_WAVES_PER_CU, waves_per_cu)
+    print("waves per CU:", waves_per_cu)
 pc.upload_scene(ctx, sc, scenes.synthetic_env())
 ctx.resize(w, h)
 ctx.set_uniforms(capi.PASS_FULLSCREEN, pc.fs_uniforms(w, h, 1.0, 1, 1).tobytes())

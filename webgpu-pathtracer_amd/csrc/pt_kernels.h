@@ -221,7 +221,7 @@ void launch_debug_math(int fn, const float *a, const float *b, float *out, size_
 int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, uint32_t total, uint32_t *counter, float4 *out, int waves_per_simd,
                       int lcap, int leaf_min, int num_cus, hipStream_t s);
 int raytrace_grid_blocks(const Tile &tile);
-int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu, int num_cus, bool tuned = false);
+int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned = false);
 // writes NodePacket::cull of `npackets` packets from a dense array (the context's cull analysis)
 void launch_patch_cull(float4 *packets, const uint32_t *cull, uint32_t npackets, hipStream_t s);
 

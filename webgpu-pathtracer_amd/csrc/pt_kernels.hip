@@ -1999,11 +1999,21 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     }
 }
 
-int raytrace_persistent_blocks(const Tile &tile, int waves_per_cu, int num_cus, bool tuned)
+int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned)
 {
     const int ntiles = raytrace_grid_blocks(tile);
-    if (waves_per_cu <= 0 || waves_per_cu > 24) waves_per_cu = 4 * (tuned ? SM_TUNED_WAVES_PER_SIMD : SM_OTHER_WAVES_PER_SIMD);
     if (num_cus <= 0) num_cus = 256;
+    if (waves_per_cu <= 0 || waves_per_cu > 24) {
+        waves_per_cu = 4 * (tuned ? SM_TUNED_WAVES_PER_SIMD : SM_OTHER_WAVES_PER_SIMD);
+        // A small launch (an interactive host: one or two frames, or a small image) gets fewer waves: at least 8 jobs each,
+        // at least 4 per CU.  With a handful of jobs per wave a launch is all ramp and drain, and a launch that fills every
+        // wave slot keeps its successor out until its own waves exit; narrower launches overlap.  One 1080p frame per
+        // launch: 16 waves per CU, -6 % time; 640 x 360: 4, -20 % (profiles/r03_k_small_launches.log; fewer still is
+        // faster on light scenes and slower on heavy ones: MI3PT_OPT_WAVES_PER_CU)
+        const long long jobs = (long long)ntiles * (nframes > 0 ? nframes : 1);
+        const long long want = (jobs + (long long)num_cus * 8 - 1) / ((long long)num_cus * 8);
+        if (want < waves_per_cu) waves_per_cu = want < 4 ? 4 : (int)want;
+    }
     int resident = num_cus * waves_per_cu;                            // the device's own CU count (hipDeviceProp_t)
     if (resident > PT_MAX_RESIDENT_WAVES) resident = PT_MAX_RESIDENT_WAVES;
     return ntiles < resident ? ntiles : resident;
@@ -2055,7 +2065,7 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
     if (variant >= 3) {
         const bool one = launch_is_one_spp(L, fuse);
         const bool tuned = launch_is_tuned(L, fuse, variant);
-        const dim3 grid(raytrace_persistent_blocks(L.tile, L.waves_per_cu, L.num_cus, tuned));
+        const dim3 grid(raytrace_persistent_blocks(L.tile, L.nframes, L.waves_per_cu, L.num_cus, tuned));
         if (variant >= 10 && variant <= 12) {            // the culling walk on 4-ary wide packets
             // 11 / 12: the filtered slab test (12: with the one-axis culling condition) in the shipped batched launch; the
             // other launch flavours (fused, diagnostic, samplesPerFrame != 1) run variant 10's exact test -- same bits
