@@ -33,8 +33,8 @@ class Renderer {
     // presentEveryFrame: encode the fullscreen pass on every render() like renderer.ts:386 (false: never).
     // presentLatest (headless default): a sample frame that also presents is queued like any other and
     // the canvas is drawn once per launched batch (MI3PT_PRESENT_LATEST); reading the canvas, or a
-    // render() after sampling has stopped, shows every frame.  false = the canvas is redrawn from this
-    // very frame on every render(), which costs one kernel launch per frame.
+    // render() after sampling has stopped, shows every frame.  false = every render() gets its own accumulate and
+    // fullscreen pass, the canvas drawn from this very frame (MI3PT_PRESENT_EXACT: 2.5x the time per frame).
     this.options = Object.assign({ enableTimestampQuery: false, verbose: false, presentEveryFrame: true,
       presentLatest: true }, args.options || {});
     this.native.setPresentMode(this.handle, this.options.presentLatest ? 1 : 0);
