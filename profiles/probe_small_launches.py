@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small raytrace launches (an interactive host: one or a few frames per launch) against the number of persistent waves
 per CU: ms per frame for launches of B frames, queued back to back (q) and with a sync after each (s).
-usage: python profiles/probe_small_launches.py [demo|dragon] [WxH]"""
+usage: python profiles/probe_small_launches.py [demo|dragon|blob:<segments>] [WxH]"""
 import os
 import sys
 import time
@@ -18,12 +18,15 @@ w, h = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "1920x1080").spli
 if workload == "demo":
     sc = scenes.demo_scene()
     sc.build_bvh()
+elif workload.startswith("blob:"):          # the dragon-class generator at another size (2 x segments^2 triangles)
+    sc = scenes.dragon_class_scene(segments=int(workload[5:]))
+    sc.build_bvh()
 else:
     import bench
     sc, _ = bench.build_scene("dragon")
 env = scenes.synthetic_env()
 RT_ACC = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
-print(f"{workload} {w}x{h}: ms per frame, queued / sync after every launch")
+print(f"{workload} ({len(sc.triangles)} triangles) {w}x{h}: ms per frame, queued / sync after every launch")
 for batch in (1, 2, 4, 8):
     row = []
     for waves in (0, 20, 16, 12, 10, 8, 6, 4):

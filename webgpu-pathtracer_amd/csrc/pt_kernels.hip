@@ -2009,10 +2009,13 @@ int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, 
         // at least 4 per CU.  With a handful of jobs per wave a launch is all ramp and drain, and a launch that fills every
         // wave slot keeps its successor out until its own waves exit; narrower launches overlap.  One 1080p frame per
         // launch: 16 waves per CU, -6 % time; 640 x 360: 4, -20 % (profiles/r03_k_small_launches.log; fewer still is
-        // faster on light scenes and slower on heavy ones: MI3PT_OPT_WAVES_PER_CU)
+        // faster on the default scene and slower on every other one tried: MI3PT_OPT_WAVES_PER_CU)
+        // Up to ~3 frames of 1080p per launch, 16 per CU beats 20 on every scene tried (-5 ... -12 %: the successor finds
+        // four wave slots per CU free from the start); from 4 frames on the full width wins.
         const long long jobs = (long long)ntiles * (nframes > 0 ? nframes : 1);
         const long long want = (jobs + (long long)num_cus * 8 - 1) / ((long long)num_cus * 8);
-        if (want < waves_per_cu) waves_per_cu = want < 4 ? 4 : (int)want;
+        if (want < 16) waves_per_cu = want < 4 ? 4 : (int)want;
+        else if (want < 48 && waves_per_cu > 16) waves_per_cu = 16;
     }
     int resident = num_cus * waves_per_cu;                            // the device's own CU count (hipDeviceProp_t)
     if (resident > PT_MAX_RESIDENT_WAVES) resident = PT_MAX_RESIDENT_WAVES;
