@@ -2,7 +2,7 @@
 """The exact-canvas loop (MI3PT_PRESENT_EXACT: raytrace + accumulate + fullscreen per frame, the reference's
 renderer.ts:366-395) on the default scene at 1920x1080, 8 bounces: ms per frame and Mrays/s; with `trace <csv>` the
 kernel timeline of a rocprofv3 --kernel-trace run of this script is printed (start, duration, what ran beside it).
-usage: python profiles/probe_present_exact.py [frames]
+usage: python profiles/probe_present_exact.py [frames [present depth]]
        rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 profiles/probe_present_exact.py 32
        python profiles/probe_present_exact.py trace DIR/.../*_kernel_trace.csv"""
 import csv
@@ -33,6 +33,7 @@ def main():
     import ptcommon as pc
     from mi3pt_host import capi, scenes
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    depth = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     w, h = 1920, 1080
     sc = scenes.demo_scene()
     sc.build_bvh()
@@ -40,6 +41,8 @@ def main():
     pc.upload_scene(ctx, sc, scenes.synthetic_env())
     ctx.resize(w, h)
     ctx.set_present_mode(capi.PRESENT_EXACT)
+    if depth:
+        ctx.set_option(capi.OPT_PRESENT_DEPTH, depth)
     ctx.set_uniforms(capi.PASS_FULLSCREEN, pc.fs_uniforms(w, h, 1.0, 1, 1).tobytes())
     everything = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE | capi.SUBMIT_FULLSCREEN
 
@@ -54,7 +57,7 @@ def main():
     run(2 + frames)
     dt = time.perf_counter() - t0
     rays = ctx.counters()["rays"]
-    print(f"present_exact: {frames} frames, {dt / frames * 1e3:.4f} ms per frame, {rays / dt / 1e6:.1f} Mrays/s")
+    print(f"present_exact (depth {depth or 'default'}): {frames} frames, {dt / frames * 1e3:.4f} ms per frame, {rays / dt / 1e6:.1f} Mrays/s")
 
 
 if __name__ == "__main__":
