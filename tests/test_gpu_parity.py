@@ -810,6 +810,75 @@ def test_exact_presentation_shares_launches_without_a_trace(gpu_ctx, orc, demo, 
     ctx.resize(64, 64)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_presentation_differential_over_random_call_sequences(gpu_ctx, demo, env, seed):
+    """Two contexts get the same random sequence of calls -- frames that present, frames that do not, FULLSCREEN-only
+    submits, fullscreen uniforms and present modes changing, resets, a resize, read-backs at random points -- one
+    launching every presenting frame by itself (MI3PT_OPT_PRESENT_DEPTH 1), one sharing launches (16).  Every read-back
+    must agree byte for byte: deferring work never shows."""
+    rng = np.random.default_rng(seed)
+    own = capi.Context(0)
+    try:
+        ctxs = (gpu_ctx, own)
+        for ctx, depth in zip(ctxs, (1, 16)):
+            pc.upload_scene(ctx, demo, env)
+            ctx.set_tile(0, 1, 8)
+            ctx.set_present_mode(capi.PRESENT_EXACT)
+            ctx.set_option(capi.OPT_PRESENT_DEPTH, depth)
+            ctx.resize(80, 56)
+        size = [80, 56]
+        frame = 2
+        everything = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE | capi.SUBMIT_FULLSCREEN
+        reads = 0
+        for _ in range(120):
+            op = rng.choice(["present", "present", "present", "present", "sample", "fs_only", "fs_uniforms", "mode", "read_canvas",
+                             "read_accum", "reset", "resize"], p=[0.2, 0.2, 0.15, 0.1, 0.1, 0.03, 0.08, 0.03, 0.05, 0.03, 0.02, 0.01])
+            w, h = size
+            if op in ("present", "sample"):
+                mask = everything if op == "present" else capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+                for ctx in ctxs:
+                    pc.gpu_frame(ctx, pc.rt_uniforms(demo, w, h, frame=frame, bounces=3), pc.acc_uniforms(w, h, frame), mask)
+                frame += 1
+            elif op == "fs_only":
+                for ctx in ctxs:
+                    ctx.submit(capi.SUBMIT_FULLSCREEN)
+            elif op == "fs_uniforms":
+                f = pc.fs_uniforms(w, h, 1.0, int(rng.integers(0, 2)), int(rng.integers(0, 3))).tobytes()
+                for ctx in ctxs:
+                    ctx.set_uniforms(capi.PASS_FULLSCREEN, f)
+            elif op == "mode":
+                mode = int(rng.integers(0, 2))
+                for ctx in ctxs:
+                    ctx.set_present_mode(mode)
+            elif op == "read_canvas":
+                a, b = (ctx.read_canvas_rgba8() for ctx in ctxs)
+                assert np.array_equal(a, b), f"canvas differs at frame {frame}"
+                reads += 1
+            elif op == "read_accum":
+                a, b = (ctx.read_texture(capi.TEX_ACCUMULATION) for ctx in ctxs)
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+                reads += 1
+            elif op == "reset":
+                for ctx in ctxs:
+                    ctx.reset()
+                frame = 2
+            else:
+                size = [64, 40] if size == [80, 56] else [80, 56]
+                for ctx in ctxs:
+                    ctx.resize(*size)
+                    ctx.set_uniforms(capi.PASS_FULLSCREEN, pc.fs_uniforms(size[0], size[1], 1.0, 1, 1).tobytes())
+                frame = 2
+        a, b = (ctx.read_canvas_rgba8() for ctx in ctxs)
+        assert np.array_equal(a, b)
+        a, b = (ctx.read_texture(capi.TEX_CANVAS) for ctx in ctxs)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    finally:
+        own.close()
+        gpu_ctx.set_present_mode(capi.PRESENT_EXACT)
+        gpu_ctx.set_option(capi.OPT_PRESENT_DEPTH, 16)
+        gpu_ctx.resize(64, 64)
+
+
 def test_batch_capacity_and_launch_statistics(gpu_ctx, demo, env):
     w, h = 640, 360
     ctx = gpu_ctx
