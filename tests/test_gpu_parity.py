@@ -826,6 +826,7 @@ def test_presentation_differential_over_random_call_sequences(gpu_ctx, demo, env
             ctx.set_present_mode(capi.PRESENT_EXACT)
             ctx.set_option(capi.OPT_PRESENT_DEPTH, depth)
             ctx.resize(80, 56)
+            ctx.set_uniforms(capi.PASS_FULLSCREEN, pc.fs_uniforms(80, 56, 1.0, 1, 1).tobytes())      # (a shared context arrives with another test's)
         size = [80, 56]
         frame = 2
         everything = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE | capi.SUBMIT_FULLSCREEN

@@ -132,9 +132,9 @@ struct mi3pt_ctx {
     int wave_times_slots = 0;
     int nblocks = 0;
 
-    uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE];
-    uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE];
-    uint8_t u_fs[MI3PT_FULLSCREEN_UNIFORMS_SIZE];
+    uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE] = {};
+    uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE] = {};
+    uint8_t u_fs[MI3PT_FULLSCREEN_UNIFORMS_SIZE] = {};
 
     int storage = MI3PT_STORAGE_F32;
     int variant = 0;
@@ -161,7 +161,7 @@ struct mi3pt_ctx {
     // multi-frame accumulate, so the persistent kernel's drain tail is paid once per batch.
     // Anything that observes or changes device state flushes the queue first.
     struct PendingFrame {
-        uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE]; uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE];
+        uint8_t u_rt[MI3PT_RAYTRACE_UNIFORMS_SIZE] = {}; uint8_t u_acc[MI3PT_ACCUMULATE_UNIFORMS_SIZE] = {};
         bool present = false;                                   // EXACT: the canvas is drawn after this frame's mean ...
         uint8_t u_fs[MI3PT_FULLSCREEN_UNIFORMS_SIZE] = {};      // ... with the pass's uniforms as they were at its submit
     };
