@@ -408,6 +408,54 @@ def test_deferred_batching_matches_frame_by_frame(gpu_ctx, orc, demo, env):
     assert pc.same_bits(batched, acc), pc.describe_diff(batched, acc)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations_shipped_path_equals_per_pixel_kernel(gpu_ctx, demo, env, seed):
+    """Random image sizes (1 x 1 upwards, not multiples of the 8 x 8 job tiles), bounce counts from 0, samples per frame,
+    thin-lens and pinhole cameras, environment intensity / rotation, frame counts that cut batches anywhere, tile splits,
+    both storage formats: the shipped path (auto variant, batched persistent kernel) against the per-pixel kernel that runs
+    the WGSL control flow verbatim (variant 1, one fused launch per frame, pipelining off) -- same accumulation bits, same
+    path counters.  (The per-pixel kernel itself is held to the oracle by the tests above.)"""
+    rng = np.random.default_rng(1000 + seed)
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    w = int(rng.choice([1, 2, 7, 8, 9, 33, 64, 65, 100, 191]))
+    h = int(rng.choice([1, 3, 8, 15, 17, 40, 72, 113]))
+    nranks = int(rng.choice([1, 1, 2, 3]))
+    rank = int(rng.integers(0, nranks))
+    block_rows = int(rng.choice([8, 8, 5, 16]))
+    storage = capi.STORAGE_F16 if rng.random() < 0.3 else capi.STORAGE_F32
+    frames = int(rng.choice([1, 2, 5, 9, 17]))
+    spf = int(rng.choice([1, 1, 1, 2, 3]))
+    bounces = int(rng.choice([0, 1, 2, 4, 8]))
+    kw = dict(bounces=bounces, spf=spf, aperture=float(rng.choice([0.0, 0.0, 0.05])), focal=float(rng.choice([2.0, 4.1])),
+              intensity=float(rng.choice([1.0, 0.25])), rotation=float(rng.choice([0.0, 1.3])))
+    first = int(rng.integers(1, 1000))
+    mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+    ctx.set_storage(storage)
+    ctx.set_tile(rank, nranks, block_rows)
+    results = []
+    try:
+        for variant, pipelined in ((0, True), (1, False)):
+            ctx.set_kernel_variant(variant)
+            ctx.set_pipelining(pipelined)
+            ctx.resize(w, h)
+            ctx.reset_counters()
+            for f in range(first, first + frames):
+                pc.gpu_frame(ctx, pc.rt_uniforms(demo, w, h, frame=f, **kw), pc.acc_uniforms(w, h, f), mask)
+            results.append((ctx.read_texture(capi.TEX_ACCUMULATION), ctx.counters()))
+    finally:
+        ctx.set_kernel_variant(0)
+        ctx.set_pipelining(True)
+        ctx.set_storage(capi.STORAGE_F32)
+        ctx.set_tile(0, 1, 8)
+        ctx.resize(64, 64)
+    (a, ca), (b, cb) = results
+    what = f"{w}x{h} rank {rank}/{nranks} rows {block_rows} storage {storage} frames {frames} from {first} {kw}"
+    assert pc.same_bits(a, b), what + ": " + pc.describe_diff(a, b)
+    for k in pc.PATH_COUNTERS:
+        assert ca[k] == cb[k], (what, k)
+
+
 def test_accumulate_disabled_passes_frame_through(gpu_ctx, orc, demo, env):
     w = h = 32
     ctx = gpu_ctx
