@@ -467,6 +467,8 @@ def main():
         tile_rank, tile_world = (int(v) for v in args.tile.split("/")) if args.tile else (rank, world)
         job = Job(workload, width, height, tile_rank, tile_world, local_rank, args.variant, stream.cuda_stream)
         ctx = job.ctx
+        if present:
+            ctx.enable_timing(False)       # (an event pair around each of the 2 x frames little passes costs this leg 10-15 %)
         # the accumulation image lives in a torch tensor so RCCL can gather it in place
         accum = torch.zeros((ctx.local_rows, width, 4), dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()           # (the fill ran on torch's stream, the passes run on the context's)
@@ -586,7 +588,7 @@ def main():
             "ms_per_frame": round(a["elapsed"] * 1e3 / (psteps * FRAMES_PER_STEP), 4), "steps": psteps,
             "workload": workload_name("demo", a["job"].sc) + f", {width}x{height}, {BOUNCES} bounces; every frame: raytrace, accumulate and "
                         "fullscreen pass (de-noise + ACES + RGBA8 canvas), MI3PT_PRESENT_EXACT",
-            "frames_per_launch": a["frames_per_launch"]}
+            "presenting_frames_per_raytrace_launch": a["job"].ctx.get_option(capi.OPT_PRESENT_DEPTH)}
         a["job"].ctx.close()
 
     # ---- the forest leg (N = 1): config 5's scene -- 10 M triangles, 2.08 GB, the only one larger than the 256 MiB
