@@ -72,16 +72,18 @@ service_steps, leaf_lanes = hi(raw[:, 5]).sum(), lo(raw[:, 5]).sum()
 shade_lanes, hit_lanes = hi(raw[:, 6]).sum(), lo(raw[:, 6]).sum()
 path_lanes, segment_lanes = hi(raw[:, 7]).sum(), lo(raw[:, 7]).sum()
 print(f"walk steps {walk_steps} ({walk_steps / nframes / 1e6:.3f} M per frame), mean walking lanes/step "
-      f"{walk_lanes / max(walk_steps, 1):.1f}" + ("" if raw[:, 8].any() else f", of which on a leaf {leaf_lanes / max(walk_steps, 1):.1f}"))
+      f"{walk_lanes / max(walk_steps, 1):.1f}" + ("" if lo(raw[:, 8]).any() else f", of which on a leaf {leaf_lanes / max(walk_steps, 1):.1f}"))
 hit_steps, b_steps = hi(raw[:, 12]).sum(), lo(raw[:, 12]).sum()       # service steps that served the hit group / the miss + path group
 print(f"service steps {service_steps} ({service_steps / nframes / 1e3:.1f} k per frame): {hit_steps} shaded hits, "
       f"{hit_lanes / max(hit_steps, 1):.1f} lanes each; {b_steps} shaded misses / started paths, "
       f"{shade_lanes / max(b_steps, 1):.1f} miss lanes + {path_lanes / max(b_steps, 1):.1f} path starts each; "
       f"segment starts/service step {segment_lanes / max(service_steps, 1):.1f}")
-tri_steps = raw[:, 8].astype(np.int64).sum() if raw.shape[1] > 8 else 0
+tri_steps = lo(raw[:, 8]).sum() if raw.shape[1] > 8 else 0
+parked = hi(raw[:, 8]).sum() if raw.shape[1] > 8 else 0       # triangles parked in the wave, summed over its triangle steps
 if tri_steps:
     print(f"deferred-leaf walk: the walk steps above are node steps; triangle steps {tri_steps} "
-          f"({tri_steps / nframes / 1e6:.3f} M per frame), lanes/triangle step {leaf_lanes / tri_steps:.1f}")
+          f"({tri_steps / nframes / 1e6:.3f} M per frame), lanes/triangle step {leaf_lanes / tri_steps:.1f}; triangles parked in the "
+          f"wave when a triangle step starts {parked / tri_steps:.1f} ({parked / max(leaf_lanes, 1):.2f} per lane that has any)")
 print(f"steps per wave: walk {walk_steps / len(raw):.0f}  triangle {tri_steps / len(raw):.0f}  service {service_steps / len(raw):.0f}")
 if raw.shape[1] > 11 and raw[:, 9:12].any():
     cyc = raw[:, 9:12].astype(np.float64).sum(0)

@@ -1252,7 +1252,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     uint64_t t_empty_rt = 0ull;
     // diagnostic step statistics (wave-uniform; stored with the stamps)
     uint32_t st_walk_steps = 0, st_walk_lanes = 0, st_leaf_lanes = 0, st_service_steps = 0;
-    uint32_t st_shade_lanes = 0, st_hit_lanes = 0, st_path_lanes = 0, st_segment_lanes = 0, st_tri_steps = 0;
+    uint32_t st_shade_lanes = 0, st_hit_lanes = 0, st_path_lanes = 0, st_segment_lanes = 0, st_tri_steps = 0, st_parked = 0;
     uint32_t st_hit_steps = 0, st_b_steps = 0;       // service steps that served the hit group / the miss + path group
     uint32_t st_tail_node = 0, st_tail_tri = 0, st_tail_service = 0, st_tail_lanes = 0, st_live_at_empty = 0;   // after the queue ran empty
     uint64_t st_cyc_node = 0, st_cyc_tri = 0, st_cyc_service = 0, st_mark = t_begin_clk;     // shader cycles per kind of step
@@ -1357,7 +1357,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 // loads are in flight with the first's, and the lane needs one triangle step less
                 const bool two = k_tri_pair && (CULL ? nl > 1 : (has_leaf && nl > 1));
                 u_tri += (uint32_t)n_leaf + (k_tri_pair ? (uint32_t)__popcll(__ballot(two)) : 0u);      // (wave-uniform count: scalar)
-                if (wave_times) { st_switch(1); st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
+                if (wave_times) { st_switch(1); st_tri_steps++; st_parked += wave_sum((uint32_t)(has_leaf ? nl : 0)); st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
                 if (has_leaf) {
                     nl--;
                     const uint32_t ti = stack[(DEPTH - 1 - nl) * 64];
@@ -1959,7 +1959,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     if (wave_times && lane == 0) {
         uint64_t *w = wave_times + (size_t)blockIdx.x * 16;
         st_switch(2);
-        w[8] = st_tri_steps;
+        w[8] = ((uint64_t)st_parked << 32) | st_tri_steps;      // (high half: triangles parked in the wave, summed over its triangle steps)
         w[9] = st_cyc_node; w[10] = st_cyc_tri; w[11] = st_cyc_service;
         w[12] = ((uint64_t)st_hit_steps << 32) | st_b_steps;
 #ifdef PT_DIAG_SERVICE
