@@ -255,7 +255,8 @@ def inner_pmc(args):
     width, height = FOREST_IMAGE if args.workload == "forest" else image_size(1, args.scaling)
     if args.image:
         width, height = (int(v) for v in args.image.lower().split("x"))
-    job = Job(args.workload, width, height, variant=args.variant)
+    tile_rank, tile_world = (int(v) for v in args.tile.split("/")) if args.tile else (0, 1)
+    job = Job(args.workload, width, height, tile_rank, tile_world, variant=args.variant)
     per_launch = frames_per_launch(job.ctx.batch_capacity())
     job.frames(args.warmup * FRAMES_PER_STEP, per_launch, sync_each=True)
     job.frames(args.steps * FRAMES_PER_STEP, per_launch, sync_each=True)
@@ -282,6 +283,8 @@ def collect_pmc(args, timed_launches, log, workload=None, steps=None, warmup=Non
                    "--workload", workload, "--scaling", args.scaling, "--variant", str(args.variant)]
             if args.image and workload == args.workload:
                 cmd += ["--image", args.image]
+            if args.tile and workload == args.workload:
+                cmd += ["--tile", args.tile]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
             except (subprocess.TimeoutExpired, OSError) as e:
@@ -604,7 +607,7 @@ def main():
         pmc, source = {}, None
         key = {"workload": args.workload, "image": [width, height], "frames_per_launch": m["frames_per_launch"],
                "variant": args.variant, "n_gpus": world}
-        if world == 1 and not args.no_pmc and not args.tile and not under_profiler():
+        if world == 1 and not args.no_pmc and not under_profiler():
             try:
                 pmc = collect_pmc(args, m["launches"], log)
             except Exception as e:          # noqa: BLE001 -- a profiler problem must not lose the measurement

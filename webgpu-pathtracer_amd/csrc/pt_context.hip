@@ -956,7 +956,10 @@ extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
     const size_t canvas_px = (size_t)width * height;
     pt::Tile t;
     t.tex_w = width; t.tex_h = height; t.local_rows = local_rows; t.rank = rank; t.nranks = nranks; t.block_rows = block_rows;
-    const int nblocks = pt::raytrace_grid_blocks(t);
+    // per-wave counter slots: one per tile for the per-pixel kernels' grids, one per resident wave for the persistent kernels'
+    // (whose grid is capped by the launch's JOBS -- tiles x frames -- and may exceed the tiles of one frame)
+    const int ntiles_frame = pt::raytrace_grid_blocks(t);
+    const int nblocks = ntiles_frame > 0 ? std::max(ntiles_frame, pt::PT_MAX_RESIDENT_WAVES) : 0;
     // two counter sets: overlapping raytrace kernels of consecutive frames use alternate halves
     const size_t cbytes = 2 * (size_t)(nblocks ? nblocks : 1) * pt::CNT_COUNT * sizeof(uint64_t);
     float4 *radiance = nullptr, *accum = nullptr, *canvas = nullptr;

@@ -1755,8 +1755,23 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 mode = M_DEAD;        // until a path / segment is started below
                 if (ended) {
                     if constexpr (SPF1) {
-                        // one sample per frame: the pixel is finished (:455, :477); incomingLight = 0 + light
-                        write_radiance(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
+                        // the sample is finished: incomingLight += trace(...) (:450); after the last one the pixel is, too (:455, :477).
+                        // One sample per frame (the reference's default): incomingLight = 0 + light, stored at once.  More: the
+                        // running sum and the number of samples taken rest in the pixel's own texel of the frame's radiance slot
+                        // (xyz, w; zeroed when the job was handed out) -- the lane is the texel's only writer until the pixel is
+                        // finished, and nothing has to be carried through the walks.  Same additions in the same order.
+                        f3 pix = F3(0.0f, 0.0f, 0.0f) + light;
+                        bool finished = true;
+                        if (un.samples_per_frame != 1) {
+                            float4 *const px = L.radiance + ((size_t)(slot >> 16) * L.slot_pixels + gx);
+                            const float4 sum = *px;
+                            pix = xyz(sum) + light;
+                            const float taken = sum.w + 1.0f;
+                            finished = taken >= spf_f;
+                            if (finished) pix = F3(pix.x / spf_f, pix.y / spf_f, pix.z / spf_f);
+                            else { *px = make_float4(pix.x, pix.y, pix.z, taken); mode = M_PATH; }
+                        }
+                        if (finished) write_radiance(L, gx, slot >> 16, pix);
                         if (L.tile_cost) {      // a measuring launch: this path's segments go to its tile's cost
                             const int row = fast_div((int)gx, S.dv_w), col = (int)gx - row * L.tile.tex_w;
                             atomicAdd(L.tile_cost + ((row >> 3) * S.tiles_x + (col >> 3)), (slot & 0xffffu) + 1u);
@@ -1833,6 +1848,8 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                             job_px = (uint32_t)px; job_py = (uint32_t)pgy;
                             gx = (uint32_t)ply * (uint32_t)L.tile.tex_w + (uint32_t)px;
                             slot = (uint32_t)fslot << 16;
+                            if (un.samples_per_frame != 1)      // (the pixel's running sum and sample count: see the path end above)
+                                L.radiance[(size_t)fslot * L.slot_pixels + gx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         } else {
                             gx = (uint32_t)px; gy = (uint32_t)pgy; ly = (uint32_t)ply;
                             slot = (uint32_t)fslot;
@@ -1861,7 +1878,23 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     }
                 }
                 float uvx, uvy;
-                const uint32_t pxx = SPF1 ? job_px : gx, pyy = SPF1 ? job_py : gy;
+                uint32_t pxx = SPF1 ? job_px : gx, pyy = SPF1 ? job_py : gy;
+                if constexpr (SPF1) {
+                    if (un.samples_per_frame != 1) {
+                        // a later sample of a multi-sample frame: the lane only carries the texel index; its pixel, once more
+                        const int row = fast_div((int)gx, S.dv_w);
+                        pxx = gx - (uint32_t)row * (uint32_t)L.tile.tex_w;
+                        pyy = (uint32_t)local_to_global_row(row, L.tile);
+                    }
+                    // no sample to take (samplesPerFrame < 1: the shader's loop does not run and the sum, 0, is divided by
+                    // f32(samplesPerFrame), :441-455) or no segment to trace (maxBounces < 1: every path returns 0, :376-377):
+                    // the pixel is 0 / f32(samplesPerFrame)
+                    if (un.samples_per_frame < 1 || un.max_bounces < 1) {
+                        const float z = un.samples_per_frame == 1 ? 0.0f : 0.0f / spf_f;
+                        write_radiance(L, gx, slot >> 16, F3(z, z, z));
+                        break;
+                    }
+                }
                 if (TUNED || res_ordinary_ != 0) { uvx = div_pre((float)pxx, un.res_x, inv_res_x); uvy = div_pre((float)pyy, un.res_y, inv_res_y); }
                 else { uvx = (float)pxx / un.res_x; uvy = (float)pyy / un.res_y; }
                 const f3 dir0 = camera_direction(cf, un.aspect, uvx, uvy);
@@ -1886,14 +1919,9 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 if constexpr (SPF1) slot &= 0xffff0000u; else bounce = 0;
                 light = F3(0.0f, 0.0f, 0.0f);
                 ray_color = F3(1.0f, 1.0f, 1.0f);
-                if (TUNED || un.max_bounces > 0) { need_segment = true; break; }
-                if constexpr (SPF1) {       // (max_bounces == 0: the path is over before it began)
-                    write_radiance(L, gx, slot >> 16, F3(0.0f, 0.0f, 0.0f) + light);
-                    break;
-                } else {
-                    incoming = incoming + light;
-                    sample++;
-                }
+                if (SPF1 || un.max_bounces > 0) { need_segment = true; break; }
+                incoming = incoming + light;        // (max_bounces == 0: the path is over before it began)
+                sample++;
             }
         }
 #ifdef PT_DIAG_SERVICE
@@ -2019,7 +2047,12 @@ int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, 
     }
     int resident = num_cus * waves_per_cu;                            // the device's own CU count (hipDeviceProp_t)
     if (resident > PT_MAX_RESIDENT_WAVES) resident = PT_MAX_RESIDENT_WAVES;
-    return ntiles < resident ? ntiles : resident;
+    // One wave per JOB at most -- (frame slot, tile) pairs, not tiles of one frame.  Until round 4 this read `ntiles`: a rank of an
+    // 8-way split of 1080p has 17 x 240 = 4 080 tiles per frame, so its 512-frame launches ran 4 080 of the 5 120 wave slots
+    // (16 instead of 20 per CU) -- the "unexplained +14 % per pixel" of a rank of eight (profiles/r04_a_rank_penalty.log:
+    // fewer wave cycles per ray than the whole image, yet more time per ray).
+    const long long jobs = (long long)ntiles * (nframes > 0 ? nframes : 1);
+    return jobs < (long long)resident ? (int)jobs : resident;
 }
 
 int raytrace_grid_blocks(const Tile &tile)
@@ -2033,7 +2066,8 @@ int raytrace_grid_blocks(const Tile &tile)
 // default -- no per-pixel sum and sample counter to carry through the walk: five registers less)
 static bool launch_is_one_spp(const RtLaunch &L, bool fuse)
 {
-    return L.un.samples_per_frame == 1 && !fuse && L.un.max_bounces < 65536 && L.nframes <= 65535;
+    // (frame slot and bounce share a word; the sample count of a multi-sample frame is a float in the pixel's texel)
+    return !fuse && L.un.max_bounces < 65536 && L.nframes <= 65535 && L.un.samples_per_frame <= 16777216;
 }
 // The tuned twin runs when: one sample per frame, no diagnostic buffer, every step-voting option at its default (they are
 // constants there), a scene with nodes whose root is an internal node with a guard-range box, the API's environment size,
@@ -2046,7 +2080,7 @@ static bool launch_is_tuned(const RtLaunch &L, bool fuse, int variant)
            L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 &&
            L.scene.nnodes != 0 && (L.scene.flags & 1u) != 0u && (L.scene.root_ref & PT_REF_LEAF) == 0u &&
            L.scene.env_w == ENV_W && L.scene.env_h == ENV_H &&
-           L.service != nullptr && L.un.max_bounces > 0 && L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
+           L.service != nullptr && L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
            L.un.res_y >= 9.5367431640625e-07f && L.un.res_y <= 1.099511627776e12f;
 }
 
