@@ -307,6 +307,14 @@ int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option /* mi3pt_option */, int *v
 /* The variant a raytrace submit would run right now: the selected one, or its fall-back when the
  * uploaded scene does not admit it (tests use it to make sure nothing fell back silently). */
 int mi3pt_debug_active_variant(mi3pt_ctx *ctx, int *variant);
+/* The kernel the most recent raytrace launch actually ran: kind 0 = per-pixel kernel (one 8x8 tile per wave, the WGSL control
+ * flow: variants 1 / 2, and the fall-back for launches beyond the state-machine kernel's packing limits), 1 = the persistent
+ * state-machine kernel; its variant after the scene / launch fall-backs; lean = 1: the build without diagnostics that every
+ * ordinary launch runs (96 vector registers, five waves per SIMD) -- whatever samplesPerFrame, maxBounces, storage format,
+ * pipelining and presentation mode are (tests/test_gpu_parity.py::test_every_reference_setting_runs_the_lean_kernel); 0: the
+ * diagnostic twin (a diagnostic buffer is bound or a step-voting option was changed through mi3pt_debug_set_option);
+ * workgroups = the launch's grid.  Any pointer may be NULL. */
+int mi3pt_debug_last_launch(mi3pt_ctx *ctx, int *kind, int *variant, int *lean, int *workgroups);
 /* The reference's environment importance sampling (raytrace.wgsl:315-367: getEnvironmentMapUV /
  * ...MarginalCDF / ...ConditionalCDF / ...PDF over the CDF texture of renderer.ts:159-266) is dead
  * code as shipped -- its call sites raytrace.wgsl:398 and :402-404 are commented out.  enabled = 1

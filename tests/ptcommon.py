@@ -106,3 +106,31 @@ def check_counters(cnt, want, culled=False, what=""):
     else:
         for k in WALK_COUNTERS:
             assert cnt[k] == want[k], f"{what} counter {k}: gpu {cnt[k]} reference {want[k]}"
+
+
+def set_variant_or_skip(ctx, variant):
+    """Kernel variants 3, 5, 6 and 8 (measured, not adopted) only exist in the experiment build of the library
+    (`make -C webgpu-pathtracer_amd/csrc experiments`, loaded through MI3PT_LIBRARY): a release library refuses them."""
+    import pytest
+    from mi3pt_host import capi
+    try:
+        ctx.set_kernel_variant(variant)
+    except capi.Mi3ptError as e:
+        if "experiment build only" in e.message:
+            pytest.skip(f"kernel variant {variant}: experiment build only")
+        raise
+
+
+def variants_available(ctx, variants):
+    """The subset of `variants` this build of the library has (see set_variant_or_skip)."""
+    from mi3pt_host import capi
+    out = []
+    for v in variants:
+        try:
+            ctx.set_kernel_variant(v)
+            out.append(v)
+        except capi.Mi3ptError as e:
+            if "experiment build only" not in e.message:
+                raise
+    ctx.set_kernel_variant(0)
+    return tuple(out)

@@ -197,7 +197,7 @@ def test_stack_overflow_inside_a_frame(gpu_ctx, orc, env, variant):
     ctx.upload_triangles(tris)
     ctx.upload_materials(mats)
     ctx.upload_environment(env)
-    ctx.set_kernel_variant(variant)
+    pc.set_variant_or_skip(ctx, variant)
     ctx.set_tile(0, 1, 8)
     w = h = 24
     ctx.resize(w, h)
@@ -260,7 +260,7 @@ def test_equal_t_ties_keep_the_first_visited_leaf_in_every_kernel(gpu_ctx, orc, 
         want = orc.accumulate(pc.acc_uniforms(w, h, f).tobytes(), w, h, img, want)
         ocnt = c if ocnt is None else {k: ocnt[k] + c[k] for k in c}
     picked = set()
-    for variant in (2, 4, 7, 8, 9, 10):
+    for variant in pc.variants_available(ctx, (2, 4, 7, 8, 9, 10)):
         ctx.set_kernel_variant(variant)
         ctx.reset()
         ctx.reset_counters()
@@ -298,7 +298,7 @@ def test_raytrace_pass_bit_identical(gpu_ctx, orc, demo, env, case, variant):
     w, h, bounces, spf, aperture, focal, frame, rotation = case
     ctx = gpu_ctx
     pc.upload_scene(ctx, demo, env)
-    ctx.set_kernel_variant(variant)
+    pc.set_variant_or_skip(ctx, variant)
     ctx.set_storage(capi.STORAGE_F32)
     ctx.set_tile(0, 1, 8)
     ctx.resize(w, h)
@@ -456,6 +456,58 @@ def test_random_configurations_shipped_path_equals_per_pixel_kernel(gpu_ctx, dem
         assert ca[k] == cb[k], (what, k)
 
 
+@pytest.mark.parametrize("variant", [0, 4, 7, 9, 10, 11, 12])
+def test_every_reference_setting_runs_the_lean_kernel(gpu_ctx, orc, demo, env, variant):
+    """samplesPerFrame 1 .. 16 (the reference's slider, main.ts:188), maxBounces 0 .. 10 (main.ts:195), both storage formats,
+    queued frames and a launch per frame (pipelining off), the raytrace pass alone: every one of them runs the lean build of
+    the state-machine kernel (round 3 sent everything but samplesPerFrame == 1 to a 128-register twin with scratch) and
+    renders the oracle's bits.  The sum over a frame's samples lives in the pixel's texel of the frame's radiance slot."""
+    w, h = 48, 40
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(w, h)
+    osc = pc.oracle_scene(orc, demo, env)
+    mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+    try:
+        ctx.set_kernel_variant(variant)
+        want_variant = ctx.active_variant()
+        assert want_variant >= 4
+        if variant:
+            assert want_variant == variant
+        for spf, bounces, storage, pipelined, frames, aperture in ((1, 8, capi.STORAGE_F32, True, 3, 0.0), (2, 3, capi.STORAGE_F32, True, 3, 0.0),
+                                                                   (5, 2, capi.STORAGE_F16, True, 2, 0.05), (16, 1, capi.STORAGE_F32, True, 1, 0.0),
+                                                                   (3, 0, capi.STORAGE_F32, True, 2, 0.0), (1, 0, capi.STORAGE_F16, False, 2, 0.0),
+                                                                   (1, 4, capi.STORAGE_F32, False, 3, 0.0), (4, 2, capi.STORAGE_F16, False, 2, 0.0),
+                                                                   (0, 2, capi.STORAGE_F32, True, 2, 0.0), (-1, 2, capi.STORAGE_F32, False, 1, 0.0)):
+            ctx.set_storage(storage)
+            ctx.set_pipelining(pipelined)
+            ctx.reset()
+            want = np.zeros((h, w, 4), np.float32)
+            for f in range(2, 2 + frames):
+                u = pc.rt_uniforms(demo, w, h, frame=f, bounces=bounces, spf=spf, aperture=aperture, focal=3.0)
+                a = pc.acc_uniforms(w, h, f)
+                pc.gpu_frame(ctx, u, a, mask)
+                f16 = storage == capi.STORAGE_F16
+                img, _ = orc.raytrace(osc, u.tobytes(), w, h, store_f16=f16)
+                want = orc.accumulate(a.tobytes(), w, h, img, want, store_f16=f16)
+            got = ctx.read_texture(capi.TEX_ACCUMULATION)
+            what = f"variant {variant} spf {spf} bounces {bounces} storage {storage} pipelined {pipelined}"
+            assert pc.same_bits(got, want), what + ": " + pc.describe_diff(got, want)
+            last = ctx.last_launch()
+            assert last == {"kind": 1, "variant": want_variant, "lean": True, "workgroups": last["workgroups"]}, (what, last)
+        # the raytrace pass alone (no accumulate): the frame's radiance, same kernel
+        u = pc.rt_uniforms(demo, w, h, frame=9, bounces=4, spf=3)
+        pc.gpu_frame(ctx, u)
+        img, _ = orc.raytrace(osc, u.tobytes(), w, h)
+        assert pc.same_bits(ctx.read_texture(capi.TEX_OUTPUT), img)
+        assert ctx.last_launch()["lean"] and ctx.last_launch()["kind"] == 1
+    finally:
+        ctx.set_kernel_variant(0)
+        ctx.set_pipelining(True)
+        ctx.set_storage(capi.STORAGE_F32)
+
+
 def test_accumulate_disabled_passes_frame_through(gpu_ctx, orc, demo, env):
     w = h = 32
     ctx = gpu_ctx
@@ -598,18 +650,19 @@ def test_full_hd_properties(gpu_ctx, orc, demo, env):
     u = pc.rt_uniforms(demo, w, h, frame=2, bounces=8)
     a = pc.acc_uniforms(w, h, 2)
     images = {}
-    for variant in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+    have = pc.variants_available(ctx, (1, 2, 3, 4, 5, 6, 7, 8, 9, 10))
+    for variant in have:
         ctx.set_kernel_variant(variant)
         ctx.reset()
         ctx.reset_counters()
         pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
         images[variant] = (ctx.read_texture(capi.TEX_ACCUMULATION), ctx.counters())
-    assert all(pc.same_bits(images[v][0], images[2][0]) for v in (1, 3, 4, 5, 6, 7, 8, 9, 10))
+    assert all(pc.same_bits(images[v][0], images[2][0]) for v in have)
     pc.check_counters(images[10][1], images[2][1], culled=True, what="wide culling walk")
     pc.check_counters(images[9][1], images[2][1], culled=True, what="distance-culling walk")
     assert images[9][1]["box_tests"] < 0.9 * images[2][1]["box_tests"]      # it does skip boxes
     strip = lambda c: {k: v for k, v in c.items() if k != "reserved"}   # (reserved = fallback-slab count)
-    assert all(strip(images[v][1]) == strip(images[2][1]) for v in (1, 3, 4, 5, 6, 7, 8))
+    assert all(strip(images[v][1]) == strip(images[2][1]) for v in have if v < 9)
     cnt = images[2][1]
     # the prepared-reciprocal slab test is really in use: only a small share of segments falls back
     assert images[4][1]["reserved"] < 0.05 * cnt["rays"]
@@ -719,7 +772,7 @@ def test_depth_first_relabelling_is_bit_identical(gpu_ctx, demo, env):
         assert pc.same_bits(want[2][0], want[7][0])
         ctx.set_packet_layout(1)
         pc.upload_scene(ctx, sc, env)          # the relabelling applies to what is uploaded from here on
-        for v in (1, 2, 3, 4, 6, 7, 8):
+        for v in pc.variants_available(ctx, (1, 2, 3, 4, 6, 7, 8)):
             img, cnt = render(v)
             assert pc.same_bits(img, want[2][0]), f"{sc.name} variant {v}: " + pc.describe_diff(img, want[2][0])
             pc.check_counters(cnt, want[2][1], culled=False, what=f"{sc.name}, relabelled, variant {v}")

@@ -72,6 +72,7 @@ struct mi3pt_ctx {
     int wide_leaf_cap = 0;
     uint32_t wide_root = 0;
     int num_cus = 256;              // hipDeviceProp_t::multiProcessorCount
+    pt::RtRoute last_route = { 0, 0, false, 0 };      // the kernel the most recent raytrace launch ran (mi3pt_debug_last_launch)
     // Debug: packet / triangle numbering (mi3pt_debug_set_packet_layout).  0 = breadth-first packets,
     // triangles as uploaded (shipped).  1 = packets in the reference's visiting order (node, right
     // subtree, left subtree) and triangles in leaf-visiting order: a pure relabelling.
@@ -355,7 +356,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     CREATE_TRY(hipMalloc(&ctx->d_cdf, env_bytes));
     CREATE_TRY(hipMalloc((void **)&ctx->d_tile_counter, 256));
     CREATE_TRY(hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * pt::SM_OVERFLOW_ENTRIES * 64 * 4));
-    CREATE_TRY(hipMalloc((void **)&ctx->d_service, (size_t)SERVICE_SLOTS * service_slot_bytes()));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_service, (size_t)(SERVICE_SLOTS + 1) * service_slot_bytes()));      // (+ 1: the launches mi3pt_submit runs at once on the main stream)
     CREATE_TRY(hipMalloc(&ctx->d_fs_taps, pt::fullscreen_taps_bytes()));
     CREATE_TRY(hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream));     // self-cleaning afterwards
     // a word the command processor can poll (hipStreamWaitValue32) and a running kernel can write;
@@ -489,6 +490,10 @@ extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
     PT_GROUP_ALL(ctx, false, mi3pt_set_kernel_variant(m, variant));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     if (variant < 0 || variant > 12) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..12");
+#ifndef MI3PT_EXPERIMENTS
+    if (variant == 3 || variant == 5 || variant == 6 || variant == 8)
+        return pt_set_error(MI3PT_ERR_INVALID, "kernel variants 3, 5, 6 and 8 (measured, not adopted) exist in the experiment build only: make -C webgpu-pathtracer_amd/csrc experiments");
+#endif
     if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
     return MI3PT_OK;
@@ -597,6 +602,17 @@ extern "C" int mi3pt_debug_active_variant(mi3pt_ctx *ctx, int *variant)
     if (int rc = prepare_layout(ctx)) return rc;
     if (int rc = prepare_cull(ctx)) return rc;
     *variant = pick_variant(ctx);
+    return MI3PT_OK;
+}
+
+extern "C" int mi3pt_debug_last_launch(mi3pt_ctx *ctx, int *kind, int *variant, int *lean, int *workgroups)
+{
+    PT_GROUP(ctx, mi3pt_debug_last_launch(group_member0(ctx), kind, variant, lean, workgroups));
+    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
+    if (kind) *kind = ctx->last_route.kind;
+    if (variant) *variant = ctx->last_route.variant;
+    if (lean) *lean = ctx->last_route.lean ? 1 : 0;
+    if (workgroups) *workgroups = ctx->last_route.blocks;
     return MI3PT_OK;
 }
 
@@ -1748,6 +1764,7 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame *frames, i
             L.drain_seq = ++ctx->launch_seq;
         }
     }
+    ctx->last_route = pt::raytrace_route(L, pick_variant(ctx));
     pt::launch_raytrace_setup(L, false, pick_variant(ctx), rs);
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev_rt[par][0], rs));
@@ -1902,9 +1919,16 @@ extern "C" int mi3pt_submit(mi3pt_ctx *ctx, unsigned pass_mask)
         if (int rc = flush_pending(ctx)) return rc;      // anything but a queued frame runs after the queue
         for (bool &r : ctx->ev_recorded) r = false;
         if (do_rt) {
-            const pt::RtLaunch L = build_launch(ctx, ctx->u_rt, acc);
-            // Fuse when the accumulate pass covers exactly the pixels the raytrace pass writes.
-            const bool fused = do_acc && same_region;
+            pt::RtLaunch L = build_launch(ctx, ctx->u_rt, acc);
+            // Fuse when the accumulate pass covers exactly the pixels the raytrace pass writes (the per-pixel kernels; the
+            // state-machine kernel writes the frame's radiance and the accumulate pass follows as a kernel of its own: same bits).
+            const bool fused = do_acc && same_region && pt::raytrace_variant_fuses(variant);
+            // (the service block of a launch that runs at once: its own slot -- launches on the main stream follow each other,
+            // and the batches launched before it are waited for by this stream)
+            L.service = reinterpret_cast<pt::RtService *>(ctx->d_service + (size_t)SERVICE_SLOTS * service_slot_bytes());
+            L.block_counters = ctx->d_block_counters;
+            ctx->last_route = pt::raytrace_route(L, variant);
+            pt::launch_raytrace_setup(L, fused, variant, ctx->stream);
             if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0][0], ctx->stream));
             pt::launch_raytrace(L, fused, variant, ctx->stream);
             HIP_TRY(hipGetLastError());

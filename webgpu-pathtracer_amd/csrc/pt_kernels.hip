@@ -787,6 +787,7 @@ PT_DEV int lane_rank(unsigned long long mask)
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+#ifdef MI3PT_EXPERIMENTS
 template <bool FUSE>
 PT_DEV void write_pixel(const RtLaunch &L, uint32_t gx, uint32_t gy, uint32_t ly, f3 color, uint32_t slot = 0u)
 {
@@ -805,6 +806,7 @@ PT_DEV void write_pixel(const RtLaunch &L, uint32_t gx, uint32_t gy, uint32_t ly
         L.radiance[(size_t)slot * L.slot_pixels + idx] = make_float4(color.x, color.y, color.z, 1.0f);
     }
 }
+#endif
 
 // unfused store of one finished (pixel, frame slot): texel index within the slot's image
 // (the storage format -- fp32, or the reference's rgba16float, renderer.ts:102 -- is a wave-uniform choice: one scalar
@@ -816,6 +818,7 @@ PT_DEV void write_radiance(const RtLaunch &L, uint32_t texel, uint32_t slot, f3 
         make_float4(store_round(color.x, f16), store_round(color.y, f16), store_round(color.z, f16), 1.0f);
 }
 
+#ifdef MI3PT_EXPERIMENTS
 struct PathSlot {
     f3 o, d, ray_color, light, incoming;
     uint32_t gx, gy, ly, seed;
@@ -983,6 +986,8 @@ __global__ void __launch_bounds__(64) k_raytrace_persistent(const RtLaunch L)
         c[CNT_MISS] += s_miss; c[CNT_OVERFLOW] += s_ovf; c[CNT_PIXELS] += s_pix;
     }
 }
+
+#endif      // MI3PT_EXPERIMENTS (variant 3)
 
 // ---------------------------------------------------------------------------------
 // VARIANT 4: persistent waves, per-lane state machine.
@@ -1156,10 +1161,13 @@ PT_DEV T uniform_block(const T &v)
 // YMAX (FILT only): the culling condition (S) of DESIGN.md 3a evaluated on the axis that sets the box's entry distance
 // only, with the largest of the three |RN(1/d_i)| -- one operation per child instead of four; it skips less, so the
 // context chooses it only for scenes whose culling margins are negligible (SceneRefs::cull_ymax).
-template <bool FUSE, bool TOPLDS, bool DEFER, bool CULL = false, bool WIDE = false, bool SPF1 = false, bool DIAG = true,
-          bool FILT = false, bool YMAX = false>
+//
+// DIAG = false: the lean build every ordinary launch runs (below).  TOPLDS: experiment builds only.
+template <bool DEFER, bool CULL, bool WIDE, bool FILT, bool YMAX, bool DIAG, bool TOPLDS = false>
 __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_WAVES_PER_SIMD) k_raytrace_sm(const RtLaunch L)
 {
+    static_assert(!CULL || DEFER, "the culling walks park their leaves");
+    static_assert((!WIDE || CULL) && (!FILT || WIDE) && (!YMAX || FILT), "WIDE needs CULL, FILT needs WIDE, YMAX needs FILT");
     // DIAG = false (the shipped walks' batched launches when no diagnostic buffer is bound): the per-wave step statistics
     // and stamps are compiled out -- two dozen scalar registers that the walk loop's own scalars were spilled for
     uint64_t *const wave_times = DIAG ? L.wave_times : nullptr;
@@ -1168,9 +1176,11 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     const int k_shade_split = DIAG ? L.shade_split : PT_DEFAULT_SHADE_SPLIT, k_tail_policy = DIAG ? L.tail_policy : PT_DEFAULT_TAIL_POLICY;
     const int k_job_chunk = DIAG ? L.job_chunk : PT_DEFAULT_JOB_CHUNK;
     const bool k_tri_pair = DIAG ? L.tri_pair != 0 : true;
-    // ... as are: a scene with nodes whose root is an internal node with a guard-range box, a
-    // resolution of ordinary magnitude, maxBounces > 0
     constexpr bool TUNED = !DIAG;
+    // ... and, in the lean builds of the culling walks, so are the conditions every scene that admits those walks meets at an
+    // ordinary resolution: a scene with nodes whose root is an internal node with a guard-range box, a resolution of ordinary
+    // magnitude (launch_assumptions_hold; a launch that fails them runs the lean build of variant 7 or 4, which assumes nothing)
+    constexpr bool ASSUME = TUNED && CULL;
     constexpr int DEPTH = PT_SM_LDS_DEPTH;                  // LDS stack entries per lane
     constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
@@ -1183,11 +1193,11 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     // every ray walks.  One-wave workgroups (a multi-wave workgroup would hold its LDS and
     // wave slots until its slowest wave has drained) => a private 4 KB copy per wave.
     __shared__ float4 top_lds[TOPLDS ? PT_SM_TOP_PACKETS * 4 : 1];
-    // SPF1: a path's throughput and collected light are only touched by the service step; between service steps they
-    // rest here (6 floats per lane, [k][lane]) instead of in six registers carried through every node and triangle step
-    __shared__ float park_lds[SPF1 ? 6 * 64 : 1];
+    // A path's throughput and collected light are only touched by the service step; between service steps they rest here
+    // (6 floats per lane, [k][lane]) instead of in six registers carried through every node and triangle step
+    __shared__ float park_lds[6 * 64];
     const int lane = threadIdx.x;
-    float *park = park_lds + (SPF1 ? lane : 0);
+    float *park = park_lds + lane;
     uint32_t *stack = stack_lds + lane;
     const uint32_t top_cap = (uint32_t)L.top_packets < (uint32_t)PT_SM_TOP_PACKETS ? (uint32_t)L.top_packets : (uint32_t)PT_SM_TOP_PACKETS;
     const uint32_t ntop = !TOPLDS ? 0u : (L.scene.npackets < top_cap ? L.scene.npackets : top_cap);
@@ -1276,9 +1286,11 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0 };      // per-lane: only what the in-order walk counts under divergence
     uint32_t u_rays = 0, u_box = 0, u_tri = 0, u_hit = 0, u_miss = 0, u_pix = 0, u_slow = 0;     // wave-uniform (scalar) counts
     int mode = M_DEAD;
-    f3 o = F3(0.0f, 0.0f, 0.0f), d = o, ray_color = o, light = o, incoming = o;
-    uint32_t gx = 0u, gy = 0u, ly = 0u, seed = 0u, slot = 0u;
-    int32_t bounce = 0, sample = 0;
+    f3 o = F3(0.0f, 0.0f, 0.0f), d = o, ray_color = o, light = o;
+    // What a lane carries through its walks besides the ray: the texel index of its pixel within the rank's image (the pixel's
+    // coordinates are only needed for the camera ray, formed in the service step) and frame slot << 16 | bounce.  The sum over a
+    // multi-sample frame's samples and their count rest in the pixel's texel of the frame's radiance slot (see the path end).
+    uint32_t gx = 0u, seed = 0u, slot = 0u;
     Best best;
     best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
     RayPre pre;
@@ -1684,9 +1696,6 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
         const int &tiles_x = S.tiles_x, &ntiles_frame = S.ntiles_frame, &ntiles = S.ntiles;
         const int &grp_jobs = S.grp_jobs, &grp_full = S.grp_full, &grp_last = S.grp_last;
         const FastDiv &dv_frame = S.dv_frame, &dv_grp = S.dv_grp, &dv_gs = S.dv_gs, &dv_last = S.dv_last, &dv_tx = S.dv_tx;
-        auto per_sample = [&](const f3 &sum) {     // incomingLight / f32(samplesPerFrame), raytrace.wgsl:455 (x / 1 == x)
-            return un.samples_per_frame == 1 ? sum : F3(sum.x / spf_f, sum.y / spf_f, sum.z / spf_f);
-        };
         const unsigned long long m_hit = __ballot(mode == M_SHADE && best.tri >= 0);
         const int n_hit = (int)__popcll(m_hit);
         const int n_b = (int)__popcll(__ballot((mode == M_SHADE && best.tri < 0) || mode == M_PATH || (mode == M_DEAD && !feed_empty)));
@@ -1709,11 +1718,9 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
             u_hit += (uint32_t)__popcll(__ballot(shade_hit));
             u_miss += (uint32_t)__popcll(__ballot(shade_miss));
             bool ended = true;
-            if constexpr (SPF1) {
-                if (shade_hit || shade_miss) {
-                    ray_color = F3(park[0], park[64], park[128]);
-                    light = F3(park[192], park[256], park[320]);
-                }
+            if (shade_hit || shade_miss) {
+                ray_color = F3(park[0], park[64], park[128]);
+                light = F3(park[192], park[256], park[320]);
             }
 #ifdef PT_DIAG_SERVICE
             if (wave_times) st_switch(3);
@@ -1736,8 +1743,8 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 const f3 emitted = xyz(m3) * m3.w;
                 light = light + emitted * ray_color;
                 ray_color = ray_color * mix(xyz(m0), xyz(m1), is_specular);
-                if constexpr (SPF1) { slot++; ended = (int32_t)(slot & 0xffffu) >= un.max_bounces; }
-                else { bounce++; ended = bounce >= un.max_bounces; }
+                slot++;
+                ended = (int32_t)(slot & 0xffffu) >= un.max_bounces;
             }
 #ifdef PT_DIAG_SERVICE
             if (wave_times) st_switch(4);
@@ -1747,14 +1754,14 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 
                 float u, v;
                 env_uv_from_dir(d, sinr, cosr, u, v);
-                const f3 env = sample_env(sc.env, TUNED ? ENV_W : sc.env_w, TUNED ? ENV_H : sc.env_h, u, v);      // (the environment texture is 1024 x 512 by the API: renderer.ts:76-85)
+                const f3 env = sample_env(sc.env, ENV_W, ENV_H, u, v);      // (the environment texture is 1024 x 512 by the API: renderer.ts:76-85, mi3pt_upload_environment)
                 light = light + (ray_color * env) * un.env_intensity;
             }
             PT_SERVICE_PART();
             if (shade_hit || shade_miss) {
                 mode = M_DEAD;        // until a path / segment is started below
                 if (ended) {
-                    if constexpr (SPF1) {
+                    {
                         // the sample is finished: incomingLight += trace(...) (:450); after the last one the pixel is, too (:455, :477).
                         // One sample per frame (the reference's default): incomingLight = 0 + light, stored at once.  More: the
                         // running sum and the number of samples taken rest in the pixel's own texel of the frame's radiance slot
@@ -1776,15 +1783,6 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                             const int row = fast_div((int)gx, S.dv_w), col = (int)gx - row * L.tile.tex_w;
                             atomicAdd(L.tile_cost + ((row >> 3) * S.tiles_x + (col >> 3)), (slot & 0xffffu) + 1u);
                         }
-                    } else {
-                        incoming = incoming + light;
-                        sample++;
-                        if (sample >= un.samples_per_frame) {
-                            // pixel finished (:455, :477): the slot is free for a refill
-                            write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
-                        } else {
-                            mode = M_PATH;
-                        }
                     }
                 } else {
                     need_segment = true;
@@ -1796,7 +1794,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
 #endif
         PT_SERVICE_PART();
         // refill: free lanes take new jobs
-        uint32_t job_px = 0u, job_py = 0u;          // SPF1: the pixel a lane has just been given (used below, in this step)
+        uint32_t job_px = 0u, job_py = 0u;          // the pixel a lane has just been given (used below, in this step)
         if (do_b) {
             unsigned long long dead = __ballot(mode == M_DEAD && !need_segment);
             while (dead != 0ull && !feed_empty) {
@@ -1842,20 +1840,13 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     if (ok) {
                         got_job = true;
                         seed = ((uint32_t)px + (uint32_t)pgy * res_w) + (un.frame + (uint32_t)fslot) * 719393u + PT_SEED;    // :435-436
-                        if constexpr (SPF1) {
-                            // the pixel's coordinates are only needed for the camera ray, formed in this very step;
-                            // what a lane carries through its walks: texel index, frame slot << 16 | bounce
-                            job_px = (uint32_t)px; job_py = (uint32_t)pgy;
-                            gx = (uint32_t)ply * (uint32_t)L.tile.tex_w + (uint32_t)px;
-                            slot = (uint32_t)fslot << 16;
-                            if (un.samples_per_frame != 1)      // (the pixel's running sum and sample count: see the path end above)
-                                L.radiance[(size_t)fslot * L.slot_pixels + gx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        } else {
-                            gx = (uint32_t)px; gy = (uint32_t)pgy; ly = (uint32_t)ply;
-                            slot = (uint32_t)fslot;
-                            sample = 0;
-                            incoming = F3(0.0f, 0.0f, 0.0f);
-                        }
+                        // the pixel's coordinates are only needed for the camera ray, formed in this very step;
+                        // what a lane carries through its walks: texel index, frame slot << 16 | bounce
+                        job_px = (uint32_t)px; job_py = (uint32_t)pgy;
+                        gx = (uint32_t)ply * (uint32_t)L.tile.tex_w + (uint32_t)px;
+                        slot = (uint32_t)fslot << 16;
+                        if (un.samples_per_frame != 1)      // (the pixel's running sum and sample count: see the path end above)
+                            L.radiance[(size_t)fslot * L.slot_pixels + gx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         mode = M_PATH;
                     }
                 }
@@ -1870,16 +1861,10 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
         if (do_b && mode == M_PATH) {
             // raytrace.wgsl:441-455: next sample's camera path, or the pixel is finished
             mode = M_DEAD;
-            for (;;) {
-                if constexpr (!SPF1) {
-                    if (sample >= un.samples_per_frame) {
-                        write_pixel<FUSE>(L, gx, gy, ly, per_sample(incoming), slot);
-                        break;
-                    }
-                }
+            do {
                 float uvx, uvy;
-                uint32_t pxx = SPF1 ? job_px : gx, pyy = SPF1 ? job_py : gy;
-                if constexpr (SPF1) {
+                uint32_t pxx = job_px, pyy = job_py;
+                {
                     if (un.samples_per_frame != 1) {
                         // a later sample of a multi-sample frame: the lane only carries the texel index; its pixel, once more
                         const int row = fast_div((int)gx, S.dv_w);
@@ -1895,7 +1880,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                         break;
                     }
                 }
-                if (TUNED || res_ordinary_ != 0) { uvx = div_pre((float)pxx, un.res_x, inv_res_x); uvy = div_pre((float)pyy, un.res_y, inv_res_y); }
+                if (ASSUME || res_ordinary_ != 0) { uvx = div_pre((float)pxx, un.res_x, inv_res_x); uvy = div_pre((float)pyy, un.res_y, inv_res_y); }
                 else { uvx = (float)pxx / un.res_x; uvy = (float)pyy / un.res_y; }
                 const f3 dir0 = camera_direction(cf, un.aspect, uvx, uvy);
                 float jx, jy, kx, ky;
@@ -1916,13 +1901,11 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     o = cam_pos + jitter2;
                 }
                 d = normalize(focal - o);
-                if constexpr (SPF1) slot &= 0xffff0000u; else bounce = 0;
+                slot &= 0xffff0000u;
                 light = F3(0.0f, 0.0f, 0.0f);
                 ray_color = F3(1.0f, 1.0f, 1.0f);
-                if (SPF1 || un.max_bounces > 0) { need_segment = true; break; }
-                incoming = incoming + light;        // (max_bounces == 0: the path is over before it began)
-                sample++;
-            }
+                need_segment = true;
+            } while (false);
         }
 #ifdef PT_DIAG_SERVICE
         if (wave_times) st_switch(6);
@@ -1932,17 +1915,15 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
         {
             const uint32_t nseg = (uint32_t)__popcll(__ballot(need_segment));
             if (DIAG) u_rays += nseg;          // (shipped kernels: every segment ends in a hit or a miss, counted there)
-            if (TUNED || sc.nnodes != 0) u_box += nseg;      // the root box test
+            if (ASSUME || sc.nnodes != 0) u_box += nseg;      // the root box test
         }
         bool slow_segment = false;
-        if constexpr (SPF1) {
-            if (need_segment) {
-                park[0] = ray_color.x; park[64] = ray_color.y; park[128] = ray_color.z;
-                park[192] = light.x; park[256] = light.y; park[320] = light.z;
-            }
-            ray_color = F3(0.0f, 0.0f, 0.0f);       // (dead until the lane's next shading: nothing to keep in registers)
-            light = F3(0.0f, 0.0f, 0.0f);
+        if (need_segment) {
+            park[0] = ray_color.x; park[64] = ray_color.y; park[128] = ray_color.z;
+            park[192] = light.x; park[256] = light.y; park[320] = light.z;
         }
+        ray_color = F3(0.0f, 0.0f, 0.0f);       // (dead until the lane's next shading: nothing to keep in registers)
+        light = F3(0.0f, 0.0f, 0.0f);
         if (need_segment) {
             // raySceneIntersect + the root test of rayBVHIntersect, raytrace.wgsl:155-164, 205-211
             best.t = PT_INF; best.u = 0.0f; best.v = 0.0f; best.tri = -1;
@@ -1956,7 +1937,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
             // take the known answer: a miss.  (Variants 1-8 walk it.)
             const bool nan_ray = CULL && (!(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z) ||
                                           !(o.x == o.x) || !(o.y == o.y) || !(o.z == o.z));
-            if ((TUNED || sc.nnodes != 0) && !nan_ray) {
+            if ((ASSUME || sc.nnodes != 0) && !nan_ray) {
                 pre = ray_prepare(o, d, sc.flags);
                 slow_segment = (pre.flags & 8u) != 0u;
                 if (CULL) cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
@@ -1968,8 +1949,8 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 // four box tests in the segment start, from scalars of the service block: one node step less per segment, but 230
                 // more instructions in the issue-bound service step -- lost 6 %: profiles/r03_i_skip_root_ab.log)
                 const bool skip_root = WIDE && (sc.flags & 2u) != 0u;
-                if (skip_root || ray_aabb_pre(o, d, pre, !TUNED && (sc.flags & 1u) == 0u, S.root_mn[0], S.root_mn[1], S.root_mn[2], S.root_mx[0], S.root_mx[1], S.root_mx[2])) {
-                    if (!TUNED && DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
+                if (skip_root || ray_aabb_pre(o, d, pre, !ASSUME && (sc.flags & 1u) == 0u, S.root_mn[0], S.root_mn[1], S.root_mn[2], S.root_mx[0], S.root_mx[1], S.root_mx[2])) {
+                    if (!ASSUME && DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
                         stack[(DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu;
                         sp = 0; nl = 1;
                     } else {
@@ -2062,86 +2043,145 @@ int raytrace_grid_blocks(const Tile &tile)
     return tiles_x * tiles_y;
 }
 
-// (SPF1: the shipped walks' batched launches have a specialisation for samplesPerFrame == 1, the reference's
-// default -- no per-pixel sum and sample counter to carry through the walk: five registers less)
-static bool launch_is_one_spp(const RtLaunch &L, bool fuse)
+// Frame slot and bounce share a word in the state-machine kernel, and the sample count of a multi-sample frame is a float in the
+// pixel's texel: launches beyond these (absurd) limits run the per-pixel kernel, frame by frame.
+static bool launch_packs(const RtLaunch &L)
 {
-    // (frame slot and bounce share a word; the sample count of a multi-sample frame is a float in the pixel's texel)
-    return !fuse && L.un.max_bounces < 65536 && L.nframes <= 65535 && L.un.samples_per_frame <= 16777216;
+    return L.un.max_bounces < 65536 && L.nframes <= 65535 && L.un.samples_per_frame <= 16777216;
 }
-// The tuned twin runs when: one sample per frame, no diagnostic buffer, every step-voting option at its default (they are
-// constants there), a scene with nodes whose root is an internal node with a guard-range box, the API's environment size,
-// a resolution of ordinary magnitude, maxBounces > 0, and a service block to read (variants 9 .. 12).  The kernel's TUNED
-// constants are exactly these conditions; test_tuned_and_diagnostic_twins_render_the_same_bits holds the twins together.
-static bool launch_is_tuned(const RtLaunch &L, bool fuse, int variant)
+// The lean build (DIAG = false: no step statistics, the step-voting options as constants, the service step's scalars in
+// memory) runs unless a diagnostic buffer is bound or a step-voting option was changed (mi3pt_debug_set_option).
+static bool launch_is_lean(const RtLaunch &L)
 {
-    return variant >= 9 && variant <= 12 && launch_is_one_spp(L, fuse) && !L.wave_times && L.walk_min == PT_DEFAULT_WALK_MIN &&
-           L.leaf_min == PT_DEFAULT_LEAF_MIN && L.shade_split == PT_DEFAULT_SHADE_SPLIT && L.tail_policy == PT_DEFAULT_TAIL_POLICY &&
-           L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 &&
-           L.scene.nnodes != 0 && (L.scene.flags & 1u) != 0u && (L.scene.root_ref & PT_REF_LEAF) == 0u &&
-           L.scene.env_w == ENV_W && L.scene.env_h == ENV_H &&
-           L.service != nullptr && L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
+    return !L.wave_times && L.walk_min == PT_DEFAULT_WALK_MIN && L.leaf_min == PT_DEFAULT_LEAF_MIN && L.shade_split == PT_DEFAULT_SHADE_SPLIT &&
+           L.tail_policy == PT_DEFAULT_TAIL_POLICY && L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 && L.service != nullptr;
+}
+// What the lean builds of the culling walks have as constants (ASSUME in the kernel): a scene with nodes whose root is an
+// internal node with a guard-range box, and a resolution of ordinary magnitude.  Every tree the culling walks are offered for
+// has nodes and an internal root; the rest fails for scenes ~1e18 across or images ~1e12 wide.
+static bool launch_assumptions_hold(const RtLaunch &L)
+{
+    return L.scene.nnodes != 0 && (L.scene.flags & 1u) != 0u && (L.scene.root_ref & PT_REF_LEAF) == 0u &&
+           L.un.res_x >= 9.5367431640625e-07f && L.un.res_x <= 1.099511627776e12f &&
            L.un.res_y >= 9.5367431640625e-07f && L.un.res_y <= 1.099511627776e12f;
 }
 
-// The tuned twins read their service step's scalars from L.service: filled here, in stream order, by one wave.  Its own
+// The kernel a launch runs for a requested variant.  kind: 0 = per-pixel kernel (variant 1 / 2), 1 = state-machine kernel
+// (variant 4, 7, 9 .. 12; experiment builds: 5, 6, 8), 2 = k_raytrace_persistent (variant 3, experiment builds).
+static RtRoute route_launch(const RtLaunch &L, int variant)
+{
+    RtRoute r = { 0, variant <= 1 ? 1 : 2, false, 0 };
+    if (variant < 3) return r;
+#ifdef MI3PT_EXPERIMENTS
+    if (variant == 3) { r.kind = 2; r.variant = 3; return r; }
+#else
+    if (variant == 3) variant = 4;                       // (release builds: the experiment variants resolve to their nearest walk)
+    if (variant == 5 || variant == 6) variant = 4;
+    if (variant == 8) variant = 7;
+#endif
+    if (!launch_packs(L)) return r;                      // per-pixel kernel 2, frame by frame
+    r.kind = 1;
+    r.lean = launch_is_lean(L);
+    if (variant >= 9 && variant <= 12 && r.lean && !launch_assumptions_hold(L)) variant = L.scene.leaf_cap >= 4 ? 7 : 4;
+    if (variant >= 10 && variant <= 12 && !r.lean) variant = 10;      // the diagnostic twin of the wide walks runs the exact slab test: same bits
+#ifndef MI3PT_EXPERIMENTS
+    if (variant < 9 && !r.lean) {
+        // release builds carry diagnostic twins for the culling walks only: the lean build runs (options and the diagnostic buffer
+        // are ignored) -- or, without a service block, the per-pixel kernel
+        if (!L.service) { r.kind = 0; r.variant = 2; return r; }
+        r.lean = true;
+    }
+#endif
+    r.variant = variant;
+    return r;
+}
+bool raytrace_variant_fuses(int variant)
+{
+#ifdef MI3PT_EXPERIMENTS
+    return variant <= 3;
+#else
+    return variant <= 2;
+#endif
+}
+static int persistent_blocks_for(const RtLaunch &L, const RtRoute &r)
+{
+    return raytrace_persistent_blocks(L.tile, L.nframes, L.waves_per_cu, L.num_cus, r.kind == 1 && r.lean);
+}
+RtRoute raytrace_route(const RtLaunch &L, int variant)
+{
+    RtRoute r = route_launch(L, variant);
+    r.blocks = r.kind == 1 ? persistent_blocks_for(L, r) : raytrace_grid_blocks(L.tile);
+    return r;
+}
+
+// The lean builds read their service step's scalars from L.service: filled here, in stream order, by one wave.  Its own
 // call so that the caller can put its timing event between this and the raytrace kernel (the little kernel waits for the
 // first wave slot a draining predecessor frees; that wait is not the raytrace kernel's time).
 void launch_raytrace_setup(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
 {
-    if (raytrace_grid_blocks(L.tile) > 0 && launch_is_tuned(L, fuse, variant))
+    (void)fuse;
+    const RtRoute r = route_launch(L, variant);
+    if (raytrace_grid_blocks(L.tile) > 0 && r.kind == 1 && r.lean)
         hipLaunchKernelGGL(k_rt_service_setup, dim3(1), dim3(64), 0, s, L, L.service);
 }
 
-// (the caller has called launch_raytrace_setup with the same arguments on the same stream)
+// (the caller has called launch_raytrace_setup with the same arguments on the same stream; `fuse` only where
+// raytrace_variant_fuses(variant))
 void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
 {
     const int blocks = raytrace_grid_blocks(L.tile);
     if (blocks <= 0) return;
     const dim3 block(64);
-    if (variant >= 3) {
-        const bool one = launch_is_one_spp(L, fuse);
-        const bool tuned = launch_is_tuned(L, fuse, variant);
-        const dim3 grid(raytrace_persistent_blocks(L.tile, L.nframes, L.waves_per_cu, L.num_cus, tuned));
-        if (variant >= 10 && variant <= 12) {            // the culling walk on 4-ary wide packets
-            // 11 / 12: the filtered slab test (12: with the one-axis culling condition) in the shipped batched launch; the
-            // other launch flavours (fused, diagnostic, samplesPerFrame != 1) run variant 10's exact test -- same bits
-            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true, true>), grid, block, 0, s, L);
-            else if (tuned && variant == 12) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true, false, true, true>), grid, block, 0, s, L);
-            else if (tuned && variant == 11) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true, false, true, false>), grid, block, 0, s, L);
-            else if (tuned) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true, false>), grid, block, 0, s, L);
-            else if (one) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true, true>), grid, block, 0, s, L);
-            else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, true>), grid, block, 0, s, L);
-        } else if (variant == 9) {                       // deferred leaves + exact-image distance culling
-            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true, true>), grid, block, 0, s, L);
-            else if (tuned) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, false, true, false>), grid, block, 0, s, L);
-            else if (one) hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true, false, true>), grid, block, 0, s, L);
-            else hipLaunchKernelGGL((k_raytrace_sm<false, false, true, true>), grid, block, 0, s, L);
-        } else if (variant == 3) {
-            if (fuse) hipLaunchKernelGGL((k_raytrace_persistent<true>), grid, block, 0, s, L);
-            else hipLaunchKernelGGL((k_raytrace_persistent<false>), grid, block, 0, s, L);
-        } else if (variant == 6) {
-            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, true, false>), grid, block, 0, s, L);
-            else hipLaunchKernelGGL((k_raytrace_sm<false, true, false>), grid, block, 0, s, L);
-        } else if (variant == 8) {                       // deferred leaves + top of the tree in LDS
-            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, true, true>), grid, block, 0, s, L);
-            else hipLaunchKernelGGL((k_raytrace_sm<false, true, true>), grid, block, 0, s, L);
-        } else if (variant == 7) {
-            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, true>), grid, block, 0, s, L);
-            else hipLaunchKernelGGL((k_raytrace_sm<false, false, true>), grid, block, 0, s, L);
-        } else {
-            if (fuse) hipLaunchKernelGGL((k_raytrace_sm<true, false, false>), grid, block, 0, s, L);
-            else hipLaunchKernelGGL((k_raytrace_sm<false, false, false>), grid, block, 0, s, L);
+    const RtRoute r = route_launch(L, variant);
+    if (r.kind == 1) {
+        const dim3 grid(persistent_blocks_for(L, r));
+#define PT_SM(...) hipLaunchKernelGGL((k_raytrace_sm<__VA_ARGS__>), grid, block, 0, s, L)
+        //                               DEFER  CULL   WIDE   FILT   YMAX   DIAG
+        if (r.lean) switch (r.variant) {
+            case 12: PT_SM(true,  true,  true,  true,  true,  false); break;
+            case 11: PT_SM(true,  true,  true,  true,  false, false); break;
+            case 10: PT_SM(true,  true,  true,  false, false, false); break;
+            case 9:  PT_SM(true,  true,  false, false, false, false); break;
+            case 7:  PT_SM(true,  false, false, false, false, false); break;
+            default: PT_SM(false, false, false, false, false, false); break;
+        } else switch (r.variant) {
+            case 10: PT_SM(true,  true,  true,  false, false, true); break;
+            case 9:  PT_SM(true,  true,  false, false, false, true); break;
+#ifdef MI3PT_EXPERIMENTS
+            case 8:  PT_SM(true,  false, false, false, false, true, true); break;
+            case 7:  PT_SM(true,  false, false, false, false, true); break;
+            case 6:  PT_SM(false, false, false, false, false, true, true); break;
+            default: PT_SM(false, false, false, false, false, true); break;
+#else
+            default: break;          // (not reached: route_launch)
+#endif
         }
+#undef PT_SM
         return;
     }
+#ifdef MI3PT_EXPERIMENTS
+    if (r.kind == 2) {
+        const dim3 grid(raytrace_persistent_blocks(L.tile, 1, L.waves_per_cu, L.num_cus, false));
+        if (fuse) hipLaunchKernelGGL((k_raytrace_persistent<true>), grid, block, 0, s, L);
+        else hipLaunchKernelGGL((k_raytrace_persistent<false>), grid, block, 0, s, L);
+        return;
+    }
+#endif
+    // per-pixel kernels: one launch per frame of the batch
     const dim3 grid(blocks);
-    if (variant == 2) {
-        if (fuse) hipLaunchKernelGGL((k_raytrace<true, 2>), grid, block, 0, s, L);
-        else hipLaunchKernelGGL((k_raytrace<false, 2>), grid, block, 0, s, L);
-    } else {
-        if (fuse) hipLaunchKernelGGL((k_raytrace<true, 1>), grid, block, 0, s, L);
-        else hipLaunchKernelGGL((k_raytrace<false, 1>), grid, block, 0, s, L);
+    for (int k = 0; k < (L.nframes > 0 ? L.nframes : 1); k++) {
+        RtLaunch F = L;
+        F.nframes = 1;
+        F.un.frame = L.un.frame + (uint32_t)k;
+        F.acc.frame = L.acc.frame + (uint32_t)k;
+        F.radiance = L.radiance + (size_t)k * L.slot_pixels;
+        if (r.variant == 2) {
+            if (fuse) hipLaunchKernelGGL((k_raytrace<true, 2>), grid, block, 0, s, F);
+            else hipLaunchKernelGGL((k_raytrace<false, 2>), grid, block, 0, s, F);
+        } else {
+            if (fuse) hipLaunchKernelGGL((k_raytrace<true, 1>), grid, block, 0, s, F);
+            else hipLaunchKernelGGL((k_raytrace<false, 1>), grid, block, 0, s, F);
+        }
     }
 }
 

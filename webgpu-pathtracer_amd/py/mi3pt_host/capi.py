@@ -38,7 +38,7 @@ SYMBOLS = (
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
     "mi3pt_set_env_sampling", "mi3pt_debug_walk_probe", "mi3pt_device_build_bvh",
-    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_debug_active_variant", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
+    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_debug_active_variant", "mi3pt_debug_last_launch", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf", "mi3pt_debug_set_option", "mi3pt_debug_get_option",
     "mi3pt_create_group", "mi3pt_group_size", "mi3pt_group_member",
@@ -99,6 +99,7 @@ def load_library(path=None):
     lib.mi3pt_raytrace_launch_span.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.mi3pt_batch_capacity.argtypes = [c_void_p, ctypes.POINTER(c_int)]
     lib.mi3pt_debug_active_variant.argtypes = [c_void_p, ctypes.POINTER(c_int)]
+    lib.mi3pt_debug_last_launch.argtypes = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.mi3pt_create_group.argtypes = [ctypes.POINTER(c_int), c_int, c_int, ctypes.POINTER(c_void_p)]
     lib.mi3pt_group_size.argtypes = [c_void_p, ctypes.POINTER(c_int)]
     lib.mi3pt_group_member.argtypes = [c_void_p, c_int, ctypes.POINTER(c_void_p)]
@@ -361,6 +362,12 @@ class Context:
         v = ctypes.c_int()
         self._c(self.lib.mi3pt_debug_active_variant(self.handle, ctypes.byref(v)))
         return v.value
+
+    def last_launch(self):
+        """The kernel the most recent raytrace launch ran: dict(kind, variant, lean, workgroups) -- mi3pt_debug_last_launch."""
+        k, v, l, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._c(self.lib.mi3pt_debug_last_launch(self.handle, ctypes.byref(k), ctypes.byref(v), ctypes.byref(l), ctypes.byref(w)))
+        return {"kind": k.value, "variant": v.value, "lean": bool(l.value), "workgroups": w.value}
 
     def batch_capacity(self):
         n = ctypes.c_int()
