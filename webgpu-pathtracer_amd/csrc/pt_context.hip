@@ -654,6 +654,22 @@ static int replace_buffer(mi3pt_ctx *ctx, void **dst, const void *bytes, size_t 
     return MI3PT_OK;
 }
 
+// The 48-byte intersection record of a 112-byte triangle record: a, the material index, and the edges b - a, c - a -- the two
+// subtractions Moller-Trumbore starts with (raytrace.wgsl:82-83), each ONE fp32 rounding (this is a float subtraction of two
+// floats: round-to-nearest-even, subnormals kept, like the device's v_sub_f32), so the kernels start from the same operands.
+static pt::TriPacket tri_packet_of(const uint8_t *rec)
+{
+    pt::TriPacket p;
+    for (int k = 0; k < 3; k++) {
+        const float a = ldf(rec, 4 * (size_t)k), b = ldf(rec, 16 + 4 * (size_t)k), c = ldf(rec, 32 + 4 * (size_t)k);
+        volatile float e1 = b - a, e2 = c - a;      // (volatile: each difference is rounded to binary32 here, whatever the host's evaluation method)
+        p.a[k] = a; p.e1[k] = e1; p.e2[k] = e2;
+    }
+    p.material = (uint32_t)ldi(rec, 92);
+    p.pad0 = p.pad1 = 0;
+    return p;
+}
+
 extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t nbytes)
 {
     PT_GROUP_ALL(ctx, false, mi3pt_upload_triangles(m, bytes, nbytes));
@@ -667,13 +683,9 @@ extern "C" int mi3pt_upload_triangles(mi3pt_ctx *ctx, const void *bytes, size_t 
     int64_t max_mat = -1;
     for (size_t i = 0; i < n; i++) {
         const uint8_t *t = src + i * MI3PT_TRIANGLE_STRIDE;
-        std::memcpy(pk[i].a, t + 0, 12);
-        std::memcpy(pk[i].b, t + 16, 12);
-        std::memcpy(pk[i].c, t + 32, 12);
         const int32_t mi = ldi(t, 92);
         if (mi < 0) return pt_set_error(MI3PT_ERR_INVALID, "triangle with negative materialIndex");
-        pk[i].material = (uint32_t)mi;
-        pk[i].pad0 = pk[i].pad1 = 0;
+        pk[i] = tri_packet_of(t);
         if (mi > max_mat) max_mat = mi;
     }
     if (int rc = replace_buffer(ctx, &ctx->d_tris, bytes, nbytes)) return rc;
@@ -1126,11 +1138,7 @@ static int prepare_layout(mi3pt_ctx *ctx)
         const uint8_t *rec = tris.data() + t * MI3PT_TRIANGLE_STRIDE;
         const size_t to = tri_new[t];
         std::memcpy(tris_perm.data() + to * MI3PT_TRIANGLE_STRIDE, rec, MI3PT_TRIANGLE_STRIDE);
-        std::memcpy(tripk[to].a, rec + 0, 12);
-        std::memcpy(tripk[to].b, rec + 16, 12);
-        std::memcpy(tripk[to].c, rec + 32, 12);
-        tripk[to].material = (uint32_t)ldi(rec, 92);
-        tripk[to].pad0 = tripk[to].pad1 = 0;
+        tripk[to] = tri_packet_of(rec);
         rank[to] = (uint32_t)to;          // leaf-visiting order IS the new numbering
     }
     if (int rc = replace_buffer(ctx, &ctx->d_packets, pk.data(), pk.size() * sizeof(pt::NodePacket))) return rc;
@@ -1195,15 +1203,28 @@ static int prepare_cull(mi3pt_ctx *ctx)
     for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(ctx->rt_stream[k]));
     const size_t n = ctx->nnodes, nt = ctx->ntris;
     std::vector<uint8_t> nodes(n * MI3PT_BVHNODE_STRIDE);
-    std::vector<pt::TriPacket> tris(nt);
+    // the three vertices of every triangle: the first 48 of every 112 bytes of the records, packed by a small kernel (the 48-B
+    // triangle packets hold edges, not b and c; uploaded numbering -- the analysis does not run on a relabelled scene)
+    struct TriVerts { float a[3], pa, b[3], pb, c[3], pc; };
+    static_assert(sizeof(TriVerts) == 48, "three vec3f + padding (raytrace.wgsl:40-49)");
+    std::vector<TriVerts> tris(nt);
     HIP_TRY(hipMemcpy(nodes.data(), ctx->d_nodes, nodes.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tris.data(), ctx->d_tripk, nt * sizeof(pt::TriPacket), hipMemcpyDeviceToHost));
+    {
+        float4 *packed = nullptr;
+        HIP_TRY(hipMalloc((void **)&packed, nt * sizeof(TriVerts)));
+        pt::launch_pack_vertices(static_cast<const float4 *>(ctx->d_tris), packed, (uint32_t)nt, ctx->stream);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(tris.data(), packed, nt * sizeof(TriVerts), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(packed);
+        if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("cull analysis: reading the vertices back: ") + hipGetErrorString(e));
+    }
     const uint8_t *src = nodes.data();
     auto is_leaf = [&](size_t i) { return ldi(src + i * MI3PT_BVHNODE_STRIDE, 28) == 1; };
 
     // per triangle: E and L in double from the fp32 vertices
     auto tri_el = [&](size_t ti, double &E, double &Lsum) {
-        const pt::TriPacket &t = tris[ti];
+        const TriVerts &t = tris[ti];
         double e1 = 0, e2 = 0;
         for (int k = 0; k < 3; k++) {
             const double u = (double)t.b[k] - (double)t.a[k], v = (double)t.c[k] - (double)t.a[k];
@@ -1247,7 +1268,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
     for (size_t i = n; i-- > 0;) {          // children come after their parent (checked at upload)
         const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
         if (is_leaf(i)) {
-            const pt::TriPacket &t = tris[(size_t)ldi(r, 40)];
+            const TriVerts &t = tris[(size_t)ldi(r, 40)];
             float mn[3], mx[3];
             for (int k = 0; k < 3; k++) {
                 mn[k] = std::fmin(std::fmin(t.a[k], t.b[k]), t.c[k]);

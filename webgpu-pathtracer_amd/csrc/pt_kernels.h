@@ -89,13 +89,15 @@ struct WidePacket {
 };
 static_assert(sizeof(WidePacket) == 128, "two 64-B lines");
 
-// 48-byte triangle record for intersection only (positions + material index); the
-// vertex normals (only needed for the one closest hit per ray) stay in the uploaded
-// 112-B records.
+// 48-byte triangle record for intersection only: vertex a, the material index, and the two EDGES b - a and c - a as
+// Moller-Trumbore forms them first (raytrace.wgsl:82-83) -- one fp32 subtraction each, rounded to nearest, wherever it is
+// computed: at upload (pt_context.hip: tri_packet_of, the host's float subtraction) instead of per test (six vector
+// instructions of every triangle test).  The vertex normals (only needed for the one closest hit per ray) stay in the
+// uploaded 112-B records, like b and c themselves.
 struct TriPacket {
     float a[3]; uint32_t material;
-    float b[3]; uint32_t pad0;
-    float c[3]; uint32_t pad1;
+    float e1[3]; uint32_t pad0;      // fl(b - a)
+    float e2[3]; uint32_t pad1;      // fl(c - a)
 };
 static_assert(sizeof(TriPacket) == 48, "three 16-B vectors");
 
@@ -229,6 +231,8 @@ int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, ui
 int raytrace_grid_blocks(const Tile &tile);
 int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned = false);
 // writes NodePacket::cull of `npackets` packets from a dense array (the context's cull analysis)
+// packs the three position vectors of `ntris` 112-byte triangle records into 48-byte rows (the context's cull analysis)
+void launch_pack_vertices(const float4 *tris, float4 *out, uint32_t ntris, hipStream_t s);
 void launch_patch_cull(float4 *packets, const uint32_t *cull, uint32_t npackets, hipStream_t s);
 
 }  // namespace pt

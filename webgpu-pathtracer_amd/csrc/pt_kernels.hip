@@ -281,14 +281,34 @@ PT_DEV bool ray_triangle(const f3 &o, const f3 &d, const f3 &a, const f3 &b, con
     return false;
 }
 
-// The same test without early returns (the state-machine kernel's triangle step: lanes leave a wave-wide test at
-// different points anyway, and every return is a branch + lane-mask bookkeeping): all quantities are formed, the
-// conditions are the ones above in the same sense for NaNs, and t / u / v are only meaningful when it returns true.
-PT_DEV bool ray_triangle_flat(const f3 &o, const f3 &d, const f3 &a, const f3 &b, const f3 &c,
-                              float &t, float &u, float &v)
+// The same test on a triangle PACKET: vertex a and the edges edge1 = fl(b - a), edge2 = fl(c - a), formed at upload (TriPacket) --
+// the values the first two lines above compute, so every later operation sees the same operands.
+PT_DEV bool ray_triangle_e(const f3 &o, const f3 &d, const f3 &a, const f3 &edge1, const f3 &edge2,
+                           float &t_out, float &u_out, float &v_out)
 {
-    const f3 edge1 = b - a;
-    const f3 edge2 = c - a;
+    const f3 h = cross(d, edge2);
+    const float det = dot(edge1, h);
+    if (det > -PT_EPSILON && det < PT_EPSILON) return false;
+    const float f = rcp_exact(det);
+    const f3 s = o - a;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = f * dot(edge2, q);
+    if (t > PT_EPSILON) {
+        t_out = t; u_out = u; v_out = v;
+        return true;
+    }
+    return false;
+}
+// ... and without early returns (the state-machine kernel's triangle step: lanes leave a wave-wide test at different points
+// anyway, and every return is a branch + lane-mask bookkeeping): all quantities are formed, the conditions are the ones
+// above in the same sense for NaNs, and t / u / v are only meaningful when it returns true.
+PT_DEV bool ray_triangle_flat_e(const f3 &o, const f3 &d, const f3 &a, const f3 &edge1, const f3 &edge2,
+                                float &t, float &u, float &v)
+{
     const f3 h = cross(d, edge2);
     const float det = dot(edge1, h);
     const float f = rcp_exact(det);
@@ -380,7 +400,7 @@ PT_DEV void traverse_packets(const SceneRefs &sc, const f3 &o, const f3 &d,
             const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
             cnt.tri++;
             float t, u, v;
-            if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
+            if (ray_triangle_e(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
                 best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti;
             }
         } else {
@@ -428,7 +448,7 @@ PT_DEV void traverse_packets_pre(const SceneRefs &sc, const f3 &o, const f3 &d,
             const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
             cnt.tri++;
             float t, u, v;
-            if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
+            if (ray_triangle_e(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
                 best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti;
             }
         } else {
@@ -1392,7 +1412,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     asm volatile("" : "+v"(pc.x), "+v"(pc.y), "+v"(pc.z), "+v"(pc.w));
                     {
                         float t, u, v;
-                        const bool hit = ray_triangle_flat(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v);
+                        const bool hit = ray_triangle_flat_e(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v);
                         bool take = hit && t < best.t;
                         if (hit && t == best.t && best.tri >= 0)      // rare: the earlier leaf of the reference order wins
                             take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
@@ -1404,7 +1424,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                         asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
                         asm volatile("" : "+v"(qc.x), "+v"(qc.y), "+v"(qc.z), "+v"(qc.w));
                         float t, u, v;
-                        const bool hit = ray_triangle_flat(o, d, xyz(qa), xyz(qb), xyz(qc), t, u, v);
+                        const bool hit = ray_triangle_flat_e(o, d, xyz(qa), xyz(qb), xyz(qc), t, u, v);
                         bool take = hit && t < best.t;
                         if (hit && t == best.t && best.tri >= 0)
                             take = sc.leaf_rank[tj] < sc.leaf_rank[best.tri];
@@ -1596,7 +1616,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                         const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
                         cnt.tri++;
                         float t, u, v;
-                        if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
+                        if (ray_triangle_e(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
                             best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti;
                         }
                     } else {
@@ -1639,7 +1659,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
                     cnt.tri++;
                     float t, u, v;
-                    if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
+                    if (ray_triangle_e(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v) && t < best.t) {
                         best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti;
                     }
                 } else {
@@ -2750,7 +2770,7 @@ __global__ void __launch_bounds__(64, MINW) k_walk_probe(const SceneRefs sc, con
                     const float4 pb = sc.tripk[(size_t)ti * 3 + 1];
                     const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
                     float t, u, v;
-                    if (ray_triangle(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v)) {
+                    if (ray_triangle_e(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v)) {
                         bool take = t < best.t;
                         if (t == best.t && best.tri >= 0) take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
                         if (take) { best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti; }
@@ -2808,6 +2828,21 @@ void launch_patch_cull(float4 *packets, const uint32_t *cull, uint32_t npackets,
 {
     if (npackets == 0) return;
     hipLaunchKernelGGL(k_patch_cull, dim3((npackets + 255u) / 256u), dim3(256), 0, s, packets, cull, npackets);
+}
+
+// the three position vectors (48 of 112 bytes) of every triangle record, packed: what the context's cull analysis reads back
+__global__ void __launch_bounds__(256) k_pack_vertices(const float4 *__restrict__ tris, float4 *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[(size_t)i * 3 + k] = tris[(size_t)i * 7 + k];
+}
+
+void launch_pack_vertices(const float4 *tris, float4 *out, uint32_t ntris, hipStream_t s)
+{
+    if (ntris == 0) return;
+    hipLaunchKernelGGL(k_pack_vertices, dim3((ntris + 255u) / 256u), dim3(256), 0, s, tris, out, ntris);
 }
 
 void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s)
