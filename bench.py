@@ -88,7 +88,17 @@ def image_size(n_gpus, scaling):
     return 1920 * a, 1080 * b
 
 
-def build_scene(workload):
+def host_threads(world):
+    """Threads of the host-side scene compile (the BVH builder's pool) for one rank: the processors this process may run on,
+    at most 64, shared out among the ranks of the node (round 3: every rank of eight asked for all of them at once)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, 64) // max(world, 1))
+
+
+def build_scene(workload, nthreads=0):
     from mi3pt_host import scenes
     if workload == "demo":
         sc = scenes.demo_scene()
@@ -98,7 +108,7 @@ def build_scene(workload):
         sc = scenes.dragon_class_scene()
         if workload == "closeup":
             sc.camera = dict(sc.camera, **CLOSEUP_CAMERA)
-    sc.build_bvh()
+    sc.build_bvh(nthreads)
     return sc, scenes.synthetic_env()
 
 
@@ -132,12 +142,13 @@ def frames_per_launch(cap):
 class Job:
     """Scene + context + the frame loop, shared by the timed run and the PMC child runs."""
 
-    def __init__(self, workload, width, height, rank=0, world=1, device=0, variant=0, stream_ptr=None):
+    def __init__(self, workload, width, height, rank=0, world=1, device=0, variant=0, stream_ptr=None, group=None, nthreads=0):
+        """group = [d0, d1, ...]: one device group (mi3pt_create_group) instead of one context; rank / world then stay 0 / 1."""
         from mi3pt_host import capi, layout
         self.capi, self.layout = capi, layout
         self.workload, self.width, self.height = workload, width, height
-        self.sc, self.env = build_scene(workload)
-        self.ctx = capi.Context(device)
+        self.sc, self.env = build_scene(workload, nthreads)
+        self.ctx = capi.Context(devices=group, block_rows=BLOCK_ROWS) if group else capi.Context(device)
         if stream_ptr is not None:
             self.ctx.set_stream(stream_ptr)
         self.ctx.set_kernel_variant(variant)
@@ -146,7 +157,8 @@ class Job:
         self.ctx.upload_triangles(self.sc.triangles)
         self.ctx.upload_materials(self.sc.material_bytes)
         self.ctx.upload_environment(self.env)
-        self.ctx.set_tile(rank, world, BLOCK_ROWS)
+        if not group:
+            self.ctx.set_tile(rank, world, BLOCK_ROWS)
         self.ctx.resize(width, height)
         self.frame = 2
 
@@ -166,7 +178,7 @@ class Job:
         u.set({"resolution": [self.width, self.height], "frame": frame, "enabled": 1})
         return u.tobytes()
 
-    def frames(self, n, per_launch, sync_each=False, present=False):
+    def frames(self, n, per_launch, sync_each=False, present=False, plan=None):
         """n consecutive frames, `per_launch` per launch: one mi3pt_submit_frames call per launch
         (= that many Renderer.render() calls with only the frame counter moving), launched at
         once, nothing waited for (sync_each: wait after every launch -- the counter passes).
@@ -180,15 +192,22 @@ class Job:
             f.set({"resolution": [self.width, self.height], "aspect": self.width / self.height, "scalingFactor": 1.0,
                    "denoise": 1, "tonemapping": 1})
             ctx.set_uniforms(capi.PASS_FULLSCREEN, f.tobytes())
-        done = 0
-        while done < n:
-            k = min(per_launch, n - done)
-            ctx.set_uniforms(capi.PASS_RAYTRACE, self.rt_uniforms(self.frame))
-            ctx.set_uniforms(capi.PASS_ACCUMULATE, self.acc_uniforms(self.frame))
+        for rt, acc, k in (plan if plan is not None else self.plan(n, per_launch)):
+            ctx.set_uniforms(capi.PASS_RAYTRACE, rt)
+            ctx.set_uniforms(capi.PASS_ACCUMULATE, acc)
             ctx.submit_frames(mask, k)
             ctx.sync() if sync_each else ctx.flush()
+
+    def plan(self, n, per_launch):
+        """The uniform blocks of n consecutive frames cut into launches of per_launch: [(raytrace bytes, accumulate bytes, frames)].
+        Inputs of the job (the timed region starts with them in hand, like the scene in HBM); advances the frame counter."""
+        out, done = [], 0
+        while done < n:
+            k = min(per_launch, n - done)
+            out.append((self.rt_uniforms(self.frame), self.acc_uniforms(self.frame), k))
             self.frame += k
             done += k
+        return out
 
 
 def cpu_baseline(job, budget_s=20.0):
@@ -408,6 +427,9 @@ def main():
     ap.add_argument("--image", default=None, help="WxH override (experiments only)")
     ap.add_argument("--tile", default=None, help="R/N: render only rank R's share of an N-way tile split on this one GPU, no gather "
                                                  "(experiments only: profiles/scaling_model.py predicts the multi-GPU curve from it)")
+    ap.add_argument("--group", action="store_true", help="ONE process drives all N GPUs through a device group (mi3pt_create_group: the library's own "
+                                                         "tile split + peer-copy gather) instead of one process per GPU over torch.distributed; launch as "
+                                                         "`python bench.py --gpus N --group` (MI3PT_BENCH_REHEARSAL=1: all members on device 0)")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -418,9 +440,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    group_devices = None
+    if args.group:
+        if world != 1:
+            raise SystemExit("--group is one process for all GPUs: do not launch it through torch.distributed.run")
+        group_devices = [0] * args.gpus if os.environ.get("MI3PT_BENCH_REHEARSAL") == "1" else list(range(args.gpus))
+    elif world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N   (or: --gpus N --group)")
         args.gpus = world
 
     # Build (make / g++ children) BEFORE anything touches the GPU; the other ranks meet rank 0 at
@@ -451,7 +478,9 @@ def main():
         dist.barrier()
     capi.load_library()
 
-    base_width, base_height = FOREST_IMAGE if args.workload == "forest" else image_size(world, args.scaling)
+    n_gpus = args.gpus if group_devices else world
+    threads = host_threads(world)
+    base_width, base_height = FOREST_IMAGE if args.workload == "forest" else image_size(n_gpus, args.scaling)
     if args.image:
         base_width, base_height = (int(v) for v in args.image.lower().split("x"))
     width, height = base_width, base_height
@@ -468,16 +497,21 @@ def main():
         width, height = size or (base_width, base_height)
         stream = torch.cuda.Stream()       # the context's main stream
         tile_rank, tile_world = (int(v) for v in args.tile.split("/")) if args.tile else (rank, world)
-        job = Job(workload, width, height, tile_rank, tile_world, local_rank, args.variant, stream.cuda_stream)
+        use_group = group_devices if (gather and group_devices) else None
+        job = Job(workload, width, height, tile_rank, tile_world, local_rank, args.variant, None if use_group else stream.cuda_stream,
+                  group=use_group, nthreads=threads)
         ctx = job.ctx
         if present:
             ctx.enable_timing(False)       # (an event pair around each of the 2 x frames little passes costs this leg 10-15 %)
-        # the accumulation image lives in a torch tensor so RCCL can gather it in place
-        accum = torch.zeros((ctx.local_rows, width, 4), dtype=torch.float32, device="cuda")
-        torch.cuda.synchronize()           # (the fill ran on torch's stream, the passes run on the context's)
-        ctx.bind_accumulation(accum.data_ptr(), accum.numel() * 4)
+        accum = None
+        if not use_group:
+            # the accumulation image lives in a torch tensor so RCCL can gather it in place
+            accum = torch.zeros((ctx.local_rows, width, 4), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()           # (the fill ran on torch's stream, the passes run on the context's)
+            ctx.bind_accumulation(accum.data_ptr(), accum.numel() * 4)
         max_rows = capi.tile_local_rows(height, 0, tile_world, BLOCK_ROWS)
         send = gathered = None
+        ev_g0, ev_g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if world > 1 and gather:
             send = torch.zeros((max_rows, width, 4), dtype=torch.float32, device="cuda")
             if rank == 0:
@@ -486,6 +520,7 @@ def main():
         def exchange():
             # the one exchange of the job: HDR accumulation buffers -> rank 0 over xGMI
             with torch.cuda.stream(stream):
+                ev_g0.record(stream)
                 send[: ctx.local_rows].copy_(accum)
                 if rehearsal:
                     stream.synchronize()
@@ -493,6 +528,7 @@ def main():
                     dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
                 else:
                     dist.gather(send, gathered, dst=0)
+                ev_g1.record(stream)
 
         per_launch = frames_per_launch(ctx.batch_capacity())
         if send is not None and warmup > 0:
@@ -508,24 +544,42 @@ def main():
         warm_ms, warm_launches, _ = ctx.raytrace_launch_stats()      # (the warm-up's launches: for the all-launch average below)
         ctx.raytrace_launch_stats(reset=True)
 
+        timed_plan = job.plan(steps * FRAMES_PER_STEP, per_launch)
         sync_all()
         t0 = time.perf_counter()
-        job.frames(steps * FRAMES_PER_STEP, per_launch, present=present)      # ends with a flush: everything is launched, nothing waited for
+        job.frames(steps * FRAMES_PER_STEP, per_launch, present=present, plan=timed_plan)      # ends with a flush: everything is launched, nothing waited for
+        t_submitted = time.perf_counter()
         if send is not None:
             exchange()
+        elif use_group:
+            ctx.accumulation_device_ptr()  # the group's one exchange: every member's rows -> the presenting context's image (peer copies), waited for
         sync_all()
         elapsed = time.perf_counter() - t0
+        submit_ms = (t_submitted - t0) * 1e3
+        gather_ms = ev_g0.elapsed_time(ev_g1) if send is not None else None
 
         counters = ctx.counters()
         launch_ms_total, launches, launch_frames = ctx.raytrace_launch_stats()
         span_ms = ctx.raytrace_launch_span()
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         c = torch.tensor([counters[k] for k in capi.COUNTER_NAMES], dtype=torch.float64, device=red_dev)
+        # per rank: wall time of the timed region, host time until everything was launched, GPU-clock span of the rank's raytrace
+        # launches, GPU time of its part of the gather (copy into the send buffer + the RCCL call on its stream)
+        mine = torch.tensor([elapsed * 1e3, submit_ms, span_ms, gather_ms if gather_ms is not None else -1.0, float(ctx.local_rows)],
+                            dtype=torch.float64, device=red_dev)
+        per_rank = [mine]
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            per_rank = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(per_rank, mine)
         total = dict(zip(capi.COUNTER_NAMES, (int(x) for x in c.tolist())))
-        m = {"job": job, "elapsed": float(t.item()), "total": total, "counters": counters,
+        ranks = [dict(zip(("elapsed_ms", "submit_ms", "launch_span_ms", "gather_ms", "rows"), (round(float(v), 4) for v in r.tolist()))) for r in per_rank]
+        for r in ranks:
+            r["rows"] = int(r["rows"])
+            if r["gather_ms"] < 0:
+                r["gather_ms"] = None
+        m = {"job": job, "elapsed": float(t.item()), "total": total, "counters": counters, "per_rank": ranks, "host_threads": threads,
              "kernel_ms": launch_ms_total / max(launches, 1), "launches": int(launches),
              "kernel_ms_exclusive": span_ms / max(launches, 1),
              # average over EVERY launch of the process, warm-up included -- the population `rocprofv3 --stats` averages
@@ -533,13 +587,17 @@ def main():
              "kernel_ms_all": (launch_ms_total + warm_ms) / max(launches + warm_launches, 1), "launches_all": int(launches + warm_launches),
              "frames_per_launch": round(launch_frames / max(launches, 1), 2),
              "variant": ctx.active_variant(),
-             "kernel": (lambda v: {12: "k_raytrace_sm<false,false,true,true,true,true,false,true,true>", 11: "k_raytrace_sm<false,false,true,true,true,true,false,true,false>",
-                                   10: "k_raytrace_sm<false,false,true,true,true,true,false>", 9: "k_raytrace_sm<false,false,true,true,false,true,false>"}
+             # (template arguments: DEFER, CULL, WIDE, FILT, YMAX, DIAG -- csrc/pt_kernels.hip; what the last launch ran: mi3pt_debug_last_launch)
+             "kernel": (lambda v: {12: "k_raytrace_sm<true,true,true,true,true,false>", 11: "k_raytrace_sm<true,true,true,true,false,false>",
+                                   10: "k_raytrace_sm<true,true,true,false,false,false>", 9: "k_raytrace_sm<true,true,false,false,false,false>",
+                                   7: "k_raytrace_sm<true,false,false,false,false,false>", 4: "k_raytrace_sm<false,false,false,false,false,false>"}
                         .get(v, f"raytrace kernel variant {v}") + " (persistent raytrace kernel: per-lane state machine, deferred-leaf walk"
                         + (" with exact-image distance culling" if v >= 9 else "") + (" on 4-ary wide packets" if v >= 10 else "")
                         + (", filtered slab test" if v >= 11 else "") + (", one-axis culling condition" if v == 12 else "")
-                        + ("; one-sample-per-frame specialisation, five waves per SIMD" if v >= 9 else "") + "; batched frames)")(ctx.active_variant())}
-        ctx.bind_accumulation(None, 0)
+                        + "; lean build, five waves per SIMD; batched frames)")(ctx.last_launch()["variant"] if not use_group else ctx.active_variant()),
+             "lean": (ctx.last_launch()["lean"] if not use_group else None)}
+        if accum is not None:
+            ctx.bind_accumulation(None, 0)
         return m
 
     m = measure(args.workload, args.steps, args.warmup, gather=True)
@@ -549,7 +607,7 @@ def main():
         rays, elapsed, steps = m["total"]["rays"], m["elapsed"], max(args.steps, 1)
         out = {
             "metric": "Mrays/s", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / steps, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name(args.workload, job.sc) + f", {width}x{height}, {BOUNCES} bounces, {FRAMES_PER_STEP} frames "
@@ -557,8 +615,11 @@ def main():
                        "frames_per_step": FRAMES_PER_STEP,
                        "triangles": int(len(job.sc.triangles)), "bvh_nodes": int(len(job.sc.nodes)),
                        "image": [width, height], "max_bounces": BOUNCES,
-                       "parallelism": (f"tile-split x{world} (8-row blocks, round robin), scene replicated, "
-                                       "one RCCL gather at the end") if world > 1 else "single GPU",
+                       "parallelism": (f"tile-split x{world} (8-row blocks, round robin), one process per GPU, scene replicated, "
+                                       "one RCCL gather at the end") if world > 1 else
+                                      (f"tile-split x{n_gpus} (8-row blocks, round robin) inside ONE process: device group (mi3pt_create_group), "
+                                       "scene replicated, one strided peer copy per member as the gather") if group_devices else "single GPU",
+                       "per_rank": m["per_rank"], "host_threads_per_rank": m["host_threads"],
                        "rays_per_step": rays // steps,
                        "frames_per_launch": m["frames_per_launch"],
                        "scheduling": "consecutive frames are batched into one persistent launch over (frame, tile) "
@@ -606,8 +667,8 @@ def main():
         log = []
         pmc, source = {}, None
         key = {"workload": args.workload, "image": [width, height], "frames_per_launch": m["frames_per_launch"],
-               "variant": args.variant, "n_gpus": world}
-        if world == 1 and not args.no_pmc and not under_profiler():
+               "variant": args.variant, "n_gpus": n_gpus}
+        if world == 1 and not group_devices and not args.no_pmc and not under_profiler():
             try:
                 pmc = collect_pmc(args, m["launches"], log)
             except Exception as e:          # noqa: BLE001 -- a profiler problem must not lose the measurement

@@ -161,6 +161,21 @@ int mi3pt_set_storage(mi3pt_ctx *ctx, int storage /* mi3pt_storage */);
  * images.  Default rank 0 of 1.  Takes effect at the next mi3pt_resize(). */
 int mi3pt_set_tile(mi3pt_ctx *ctx, int rank, int nranks, int block_rows);
 int mi3pt_tile_local_rows(int height, int rank, int nranks, int block_rows); /* returns the count */
+/* The other split: this context renders the CONTIGUOUS band of rows [first_row, first_row + nrows) of the image (clipped to
+ * it; nrows < 0: no band -- mi3pt_set_tile's split applies again); its textures are compact nrows x width images and a gather
+ * is one contiguous copy.  Any partition of the rows renders the same pixels -- the seed comes from the global pixel index,
+ * raytrace.wgsl:435-436.  Bands of equal height are badly balanced (the model sits in the middle of the image: 3x between the
+ * ranks of an 8-way split of the headline view); mi3pt_measure_tile_cost + mi3pt_host.tiles.balanced_bands cut them by measured
+ * cost.  Measured against the round-robin tiles (profiles/r04_*_bands.log) the tiles stay the default of the bench and of
+ * device groups.  Takes effect at the next mi3pt_resize(). */
+int mi3pt_set_rows(mi3pt_ctx *ctx, int first_row, int nrows);
+/* One frame of this context's share of the image at the current raytrace uniforms, measured: cost[ty * ceil(width / 8) + tx]
+ * receives what the paths of 8x8 tile (tx, ty) cost -- 4 per BVH packet popped, 3 per triangle tested, 10 per path segment
+ * (about their shares of a wave's time).  ntiles = ceil(width / 8) * ceil(local rows / 8).  Repeatable to a fraction of a per
+ * cent, not to the unit (the number of boxes a culling walk tests depends on which rays share its wave), so in a multi-process
+ * job ONE rank measures and broadcasts the bands it cut.  Overwrites MI3PT_TEX_OUTPUT like a raytrace pass; needs a scene that admits kernel variants
+ * 9 .. 12 (MI3PT_ERR_STATE otherwise). */
+int mi3pt_measure_tile_cost(mi3pt_ctx *ctx, uint32_t *cost, size_t ntiles);
 
 /* ---- scene upload: queue.writeBuffer of the structured views ----
  * raytrace.ts:104-121 (triangles), :138-160 (materials), :177-193 (BVH nodes).
@@ -298,6 +313,11 @@ typedef enum mi3pt_option {
     MI3PT_OPT_PIPELINE = 16,   /* = mi3pt_set_pipelining */
     MI3PT_OPT_PRESENT_DEPTH = 18, /* MI3PT_PRESENT_EXACT: presenting frames that share one raytrace launch, >= 1 (16); each still
                                    * gets its own accumulate and fullscreen pass, in order -- 1 = also its own launch */
+    MI3PT_OPT_HOST_ANALYSES = 19, /* READ-ONLY: host-side scene compiles this context has done (uploads that build packets, relabellings, cull
+                                   * analyses); for a device group the sum over its members -- one per scene change whatever the group's
+                                   * size: the scene is compiled by member 0 and copied device to device (tests/test_gpu_group.py) */
+    MI3PT_OPT_GATHER_STAGED = 20, /* device group: 1 = every member's rows reach the presenting context through pinned host memory -- the
+                                   * path the gather takes where peer access is unavailable or a direct copy failed (forced: tests) */
     MI3PT_OPT_COST_ORDER = 17  /* a launch's jobs in the order of the tiles' measured cost, costliest first: one launch adds up the path
                                 * segments per 8x8 tile, later launches with the same uniforms run the
                                 * cheapest quarter of the tiles last (0: measured +0.3 % on one GPU, -1.6 ... -4 % for a rank of a tile split) */

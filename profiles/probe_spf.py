@@ -3,7 +3,7 @@
 shipped kernel: Mrays/s on the dragon-class scene at 1080p, the same number of samples per pixel in every leg (64), deep
 launches.  Round 3 sent everything but samplesPerFrame == 1 to a 128-VGPR twin with scratch; round 4 keeps the per-pixel sum
 and the sample count in the pixel's texel of the frame's radiance slot, so every setting runs the lean 96-VGPR build.
-usage: python profiles/probe_spf.py [demo|dragon]"""
+usage: python profiles/probe_spf.py [demo|dragon] [samples|frames]"""
 import os, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "webgpu-pathtracer_amd", "py")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,6 +13,7 @@ name = (sys.argv[1:] or ["dragon"])[0]
 sc = scenes.demo_scene() if name == "demo" else scenes.dragon_class_scene()
 sc.build_bvh(); env = scenes.synthetic_env()
 W, H, SPP = 1920, 1080, 64
+MODE = (sys.argv[2:] or ["samples"])[0]        # "samples": 64 samples per pixel in every leg; "frames": 64 frames in every leg (the reference's `frames` setting stays, main.ts:181)
 ctx = capi.Context(0)
 pc.upload_scene(ctx, sc, env)
 ctx.resize(W, H)
@@ -20,7 +21,7 @@ ctx.resize(W, H)
 
 def job(spf, bounces=8, pipelined=True, reps=4):
     ctx.set_pipelining(pipelined)
-    frames = SPP // spf
+    frames = SPP // spf if MODE == "samples" else SPP
     best, rays = 1e9, 0
     f = 2
     for rep in range(reps):
@@ -38,7 +39,7 @@ def job(spf, bounces=8, pipelined=True, reps=4):
     return rays / best / 1e6, best * 1e3, frames
 
 
-print(f"{name} {W}x{H}, {SPP} samples per pixel per leg, kernel variant {ctx.active_variant() if hasattr(ctx, 'active_variant') else '?'}")
+print(f"{name} {W}x{H}, " + (f"{SPP} samples per pixel" if MODE == "samples" else f"{SPP} frames") + " per leg, kernel variant {ctx.active_variant() if hasattr(ctx, 'active_variant') else '?'}")
 for spf in (1, 2, 4, 16):
     r, ms, frames = job(spf)
     print(f"samplesPerFrame {spf:2d}: {frames:3d} frames, {ms:8.3f} ms, {r:8.0f} Mrays/s", flush=True)

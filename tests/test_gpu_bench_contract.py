@@ -82,6 +82,27 @@ def test_two_rank_rehearsal_line(scaling, image):
     assert (j["n_gpus"], j["steps"], j["scaling"]) == (2, 4, scaling) and j["config"]["image"] == image and "cpu_baseline" not in j
     assert "tile-split x2" in j["config"]["parallelism"] and j["value"] > 100
     assert j["config"]["frames_per_launch"] == 64.0         # 4 steps = 64 frames: one launch (a rank of a 2-way split batches up to 128)
+    # per rank: wall time, host time until everything was launched, GPU-clock span of the raytrace launches, its part of the gather
+    ranks = j["config"]["per_rank"]
+    assert len(ranks) == 2 and sum(r["rows"] for r in ranks) == image[1]
+    for r in ranks:
+        assert 0 < r["submit_ms"] < r["elapsed_ms"] and 0 < r["launch_span_ms"] < r["elapsed_ms"] and r["gather_ms"] > 0
+    assert j["config"]["host_threads_per_rank"] >= 1
+
+
+def test_device_group_rehearsal_line():
+    """`bench.py --gpus 2 --group`: one process, the library's own tile split and peer-copy gather (mi3pt_create_group) -- here
+    with both members on the box's one GPU.  Same job, same rays as two processes over torch.distributed."""
+    env = dict(os.environ, MI3PT_BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--group", "--steps", "4", "--warmup", "1", "--workload", "demo",
+                        "--no-pmc", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert (j["n_gpus"], j["steps"], j["scaling"]) == (2, 4, "strong") and j["config"]["image"] == [1920, 1080]
+    assert "device group" in j["config"]["parallelism"] and j["value"] > 100
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--workload", "demo", "--no-pmc", "--no-cpu-baseline"],
+                            capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert _line(single.stdout)["config"]["rays_per_step"] == j["config"]["rays_per_step"]
 
 
 def test_strong_and_weak_scaling_agree_on_one_gpu():

@@ -368,3 +368,26 @@ def test_ticket_division_by_multiplication():
         for t in ts:
             if 0 <= t < 2**31:
                 assert (t * m) >> sh == t // d, (t, d)
+
+
+def test_balanced_bands_partition_the_rows():
+    """tiles.balanced_bands: contiguous bands of whole tile rows with nearly equal measured cost; pure integer arithmetic
+    (the same measurement gives the same bands); degenerate inputs."""
+    import numpy as np
+    from mi3pt_host import tiles
+    rng = np.random.default_rng(5)
+    for height, n in ((1080, 8), (1080, 4), (99, 3), (13, 4), (8, 8), (2160, 8)):
+        ty = (height + 7) // 8
+        cost = rng.integers(0, 5000, size=(ty, 17)).astype(np.uint32)
+        cost[ty // 3: ty // 2] *= 9                       # the model
+        b = tiles.balanced_bands(cost, height, n)
+        assert len(b) == n + 1 and b[0] == 0 and b[-1] == height and b == sorted(b)
+        assert all(x % 8 == 0 or x == height for x in b)
+        assert b == tiles.balanced_bands(cost.copy(), height, n)
+        if ty > n:
+            share = [int(cost[b[r] // 8:(b[r + 1] + 7) // 8].sum()) for r in range(n)]
+            assert max(share) <= cost.sum() / n + cost.sum(axis=1).max()
+        parts = [np.full((b[r + 1] - b[r], 5, 4), r, np.float32) for r in range(n)]
+        whole = tiles.stack_bands(parts, b)
+        assert whole.shape == (height, 5, 4) and all((whole[b[r]:b[r + 1]] == r).all() for r in range(n))
+    assert tiles.balanced_bands(np.zeros((5, 3)), 37, 2) == [0, 8, 37]

@@ -645,7 +645,7 @@ PT_DEV int fast_div(int t, const FastDiv &f) { return (int)(uint32_t)(((uint64_t
 
 PT_DEV int local_to_global_row(int ly, const Tile &t)
 {
-    if (t.nranks == 1) return ly;                     // (wave-uniform fast paths: no division for the whole image ...
+    if (t.nranks == 1) return ly + t.row0;            // (wave-uniform fast paths: no division for the whole image or a band of it ...
     if (t.block_rows == 8) return ((((ly >> 3) * t.nranks + t.rank) << 3) | (ly & 7));      // ... nor for the usual 8-row blocks)
     const int b = ly / t.block_rows;
     return (b * t.nranks + t.rank) * t.block_rows + (ly - b * t.block_rows);
@@ -1311,6 +1311,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     // coordinates are only needed for the camera ray, formed in the service step) and frame slot << 16 | bounce.  The sum over a
     // multi-sample frame's samples and their count rest in the pixel's texel of the frame's radiance slot (see the path end).
     uint32_t gx = 0u, seed = 0u, slot = 0u;
+    uint32_t lane_cost = 0u;       // DIAG, a measuring launch (L.tile_cost): what this lane's current path has cost so far
     Best best;
     best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
     RayPre pre;
@@ -1391,6 +1392,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 u_tri += (uint32_t)n_leaf + (k_tri_pair ? (uint32_t)__popcll(__ballot(two)) : 0u);      // (wave-uniform count: scalar)
                 if (wave_times) { st_switch(1); st_tri_steps++; st_parked += wave_sum((uint32_t)(has_leaf ? nl : 0)); st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
                 if (has_leaf) {
+                    if (DIAG) lane_cost += two ? 6u : 3u;
                     nl--;
                     const uint32_t ti = stack[(DEPTH - 1 - nl) * 64];
                     uint32_t tj = ti;
@@ -1440,6 +1442,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 const bool shallow = CULL && __ballot(sp > NCAP - (WIDE ? 3 : 1)) == 0ull;
                 if (WIDE) {
                   if (has_node) {
+                    if (DIAG) lane_cost += 4u;
                     const uint32_t ref = shallow ? flat_pop() : cull_pop();
                     const float4 *P = sc.wide + (size_t)ref * 8;
                     const float4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3], q4 = P[4], q5 = P[5], q6 = P[6], q7 = P[7];
@@ -1527,6 +1530,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                   }
                 } else
                 if (has_node) {
+                    if (DIAG) lane_cost += 3u;        // (a binary packet: two boxes)
                     uint32_t ref;
                     if (CULL) ref = shallow ? flat_pop() : cull_pop();
                     else { sp--; ref = stack[sp * 64]; }
@@ -1799,9 +1803,12 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                             else { *px = make_float4(pix.x, pix.y, pix.z, taken); mode = M_PATH; }
                         }
                         if (finished) write_radiance(L, gx, slot >> 16, pix);
-                        if (L.tile_cost) {      // a measuring launch: this path's segments go to its tile's cost
-                            const int row = fast_div((int)gx, S.dv_w), col = (int)gx - row * L.tile.tex_w;
-                            atomicAdd(L.tile_cost + ((row >> 3) * S.tiles_x + (col >> 3)), (slot & 0xffffu) + 1u);
+                        if constexpr (DIAG) {
+                            if (L.tile_cost) {      // a measuring launch: what this path cost goes to its tile
+                                const int row = fast_div((int)gx, S.dv_w), col = (int)gx - row * L.tile.tex_w;
+                                atomicAdd(L.tile_cost + ((row >> 3) * S.tiles_x + (col >> 3)), lane_cost + 10u * ((slot & 0xffffu) + 1u));
+                            }
+                            lane_cost = 0u;
                         }
                     }
                 } else {
@@ -2073,7 +2080,7 @@ static bool launch_packs(const RtLaunch &L)
 // memory) runs unless a diagnostic buffer is bound or a step-voting option was changed (mi3pt_debug_set_option).
 static bool launch_is_lean(const RtLaunch &L)
 {
-    return !L.wave_times && L.walk_min == PT_DEFAULT_WALK_MIN && L.leaf_min == PT_DEFAULT_LEAF_MIN && L.shade_split == PT_DEFAULT_SHADE_SPLIT &&
+    return !L.wave_times && !L.tile_cost && L.walk_min == PT_DEFAULT_WALK_MIN && L.leaf_min == PT_DEFAULT_LEAF_MIN && L.shade_split == PT_DEFAULT_SHADE_SPLIT &&
            L.tail_policy == PT_DEFAULT_TAIL_POLICY && L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 && L.service != nullptr;
 }
 // What the lean builds of the culling walks have as constants (ASSUME in the kernel): a scene with nodes whose root is an
