@@ -303,7 +303,7 @@ typedef enum mi3pt_option {
     MI3PT_OPT_JOB_REVERSE = 6, /* the launch's jobs bottom band first (1) */
     MI3PT_OPT_JOB_GROUP = 7,   /* tiles per job group; 0 frame-major, -1 the library's choice (-1) */
     MI3PT_OPT_JOB_CHUNK = 8,   /* job tickets per draw while the queue is long (4) */
-    MI3PT_OPT_BATCH_LIMIT = 9, /* upper bound of frames per launch, process-wide (512) */
+    MI3PT_OPT_BATCH_LIMIT = 9, /* upper bound of frames per launch, of this context -- or of every member of this group (512) */
     MI3PT_OPT_BATCH = 10,      /* frames per launch on one GPU; x nranks for a rank of a tile split (64); 1 = no batching */
     MI3PT_OPT_WAVES_PER_CU = 11, /* resident one-wave workgroups per compute unit (0 = what the kernel is compiled for: 20 for the shipped batched launch, 16 otherwise) */
     MI3PT_OPT_CULL = 12,       /* 0: `auto` stops at variant 7 */
@@ -316,6 +316,8 @@ typedef enum mi3pt_option {
     MI3PT_OPT_HOST_ANALYSES = 19, /* READ-ONLY: host-side scene compiles this context has done (uploads that build packets, relabellings, cull
                                    * analyses); for a device group the sum over its members -- one per scene change whatever the group's
                                    * size: the scene is compiled by member 0 and copied device to device (tests/test_gpu_group.py) */
+    MI3PT_OPT_DIAG_LITE = 21,     /* experiment build: with mi3pt_debug_wave_times enabled, run the LEAN kernel with lane counts per kind of step
+                                   * (five waves per SIMD, like the shipped one) instead of the four-wave diagnostic twin (profiles/wave_timeline.py) */
     MI3PT_OPT_GATHER_STAGED = 20, /* device group: 1 = every member's rows reach the presenting context through pinned host memory -- the
                                    * path the gather takes where peer access is unavailable or a direct copy failed (forced: tests) */
     MI3PT_OPT_COST_ORDER = 17  /* a launch's jobs in the order of the tiles' measured cost, costliest first: one launch adds up the path

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Diagnostic: per-wave lifetime and step statistics of the persistent raytrace kernel.
 
-usage: [WORKLOAD=dragon|forest] [TILE=R/N] [VARIANT=v] python profiles/wave_timeline.py [WxH] [frames_per_launch]
+usage: [WORKLOAD=dragon|forest] [TILE=R/N] [VARIANT=v] [LITE=1] python profiles/wave_timeline.py [WxH] [frames_per_launch]
+LITE=1 (experiment build of the library, MI3PT_LIBRARY=.../libmi3pt_exp.so): the LEAN kernel with lane counts per kind of step --
+the binary that ships plus a dozen scalar counters, five waves per SIMD -- instead of the four-wave diagnostic twin; it has no
+per-step clock stamps (no cycle split, no drain statistics).  The kernel's Mrays/s with and without the counters is printed.
 Renders one launch of `frames_per_launch` batched frames (default 16; 1 = a single frame) of
 the demo (or dragon-class) scene at 8 bounces and prints when the resident waves begin, see the
 work queue run empty, and end (100 MHz wall clock), the shader clock they averaged, and how
@@ -27,15 +30,37 @@ pc.upload_scene(ctx, sc, env)
 if os.environ.get("TILE"):               # TILE=R/N: rank R's share of an N-way tile split
     ctx.set_tile(*(int(v) for v in os.environ["TILE"].split("/")), 8)
 ctx.resize(w, h)
-ctx.enable_wave_times(True)
 if os.environ.get("VARIANT"):
     ctx.set_kernel_variant(int(os.environ["VARIANT"]))
+lite = os.environ.get("LITE") == "1"
 frame = 2
-for _ in range(2):                       # warm-up batch, then the measured one
-    for _ in range(nframes):
-        pc.gpu_frame(ctx, pc.rt_uniforms(sc, w, h, frame=frame, bounces=8), pc.acc_uniforms(w, h, frame), 3)
-        frame += 1
-    ctx.sync()
+
+
+def batches(count):
+    """`count` launches of nframes frames; (ms per launch of the last, rays of the last)"""
+    global frame
+    import time
+    for _ in range(count):
+        ctx.sync(); ctx.reset_counters(); ctx.sync()
+        t = time.perf_counter()
+        ctx.set_uniforms(capi.PASS_RAYTRACE, pc.rt_uniforms(sc, w, h, frame=frame, bounces=8).tobytes())
+        ctx.set_uniforms(capi.PASS_ACCUMULATE, pc.acc_uniforms(w, h, frame).tobytes())
+        ctx.submit_frames(3, nframes); ctx.flush(); ctx.sync()
+        dt = time.perf_counter() - t
+        frame += nframes
+    return dt * 1e3, ctx.counters()["rays"]
+
+
+plain_ms, plain_rays = batches(3)        # the shipped kernel, nothing bound
+plain_launch = ctx.last_launch()
+ctx.enable_wave_times(True)
+if lite:
+    ctx.set_option(capi.OPT_DIAG_LITE, 1)
+diag_ms, diag_rays = batches(2)          # warm-up batch, then the measured one
+diag_launch = ctx.last_launch()
+print(f"kernel under the counters: variant {diag_launch['variant']} {'lean + lane counts (LITE)' if diag_launch['lean'] else 'diagnostic twin'}, "
+      f"{diag_launch['workgroups']} waves, {diag_rays / diag_ms / 1e3:.0f} Mrays/s;  shipped kernel, same launches: variant {plain_launch['variant']}, "
+      f"{plain_launch['workgroups']} waves, {plain_rays / plain_ms / 1e3:.0f} Mrays/s  ({(diag_rays / diag_ms) / (plain_rays / plain_ms) - 1:+.1%})")
 raw = ctx.wave_times()
 raw = raw[raw[:, 2] > 0]
 t = raw[:, :4].astype(np.int64)

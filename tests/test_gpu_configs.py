@@ -197,9 +197,9 @@ def test_config2_demo_1080p_64spp(gpu_ctx, demo, env):
     ctx.resize(w, h)
     ref, cref = _render_spp(ctx, demo, w, h, spp, variant=2)
     got, cgot = _render_spp(ctx, demo, w, h, spp)
-    assert ctx.active_variant() == 10          # the shipped choice for this scene: its walks are short and meet the floor's thin leaves often
+    assert ctx.active_variant() == 13          # the shipped choice: compressed wide packets (round 4) wherever the tree admits them
     _same_job(got, cgot, ref, cref, spp * w * h)
-    for v in (11, 12):
+    for v in (10, 11, 12):                     # (10: what `auto` picked among the exact-packet walks for this scene -- short walks, thin floor leaves)
         a, ca = _render_spp(ctx, demo, w, h, spp, variant=v)
         _same_job(a, ca, ref, cref, spp * w * h)
     ctx.resize(64, 64)
@@ -214,10 +214,10 @@ def test_config3_dragon_class_1080p_256spp(gpu_ctx, dragon, env):
     ctx.resize(w, h)
     ref, cref = _render_spp(ctx, dragon, w, h, spp, variant=2)
     got, cgot = _render_spp(ctx, dragon, w, h, spp)
-    assert ctx.active_variant() == 12          # the shipped choice for this scene: filtered slab test, one-axis culling condition
+    assert ctx.active_variant() == 13          # the shipped choice: compressed wide packets, one-axis culling condition (this scene's hint)
     _same_job(got, cgot, ref, cref, spp * w * h)
     assert cgot["tri_tests"] <= cref["tri_tests"]
-    for v in (10, 11):                         # ... and the two wide walks `auto` did not pick, on a shorter job
+    for v in (10, 11, 12):                     # ... and the exact-packet wide walks, on a shorter job
         a, ca = _render_spp(ctx, dragon, w, h, 16, variant=v)
         b, cb = _render_spp(ctx, dragon, w, h, 16)
         _same_job(a, ca, b, cb, 16 * w * h)
@@ -253,7 +253,7 @@ def test_config5_forest_4k_4096spp_one_rank_of_8(gpu_ctx, forest, env):
     ctx.resize(w, h)
     ref, cref = _render_spp(ctx, forest, w, h, spp, variant=9)
     got, cgot = _render_spp(ctx, forest, w, h, spp)
-    assert ctx.active_variant() == 11          # the shipped choice for this scene: filtered slab test, three-axis culling condition
+    assert ctx.active_variant() == 13          # the shipped choice: compressed wide packets, three-axis culling condition (this scene's margins are not negligible)
     _same_job(got, cgot, ref, cref, spp * w * ctx.local_rows)
     ctx.set_tile(0, 1, 8)
     ctx.resize(64, 64)

@@ -456,7 +456,7 @@ def test_random_configurations_shipped_path_equals_per_pixel_kernel(gpu_ctx, dem
         assert ca[k] == cb[k], (what, k)
 
 
-@pytest.mark.parametrize("variant", [0, 4, 7, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [0, 4, 7, 9, 10, 11, 12, 13])
 def test_every_reference_setting_runs_the_lean_kernel(gpu_ctx, orc, demo, env, variant):
     """samplesPerFrame 1 .. 16 (the reference's slider, main.ts:188), maxBounces 0 .. 10 (main.ts:195), both storage formats,
     queued frames and a launch per frame (pipelining off), the raytrace pass alone: every one of them runs the lean build of
@@ -1068,7 +1068,7 @@ def test_tuned_and_diagnostic_twins_render_the_same_bits(gpu_ctx, demo, env, sto
 
     try:
         ref, cref = job(2)                      # per-pixel kernel, the WGSL control flow
-        for variant in (9, 10, 11, 12):
+        for variant in (9, 10, 11, 12, 13):
             tuned, ct = job(variant)
             ctx.enable_wave_times(True)
             try:

@@ -69,9 +69,13 @@ def _check_against_fixture(tmp_path):
             out = _run(*args)
             assert _all_equal(out), (name, out)
             fresh[name] = dict(out["reference"], counts=[out["triangles"], out["nodes"], out["materials"]])
-        if not os.path.exists(FIXTURE) or json.load(open(FIXTURE)) != fresh:
+        # (round-3 advice: a differing fixture used to be rewritten silently.)  A change in what the reference's methods write --
+        # or in the harness -- FAILS; the tracked file is only regenerated on request: MI3PT_REGENERATE_FIXTURES=1
+        if os.environ.get("MI3PT_REGENERATE_FIXTURES") == "1" or not os.path.exists(FIXTURE):
             with open(FIXTURE, "w") as f:
                 json.dump(fresh, f, indent=1, sort_keys=True)
+        assert json.load(open(FIXTURE)) == fresh, \
+            "tests/golden/reference_scene_hashes.json differs from what the reference checkout produces now (MI3PT_REGENERATE_FIXTURES=1 rewrites it)"
     want = json.load(open(FIXTURE))
     for name, args in cases.items():
         out = _run(*args, root="-")

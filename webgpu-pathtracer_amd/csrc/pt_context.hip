@@ -68,6 +68,8 @@ struct mi3pt_ctx {
     int auto_wide_variant = 10;     // which of the wide walks (10 exact slab test, 11 filtered, 12 filtered + one-axis culling
                                     // condition) `auto` resolves to for this scene: prepare_cull's walk statistics
     bool wide_ok = false;
+    bool cwide_ok = false;          // compressed wide packets + 64-byte triangle records built (kernel variant 13): needs wide_ok, every box nested and finite
+    void *d_cwide = nullptr, *d_tripk64 = nullptr;
     void *d_wide = nullptr;
     size_t nwide = 0;
     int wide_leaf_cap = 0;
@@ -137,6 +139,7 @@ struct mi3pt_ctx {
     bool fs_taps_valid = false;
     uint8_t *d_service = nullptr;         // ring of SERVICE_SLOTS pt::RtService blocks: one per batched launch in flight (launch_batch)
     uint64_t *d_wave_times = nullptr;     // diagnostic stamps, allocated by mi3pt_debug_wave_times(enable)
+    int diag_lite = 0;                    // MI3PT_OPT_DIAG_LITE (experiment builds): with the stamps enabled, the lean build + lane counts runs instead of the diagnostic twin
     int wave_times_slots = 0;
     int nblocks = 0;
 
@@ -174,6 +177,8 @@ struct mi3pt_ctx {
         uint8_t u_fs[MI3PT_FULLSCREEN_UNIFORMS_SIZE] = {};      // ... with the pass's uniforms as they were at its submit
     };
     std::vector<PendingFrame> pending;
+    int batch_limit_frames = 512;        // MI3PT_OPT_BATCH_LIMIT (512: a rank of an 8-way split runs its 320-frame job as ONE launch instead of 256 + 64: 11.16 instead of 11.62 ms, profiles/r03_d_job_split.log): upper bound of frames per launch, THIS context's (round 3 kept one value per process:
+                                         // contexts other than the caller's went on with a stale capacity)
     int batch_max = 64;                  // MI3PT_BATCH (1 = no batching); x nranks for a tile split, see batch_limit().  16 -> 32: +3 % (fewer drains), 32 -> 64: +2 %, 64 -> 128: +1 %
     // per-launch GPU time of the batched raytrace kernel (HIP events on its own stream)
     hipEvent_t ev_rt[2][2] = {};
@@ -212,7 +217,6 @@ struct mi3pt_ctx {
 static_assert(MI3PT_ENV_WIDTH == pt::ENV_W && MI3PT_ENV_HEIGHT == pt::ENV_H, "the tuned kernels' environment size is the API's");
 static const int SERVICE_SLOTS = 8;
 static size_t service_slot_bytes() { return (pt::service_block_bytes() + 255) / 256 * 256; }
-static int BATCH_LIMIT = 512;           // (MI3PT_OPT_BATCH_LIMIT; a rank of an 8-way split: its 320-frame job as ONE launch of 512-frame capacity instead of 256 + 64: 11.16 instead of 11.62 ms, profiles/r03_d_job_split.log)
 
 static inline float ldf(const uint8_t *p, size_t off) { float f; std::memcpy(&f, p + off, 4); return f; }
 static inline int32_t ldi(const uint8_t *p, size_t off) { int32_t v; std::memcpy(&v, p + off, 4); return v; }
@@ -301,6 +305,12 @@ static bool profiler_attached()
     for (const char *name : { "ROCPROF_COUNTERS", "ROCPROF_COUNTER_GROUPS", "ROCPROF_EXTRA_COUNTERS_CONTENTS", "ROCP_METRICS", "ROCP_INPUT" })
         if (const char *v = std::getenv(name))
             if (v[0]) return true;
+    // any other tool built on rocprofiler (rocprofiler-sdk through ROCP_TOOL_LIBRARIES / HSA_TOOLS_LIB, wrappers that preload
+    // it) may serialise kernels in interception order as well: treat it as attached (round-3 advice).  The manual escape is
+    // mi3pt_debug_set_option(ctx, MI3PT_OPT_GATE, 0); mi3pt_destroy releases a held launch before it waits (below).
+    for (const char *name : { "LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB" })
+        if (const char *v = std::getenv(name))
+            if (std::strstr(v, "rocprof") || std::strstr(v, "rocprofiler") || std::strstr(v, "roctracer")) return true;
     return false;
 }
 
@@ -396,7 +406,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
             { "MI3PT_JOB_REVERSE", MI3PT_OPT_JOB_REVERSE }, { "MI3PT_JOB_GROUP", MI3PT_OPT_JOB_GROUP }, { "MI3PT_JOB_CHUNK", MI3PT_OPT_JOB_CHUNK },
             { "MI3PT_BATCH_LIMIT", MI3PT_OPT_BATCH_LIMIT }, { "MI3PT_BATCH", MI3PT_OPT_BATCH }, { "MI3PT_WAVES_PER_CU", MI3PT_OPT_WAVES_PER_CU },
             { "MI3PT_CULL", MI3PT_OPT_CULL }, { "MI3PT_WIDE", MI3PT_OPT_WIDE }, { "MI3PT_GATE", MI3PT_OPT_GATE }, { "MI3PT_SLOT_SETS", MI3PT_OPT_SLOT_SETS },
-            { "MI3PT_PIPELINE", MI3PT_OPT_PIPELINE }, { "MI3PT_COST_ORDER", MI3PT_OPT_COST_ORDER },
+            { "MI3PT_PIPELINE", MI3PT_OPT_PIPELINE }, { "MI3PT_COST_ORDER", MI3PT_OPT_COST_ORDER }, { "MI3PT_DIAG_LITE", MI3PT_OPT_DIAG_LITE },
         };
         for (const auto &eo : env_opts)
             if (const char *e = std::getenv(eo.name)) (void)mi3pt_debug_set_option(ctx, eo.opt, std::atoi(e));
@@ -429,11 +439,22 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
     PT_GROUP(ctx, group_destroy(ctx));
     if (!ctx) return MI3PT_OK;
     (void)hipSetDevice(ctx->device);
+    // A launch held at the gate is released from the host side before anything is waited for: whatever a tool did to the
+    // order of the two internal queues (counter collection serialising kernels: the deadlock of round 2), destroy returns.
+    // Early release only lets launches overlap more than intended; every launch still runs.
+    if (ctx->gate_enabled && ctx->d_drain_flag && ctx->launch_seq != 0) {
+        hipStream_t rel = nullptr;
+        if (hipStreamCreateWithFlags(&rel, hipStreamNonBlocking) == hipSuccess) {
+            if (hipStreamWriteValue32(rel, ctx->d_drain_flag, ctx->launch_seq, 0) == hipSuccess) (void)hipStreamSynchronize(rel);
+            (void)hipStreamDestroy(rel);
+        }
+        (void)hipGetLastError();
+    }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 2; k++)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     free_textures(ctx);
-    for (void *p : { ctx->d_wide, ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
+    for (void *p : { ctx->d_cwide, ctx->d_tripk64, ctx->d_wide, ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
                      (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow, (void *)ctx->d_service, ctx->d_fs_taps })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
@@ -497,7 +518,7 @@ extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
     PT_GROUP_ALL(ctx, false, mi3pt_set_kernel_variant(m, variant));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
-    if (variant < 0 || variant > 12) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..12");
+    if (variant < 0 || variant > 13) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..13");
 #ifndef MI3PT_EXPERIMENTS
     if (variant == 3 || variant == 5 || variant == 6 || variant == 8)
         return pt_set_error(MI3PT_ERR_INVALID, "kernel variants 3, 5, 6 and 8 (measured, not adopted) exist in the experiment build only: make -C webgpu-pathtracer_amd/csrc experiments");
@@ -541,12 +562,12 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
     case MI3PT_OPT_JOB_CHUNK: ctx->job_chunk = (value < 1 || value > 64) ? 1 : value; break;
     case MI3PT_OPT_BATCH_LIMIT:
         if (value < 1 || value > 4096) return pt_set_error(MI3PT_ERR_INVALID, "batch limit must be in [1, 4096]");
-        BATCH_LIMIT = value;
-        if (ctx->batch_max > BATCH_LIMIT) ctx->batch_max = BATCH_LIMIT;
+        ctx->batch_limit_frames = value;
+        if (ctx->batch_max > ctx->batch_limit_frames) ctx->batch_max = ctx->batch_limit_frames;
         recompute_batch_cap(ctx);
         break;
     case MI3PT_OPT_BATCH:
-        ctx->batch_max = value < 1 ? 1 : (value > BATCH_LIMIT ? BATCH_LIMIT : value);
+        ctx->batch_max = value < 1 ? 1 : (value > ctx->batch_limit_frames ? ctx->batch_limit_frames : value);
         recompute_batch_cap(ctx);
         break;
     case MI3PT_OPT_WAVES_PER_CU: ctx->waves_per_cu = value; break;
@@ -561,6 +582,13 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
     case MI3PT_OPT_PIPELINE: ctx->pipeline = value != 0; break;
     case MI3PT_OPT_COST_ORDER: ctx->cost_order = value != 0; ctx->cost_state = 0; break;
     case MI3PT_OPT_HOST_ANALYSES: return pt_set_error(MI3PT_ERR_INVALID, "MI3PT_OPT_HOST_ANALYSES is read-only");
+    case MI3PT_OPT_DIAG_LITE:
+#ifdef MI3PT_EXPERIMENTS
+        ctx->diag_lite = value != 0;
+        break;
+#else
+        return pt_set_error(MI3PT_ERR_INVALID, "MI3PT_OPT_DIAG_LITE: the lean build with lane counts exists in the experiment build only");
+#endif
     case MI3PT_OPT_GATHER_STAGED: break;      // (a group's option: group_set_option)
     case MI3PT_OPT_PRESENT_DEPTH:
         if (value < 1) return pt_set_error(MI3PT_ERR_INVALID, "present depth must be >= 1");
@@ -580,6 +608,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     if (!ctx || !value) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
     switch (option) {
     case MI3PT_OPT_HOST_ANALYSES: *value = (int)ctx->host_analyses; break;
+    case MI3PT_OPT_DIAG_LITE: *value = ctx->diag_lite; break;
     case MI3PT_OPT_GATHER_STAGED: *value = 0; break;
     case MI3PT_OPT_WALK_MIN: *value = ctx->walk_min; break;
     case MI3PT_OPT_LEAF_MIN: *value = ctx->leaf_min; break;
@@ -590,7 +619,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_JOB_REVERSE: *value = ctx->job_reverse ? 1 : 0; break;
     case MI3PT_OPT_JOB_GROUP: *value = ctx->job_group; break;
     case MI3PT_OPT_JOB_CHUNK: *value = ctx->job_chunk; break;
-    case MI3PT_OPT_BATCH_LIMIT: *value = BATCH_LIMIT; break;
+    case MI3PT_OPT_BATCH_LIMIT: *value = ctx->batch_limit_frames; break;
     case MI3PT_OPT_BATCH: *value = ctx->batch_max; break;
     case MI3PT_OPT_WAVES_PER_CU: *value = ctx->waves_per_cu; break;
     case MI3PT_OPT_CULL: *value = ctx->cull_enabled ? 1 : 0; break;
@@ -995,7 +1024,7 @@ static int batch_limit(const mi3pt_ctx *ctx, int nranks)
 {
     long b = (long)ctx->batch_max * (nranks > 1 ? nranks : 1);
     if (ctx->batch_max <= 1) b = 1;
-    return (int)(b > BATCH_LIMIT ? BATCH_LIMIT : b);
+    return (int)(b > ctx->batch_limit_frames ? ctx->batch_limit_frames : b);
 }
 
 extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
@@ -1094,6 +1123,8 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.leaf_rank = static_cast<const uint32_t *>(ctx->d_leaf_rank);
     s.leaf_cap = ctx->leaf_cap;
     s.wide = static_cast<const float4 *>(ctx->d_wide);
+    s.cwide = static_cast<const float4 *>(ctx->cwide_ok ? ctx->d_cwide : nullptr);
+    s.tripk64 = static_cast<const float4 *>(ctx->cwide_ok ? ctx->d_tripk64 : nullptr);
     s.wide_leaf_cap = ctx->wide_ok ? ctx->wide_leaf_cap : 0;
     s.wide_root = ctx->wide_root;
     s.cdf = static_cast<const float4 *>(ctx->d_cdf);
@@ -1103,6 +1134,7 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.root_ref = ctx->root_ref;
     s.flags = ctx->scene_flags;
     if (ctx->wide_ok && ctx->wide_root_nested) s.flags |= 2u;      // (pt_kernels.h SceneRefs::flags bit 1)
+    if (ctx->wide_ok && ctx->auto_wide_variant == 12) s.flags |= 4u;  // (bit 2: the one-axis culling condition suits this scene -- variant 13 takes the hint)
     s.cull_ka = ctx->cull_ka; s.cull_kb = ctx->cull_kb;
 #ifdef MI3PT_EXPERIMENTS
     if (ctx->exp_force_slow_slab) s.flags = 0;
@@ -1233,7 +1265,7 @@ static inline uint32_t round_up_16(float f)
 static int prepare_cull(mi3pt_ctx *ctx)
 {
     if (!ctx->cull_dirty) return MI3PT_OK;
-    const bool wanted = (ctx->variant >= 9 && ctx->variant <= 12) || (ctx->variant == 0 && ctx->cull_enabled);
+    const bool wanted = (ctx->variant >= 9 && ctx->variant <= 13) || (ctx->variant == 0 && ctx->cull_enabled);
     if (!wanted || ctx->layout_active || !ctx->cull_stack_ok || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
         return MI3PT_OK;       // stays dirty: pick_variant falls back to the reference-counter walk
     if (int rc = flush_pending(ctx)) return rc;
@@ -1476,6 +1508,100 @@ static int prepare_cull(mi3pt_ctx *ctx)
                 p.cull23 = (cw[2] << 16) | cw[3];
             }
             if (int rc = replace_buffer(ctx, &ctx->d_wide, wp.data(), wp.size() * sizeof(pt::WidePacket))) return rc;
+            // ---- compressed wide packets + 64-byte triangle records (kernel variant 13): the same packets with the boxes on a
+            // per-node 8-bit grid, rounded outward by at least one cell; the exact test moves to the leaf's own box, which travels
+            // with the triangle.  Offered when every internal box contains its children's (the reference then reaches a leaf iff
+            // the leaf's box passes) and every coordinate is finite and of ordinary magnitude.
+            ctx->cwide_ok = false;
+            {
+                bool ok = true;
+                for (size_t i = 0; i < n && ok; i++) {
+                    if (!is_leaf(i) && !nested[i]) ok = false;
+                    for (int k = 0; k < 6 && ok; k++) { const float v = ldf(src + i * MI3PT_BVHNODE_STRIDE, (size_t)(k < 3 ? 4 * k : 16 + 4 * (k - 3))); if (!(std::fabs(v) < 1e30f)) ok = false; }
+                }
+                std::vector<pt::CWidePacket> cp(ok ? wp.size() : 0);
+                for (size_t w = 0; w < cp.size() && ok; w++) {
+                    const pt::WidePacket &p = wp[w];
+                    pt::CWidePacket &c = cp[w];
+                    std::memset(&c, 0, sizeof c);
+                    const int nk = (int)((p.flags >> 4) & 7u);
+                    c.cull01 = p.cull01; c.cull23 = p.cull23;
+                    for (int k = 0; k < 4; k++) c.ref[k] = p.ref[k];
+                    uint32_t meta = (uint32_t)nk << 24;
+                    for (int ax = 0; ax < 3; ax++) {
+                        double lo = 1e300, hi = -1e300, maxabs = 0.0;
+                        auto box_of = [&](int k) { return k < 2 ? p.b01 + 6 * k : p.b23 + 6 * (k - 2); };
+                        for (int k = 0; k < 4; k++) {
+                            if (p.ref[k] == pt::REF_NONE) continue;
+                            const float *b = box_of(k);
+                            lo = std::min(lo, (double)b[ax]); hi = std::max(hi, (double)b[3 + ax]);
+                            maxabs = std::max({ maxabs, std::fabs((double)b[ax]), std::fabs((double)b[3 + ax]) });
+                        }
+                        if (!(lo <= hi)) { lo = hi = 0.0; }
+                        // cell = 2^e: the extent in at most 248 cells (2 below the lowest coordinate for the origin, 1 + 1 of outward rounding
+                        // on either side, 254 the largest index used), and no finer than 2^-20 of the largest coordinate (the origin and
+                        // the cell boundaries must be far above the fp32 grid of the coordinates themselves)
+                        int e = -100;
+                        if (hi > lo) e = std::max(e, (int)std::ceil(std::log2((hi - lo) / 248.0)));
+                        if (maxabs > 0.0) e = std::max(e, (int)std::floor(std::log2(maxabs)) - 20);
+                        double cell = std::ldexp(1.0, e);
+                        float o = 0.0f;
+                        for (;; e++, cell *= 2.0) {         // (at most a step or two: until the fp32 origin and every index fit)
+                            o = (float)(lo - 2.0 * cell);
+                            if ((double)o > lo - cell) continue;                         // the origin must leave room for a whole cell of outward rounding
+                            if (std::ceil((hi - (double)o) / cell) + 1.0 <= 254.0) break;
+                        }
+                        if (e + 127 < 1 || e + 127 > 254) { ok = false; break; }
+                        c.o[ax] = o;
+                        meta |= (uint32_t)(e + 127) << (8 * ax);
+                        uint32_t qlo = 0, qhi = 0;
+                        for (int k = 0; k < 4; k++) {
+                            uint32_t a = 255u, z = 0u;                                   // empty slot: an inverted box, never entered
+                            if (p.ref[k] != pt::REF_NONE) {
+                                const float *b = box_of(k);
+                                const double x0 = ((double)b[ax] - (double)o) / cell, x1 = ((double)b[3 + ax] - (double)o) / cell;     // exact: fp32 values, a power-of-two cell
+                                const double f0 = std::floor(x0) - 1.0, f1 = std::ceil(x1) + 1.0;
+                                if (!(f0 >= 0.0 && f1 <= 254.0 && f0 < f1)) { ok = false; break; }
+                                a = (uint32_t)f0; z = (uint32_t)f1;
+                            }
+                            qlo |= a << (8 * k); qhi |= z << (8 * k);
+                        }
+                        c.qlo[ax] = qlo; c.qhi[ax] = qhi;
+                    }
+                    c.meta = meta;
+                }
+                std::vector<pt::TriPacket64> t64(ok ? nt : 0);
+                if (ok) {
+                    std::vector<uint8_t> seen(nt, 0);
+                    for (size_t i = 0; i < n; i++) {
+                        if (!is_leaf(i)) continue;
+                        const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+                        const size_t ti = (size_t)ldi(r, 40);
+                        const TriVerts &v = tris[ti];
+                        pt::TriPacket64 &q = t64[ti];
+                        for (int k = 0; k < 3; k++) {
+                            volatile float e1 = v.b[k] - v.a[k], e2 = v.c[k] - v.a[k];        // one fp32 rounding each (see tri_packet_of)
+                            q.a[k] = v.a[k]; q.e1[k] = e1; q.e2[k] = e2;
+                            q.bmin[k] = ldf(r, 4 * (size_t)k); q.bmax[k] = ldf(r, 16 + 4 * (size_t)k);
+                        }
+                        // (the word the 48-byte records keep the material index in: here a flag -- the leaf's box has a coordinate outside the
+                        // guard range of the reduced-instruction slab tests, e.g. the 1e-33 residues three.js leaves at a sphere's poles:
+                        // its exact test takes the plain divisions.  Internal boxes live on the packets' grids: no such range.)
+                        q.unsafe = node_box_safe(src, i) ? 0u : 1u;
+                        seen[ti] = 1;
+                    }
+                    for (size_t t = 0; t < nt; t++)
+                        if (!seen[t]) {        // a triangle no leaf refers to is never tested: an empty box keeps its record inert
+                            for (int k = 0; k < 3; k++) { t64[t].a[k] = t64[t].e1[k] = t64[t].e2[k] = 0.0f; t64[t].bmin[k] = 1.0f; t64[t].bmax[k] = -1.0f; }
+                            t64[t].unsafe = 0;
+                        }
+                }
+                if (ok) {
+                    if (int rc = replace_buffer(ctx, &ctx->d_cwide, cp.data(), cp.size() * sizeof(pt::CWidePacket))) return rc;
+                    if (int rc = replace_buffer(ctx, &ctx->d_tripk64, t64.data(), t64.size() * sizeof(pt::TriPacket64))) return rc;
+                    ctx->cwide_ok = true;
+                }
+            }
             ctx->nwide = wp.size();
             ctx->wide_leaf_cap = pt::SM_CULL_LEAF_CAP;
             ctx->wide_root = 0;
@@ -1556,8 +1682,13 @@ static int pick_variant(const mi3pt_ctx *ctx)
     const bool wide_ok = cull_ok && ctx->wide_ok;
     // auto: the wide walk pays once the tree no longer sits in L1 / L2 (demo scene, 2 k nodes: binary packets 10.4, wide
     // packets 10.2 Grays/s; dragon-class 8.5 -> 8.6; 10 M-triangle forest 24 -> 21 ms per frame)
+    // ... and on COMPRESSED wide packets (13) wherever they could be built (every box nested and finite: any tree of the reference's
+    // builder): half the bytes and half the loads per node step -- 10 M-triangle forest +29 %, the 870 k-triangle scene from close
+    // up +7 %, its stated view +0.5 %, the demo scene +-0 (profiles/r04_g_cwide_ab.log); 10 / 11 / 12 stay for the trees that do not
+    // admit it and as the diagnostic twin's walk
     if (ctx->variant == 0)
-        return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? ctx->auto_wide_variant : 9) : (defer_ok ? 7 : 4);
+        return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? (ctx->cwide_ok ? 13 : ctx->auto_wide_variant) : 9) : (defer_ok ? 7 : 4);
+    if (ctx->variant == 13 && !(wide_ok && ctx->cwide_ok)) return wide_ok ? ctx->auto_wide_variant : (cull_ok ? 9 : (defer_ok ? 7 : 4));
     if (ctx->variant >= 10 && ctx->variant <= 12 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);
     if (ctx->variant == 9 && !cull_ok) return defer_ok ? 7 : 4;
     if ((ctx->variant == 7 || ctx->variant == 8) && !defer_ok) return ctx->variant == 8 ? 6 : 4;
@@ -1605,6 +1736,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
         L.job_group = (rows < 1 ? 1 : rows) * tiles_x;
     }
     L.wave_times = ctx->d_wave_times;
+    L.diag_lite = ctx->diag_lite;
     L.stack_overflow = ctx->d_stack_overflow;
     L.store_f16 = ctx->storage == MI3PT_STORAGE_F16;
     L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
@@ -1738,7 +1870,7 @@ static int cost_order_prepare(mi3pt_ctx *ctx, pt::RtLaunch &L, const uint8_t *u_
 {
     *measuring = *ordered = false;
     const size_t n = (size_t)pt::raytrace_grid_blocks(L.tile);
-    if (!ctx->cost_order || variant < 9 || variant > 12 || L.un.samples_per_frame != 1 || n < 2) return MI3PT_OK;
+    if (!ctx->cost_order || variant < 9 || variant > 13 || L.un.samples_per_frame != 1 || n < 2) return MI3PT_OK;
     uint8_t key[MI3PT_RAYTRACE_UNIFORMS_SIZE];
     std::memcpy(key, u_rt, sizeof key);
     std::memset(key + 12, 0, 4);          // the frame counter
@@ -2644,6 +2776,8 @@ static int clone_scene(mi3pt_ctx *dst, const mi3pt_ctx *src)
     if (int rc = clone_buffer(dst, &dst->d_tripk, src, src->d_tripk)) return rc;
     if (int rc = clone_buffer(dst, &dst->d_leaf_rank, src, src->d_leaf_rank)) return rc;
     if (int rc = clone_buffer(dst, &dst->d_wide, src, src->d_wide)) return rc;
+    if (int rc = clone_buffer(dst, &dst->d_cwide, src, src->d_cwide)) return rc;
+    if (int rc = clone_buffer(dst, &dst->d_tripk64, src, src->d_tripk64)) return rc;
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
     HIP_TRY(hipMemcpyPeerAsync(dst->d_env, dst->device, src->d_env, src->device, env_bytes, dst->stream));
     HIP_TRY(hipMemcpyPeerAsync(dst->d_cdf, dst->device, src->d_cdf, src->device, env_bytes, dst->stream));
@@ -2653,7 +2787,7 @@ static int clone_scene(mi3pt_ctx *dst, const mi3pt_ctx *src)
     dst->max_tri_ref = src->max_tri_ref; dst->max_mat_ref = src->max_mat_ref;
     dst->leaf_cap = src->leaf_cap; dst->cull_stack_ok = src->cull_stack_ok; dst->tree_proper = src->tree_proper;
     dst->cull_dirty = src->cull_dirty; dst->cull_ok = src->cull_ok; dst->cull_ka = src->cull_ka; dst->cull_kb = src->cull_kb;
-    dst->auto_wide_variant = src->auto_wide_variant; dst->wide_ok = src->wide_ok; dst->nwide = src->nwide;
+    dst->auto_wide_variant = src->auto_wide_variant; dst->wide_ok = src->wide_ok; dst->cwide_ok = src->cwide_ok; dst->nwide = src->nwide;
     dst->wide_leaf_cap = src->wide_leaf_cap; dst->wide_root = src->wide_root;
     dst->layout = src->layout; dst->layout_dirty = src->layout_dirty; dst->layout_active = src->layout_active;
     dst->cost_state = 0;

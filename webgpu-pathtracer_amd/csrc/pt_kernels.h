@@ -89,6 +89,32 @@ struct WidePacket {
 };
 static_assert(sizeof(WidePacket) == 128, "two 64-B lines");
 
+// "Compressed wide packet" (kernel variant 13; round-3 verdict item 4): the four child boxes of a wide packet quantised to 8 bits
+// per coordinate on a per-node grid -- origin o (fp32) and one power-of-two cell size 2^e per axis -- and rounded OUTWARD by at
+// least one whole cell: decoded box k = [o + 2^e (qlo_k), o + 2^e (qhi_k)] contains child k's box with a margin of >= one cell
+// on every side.  64 bytes = one half line: four 16-byte loads per node step instead of eight.  Internal boxes need not be exact:
+// the reference reaches a leaf iff the exact slab test passes for the LEAF's box (all boxes nested: the test is monotone under
+// nesting, every ancestor then passes too), so any test that never rejects a box the exact test would pass is enough above the
+// leaves (pt_kernels.hip: cwide_test), and the leaf's own box is tested exactly in the triangle step (TriPacket64).
+struct CWidePacket {
+    float o[3];              // grid origin: at least two cells below the smallest child coordinate on each axis
+    uint32_t meta;           // bits 0-7 / 8-15 / 16-23: biased exponents of the cell size per axis (cell = 2^(e - 127)); bits 24-26: children
+    uint32_t qlo[3];         // per axis: the four children's lower cell indices, one byte each (child k = byte k); empty slot: 255
+    uint32_t qhi[3];         // ... upper cell indices; empty slot: 0
+    uint32_t cull01, cull23; // culling weights, 16 bits each (as WidePacket)
+    uint32_t ref[4];         // child references (as WidePacket)
+};
+static_assert(sizeof(CWidePacket) == 64, "one 64-B half line");
+
+// 64-byte triangle record of the compressed-wide walk: vertex a, the edges (as TriPacket), and the LEAF's box as uploaded -- the
+// exact slab test the reference runs before it pushes the leaf (raytrace.wgsl:184-198) happens in the triangle step, from here.
+struct TriPacket64 {
+    float a[3], e1[3], e2[3];
+    float bmin[3], bmax[3];
+    uint32_t unsafe;         // 1: the leaf's box has a non-zero coordinate outside [2^-70, 2^60] (its exact test takes the plain divisions)
+};
+static_assert(sizeof(TriPacket64) == 64, "four 16-B vectors");
+
 // 48-byte triangle record for intersection only: vertex a, the material index, and the two EDGES b - a and c - a as
 // Moller-Trumbore forms them first (raytrace.wgsl:82-83) -- one fp32 subtraction each, rounded to nearest, wherever it is
 // computed: at upload (pt_context.hip: tri_packet_of, the host's float subtraction) instead of per test (six vector
@@ -109,6 +135,8 @@ struct SceneRefs {
     const float4 *packets;  // NodePacket array (internal nodes, breadth-first), or null
     const float4 *wide;     // WidePacket array (WIDE walk), or null
     const float4 *tripk;    // TriPacket array, or null
+    const float4 *cwide;    // CWidePacket array (kernel variant 13: same numbering as `wide`), or null
+    const float4 *tripk64;  // TriPacket64 array (kernel variant 13), or null
     const uint32_t *leaf_rank;  // per triangle: rank of its leaf in the reference's visiting order
     int32_t leaf_cap;       // > 0: leaves may be tested out of order; LDS slots available for deferred leaves
     int32_t wide_leaf_cap;  // > 0: the WIDE walk is offered (wide packets built, stack bound holds)
@@ -118,7 +146,8 @@ struct SceneRefs {
     uint32_t ntris, nnodes, nmats, npackets;
     uint32_t root_ref;      // reference of node 0 in packet terms
     uint32_t flags;         // bit0: every ROOT box coordinate is 0 or within [2^-70, 2^60]; bit1 (wide packets): the root's box contains the
-                            // boxes of its children, so the wide walk may start at the root packet without testing the root's own box
+                            // boxes of its children, so the wide walk may start at the root packet without testing the root's own box;
+                            // bit2: the scene's culling margins are negligible (the one-axis culling condition: what `auto` = 12 means)
     float cull_ka, cull_kb; // CULL walk: scene constants of the distance bound (pt_kernels.hip cull_setup; context: prepare_cull)
     int32_t env_w, env_h;
 };
@@ -186,7 +215,8 @@ struct RtLaunch {
     int32_t job_reverse;         // state-machine kernel: 1 = the job sequence backwards (the image's top band, usually sky, last)
     int32_t job_chunk;           // state-machine kernel: job tickets per draw from the queue while it is long (>= 1)
     uint32_t *stack_overflow;    // state-machine kernel: [grid][32][64] stack entries beyond the LDS part
-    uint64_t *wave_times;        // diagnostic: [grid][4] begin / feed-empty / end (100 MHz) + shader cycles, or null
+    uint64_t *wave_times;        // diagnostic: [grid][16] begin / feed-empty / end (100 MHz) + shader cycles + step statistics, or null
+    int32_t diag_lite;           // experiment builds, wave_times bound: 1 = the LEAN build with lane counts only (k_raytrace_sm's LITE) instead of the diagnostic twin
     int32_t store_f16;
     int32_t walk_min;            // state-machine kernel: walk while at least this many lanes are walking
     int32_t leaf_min;            // deferred-leaf walk: run a triangle step once this many lanes have a leaf parked
@@ -233,9 +263,9 @@ int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, ui
                       int lcap, int leaf_min, int num_cus, hipStream_t s);
 int raytrace_grid_blocks(const Tile &tile);
 int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned = false);
-// writes NodePacket::cull of `npackets` packets from a dense array (the context's cull analysis)
 // packs the three position vectors of `ntris` 112-byte triangle records into 48-byte rows (the context's cull analysis)
 void launch_pack_vertices(const float4 *tris, float4 *out, uint32_t ntris, hipStream_t s);
+// writes NodePacket::cull of `npackets` packets from a dense array (the context's cull analysis)
 void launch_patch_cull(float4 *packets, const uint32_t *cull, uint32_t npackets, hipStream_t s);
 
 }  // namespace pt

@@ -256,6 +256,49 @@ PT_DEV float slab_margin(float tmin, float tfar)
 // the predicate for a decided box
 PT_DEV bool slab_hit(float tmin, float tfar) { return fmaxf(tmin - tfar, -tfar) <= 0.0f; }
 
+// ---------------------------------------------------------------------------------
+// Compressed wide packets (kernel variant 13): a test that NEVER rejects a box the reference's exact test would pass.
+//
+// The packet holds boxes on an 8-bit grid, rounded outward by >= one whole cell c_i = 2^e_i per side (pt_kernels.h, CWidePacket):
+// decoded plane p' = o_i + c_i q lies >= c_i outside the child's plane p.  The kernel forms each quotient as ONE fma,
+//     t~ = fma(q, B_i, A_i),   B_i = c_i * RN(1/d_i) (exact: a power of two),   A_i = RN(RN(o_i - O_i) * RN(1/d_i))     (O = ray origin),
+// whose value differs from the real quotient t' = (p' - O_i) / d_i by at most 3u |t'| + 2.01u |A_i|, and |A_i| <= |t'| + 255 c_i / |d_i|:
+//     |t~ - t'|  <=  5.02u |t'|  +  3.1e-5 * c_i / |d_i|.
+// The second term is a 3e-5-th of the cell the plane was moved outward by (c_i / |d_i| in t), so t~ is, up to a RELATIVE error of
+// 5.02u, the real quotient of a plane that still lies >= 0.99996 c_i outside the child's: of a box E that contains the child's box
+// B.  Let the reference's fp32 test pass for B (raytrace.wgsl:118-152: tmin <= tmax and tmax >= 0, its quotients correctly
+// rounded: relative error <= 1.5u each, signs exact).  Then in real arithmetic tn(B) - tf(B) <= 3u max(|tn|, |tf|) and tf(B) >= 0; E
+// contains B, so tn(E) <= tn(B), tf(E) >= tf(B) + 0.99996 c_i / |d_i| > 0; and for the computed values (min / max commute with the
+// increasing maps x -> x (1 +- 5.02u)):  tmin~ - tfar~ <= (3 + 10.04) u M < 2^-20 M  with M = max(|tmin~|, |tfar~|), and tfar~ > 0
+// (its real value exceeds c_i / |d_i| - ..., far above its error).  So rejecting only when
+//     tmin~ - tfar~ > 2^-20 M   or   tfar~ < 0
+// never rejects a box the reference passes.  False accepts cost work, never a bit: the reference reaches a leaf iff its LEAF box
+// passes (every box nested: a leaf that passes has every ancestor pass, the monotonicity behind the wide collapse), and that test
+// is made exactly, on the leaf's own box, in the triangle step (leaf_box_hit).  The per-axis entry distances handed to the culling
+// bound are <= the child's own (E contains B) up to 5.02u, inside what DESIGN.md 3a budgets once its 4.01u is read as 5.02u -- the
+// bound's factor (1 + 2^-20) has room for 16u.
+// ---------------------------------------------------------------------------------
+#define PT_CW_BAND 9.5367431640625e-07f      // 2^-20
+PT_DEV bool cwide_hit(float tmin, float tfar)
+{
+    const float m = fmaxf(fabsf(tmin), fabsf(tfar));
+    return !(fmaf(-PT_CW_BAND, m, tmin - tfar) > 0.0f) && !(tfar < 0.0f);
+}
+
+// the reference's test of a LEAF's box (raytrace.wgsl:186, 194) for the compressed-wide walk's triangle step: the filtered test,
+// the exact one where that cannot decide, the plain-division one for the rays that take it everywhere
+PT_DEV bool leaf_box_hit(const f3 &o, const f3 &d, const RayPre &p, bool box_unsafe, const f3 &mn, const f3 &mx)
+{
+    if ((p.flags & 8u) || box_unsafe) return ray_aabb(o, d, mn.x, mn.y, mn.z, mx.x, mx.y, mx.z);
+    f3 tn;
+    float tf;
+    slab_q0(o, p, mn.x, mn.y, mn.z, mx.x, mx.y, mx.z, tn, tf);
+    const float key = fmaxf(fmaxf(tn.x, tn.y), tn.z);
+    bool h = slab_hit(key, tf);
+    if (!(slab_margin(key, tf) > 0.0f)) h = ray_aabb_fast(o, d, p, mn.x, mn.y, mn.z, mx.x, mx.y, mx.z);
+    return h;
+}
+
 // raytrace.wgsl:78-116 -- Moller-Trumbore, two-sided.  Returns hit and (t, u, v);
 // position and normal are formed once, for the closest hit, by finish_hit().
 PT_DEV bool ray_triangle(const f3 &o, const f3 &d, const f3 &a, const f3 &b, const f3 &c,
@@ -1150,6 +1193,9 @@ PT_DEV T uniform_block(const T &v)
     return t;
 }
 
+#ifndef PT_CW_NO_PAIR_TEST
+#define PT_CW_NO_PAIR_TEST 0
+#endif
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
 #define PT_SM_TOP_PACKETS 32       // node packets staged in LDS per wave (2 KB: 16 waves per CU still fit): the top 5 levels
 // TOPLDS = true additionally stages the first PT_SM_TOP_PACKETS node packets in LDS (kernel
@@ -1182,20 +1228,24 @@ PT_DEV T uniform_block(const T &v)
 // only, with the largest of the three |RN(1/d_i)| -- one operation per child instead of four; it skips less, so the
 // context chooses it only for scenes whose culling margins are negligible (SceneRefs::cull_ymax).
 //
-// DIAG = false: the lean build every ordinary launch runs (below).  TOPLDS: experiment builds only.
-template <bool DEFER, bool CULL, bool WIDE, bool FILT, bool YMAX, bool DIAG, bool TOPLDS = false>
+// DIAG = false: the lean build every ordinary launch runs (below).  TOPLDS, LITE: experiment builds only.  LITE (with DIAG = false):
+// the lean build plus the wave-uniform lane counts per kind of step (scalar registers) and two clock reads, written once at exit
+// -- how many lanes each kind of step serves in the kernel that ships, not in its four-wave diagnostic twin (round-3 verdict).
+// CW (with WIDE): the walk on compressed wide packets and 64-byte triangle records (variant 13; cwide_hit above).
+template <bool DEFER, bool CULL, bool WIDE, bool FILT, bool YMAX, bool DIAG, bool TOPLDS = false, bool LITE = false, bool CW = false>
 __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_WAVES_PER_SIMD) k_raytrace_sm(const RtLaunch L)
 {
     static_assert(!CULL || DEFER, "the culling walks park their leaves");
-    static_assert((!WIDE || CULL) && (!FILT || WIDE) && (!YMAX || FILT), "WIDE needs CULL, FILT needs WIDE, YMAX needs FILT");
+    static_assert((!WIDE || CULL) && (!FILT || WIDE) && (!YMAX || FILT) && (!CW || FILT), "WIDE needs CULL, FILT needs WIDE, YMAX and CW need FILT");
     // DIAG = false (the shipped walks' batched launches when no diagnostic buffer is bound): the per-wave step statistics
     // and stamps are compiled out -- two dozen scalar registers that the walk loop's own scalars were spilled for
     uint64_t *const wave_times = DIAG ? L.wave_times : nullptr;
+    const bool count_on = DIAG ? wave_times != nullptr : LITE;        // the step / lane counts (LITE: always; the lean build: never)
     // ... and the step-voting knobs are the defaults as constants (launch_raytrace sends any other setting to the DIAG twin)
     const int k_walk_min = DIAG ? L.walk_min : PT_DEFAULT_WALK_MIN, k_leaf_min = DIAG ? L.leaf_min : PT_DEFAULT_LEAF_MIN;
     const int k_shade_split = DIAG ? L.shade_split : PT_DEFAULT_SHADE_SPLIT, k_tail_policy = DIAG ? L.tail_policy : PT_DEFAULT_TAIL_POLICY;
     const int k_job_chunk = DIAG ? L.job_chunk : PT_DEFAULT_JOB_CHUNK;
-    const bool k_tri_pair = DIAG ? L.tri_pair != 0 : true;
+    const bool k_tri_pair = DIAG ? L.tri_pair != 0 : !PT_CW_NO_PAIR_TEST;
     constexpr bool TUNED = !DIAG;
     // ... and, in the lean builds of the culling walks, so are the conditions every scene that admits those walks meets at an
     // ordinary resolution: a scene with nodes whose root is an internal node with a guard-range box, a resolution of ordinary
@@ -1277,8 +1327,8 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     RtService S0;
     if constexpr (!TUNED) S0 = uniform_block(compute_service(L, sc.nnodes != 0));
     // diagnostic stamps (only when a buffer is bound): wall clock (100 MHz) and shader clock
-    const uint64_t t_begin_rt = wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const uint64_t t_begin_clk = wave_times ? __builtin_amdgcn_s_memtime() : 0ull;
+    const uint64_t t_begin_rt = (wave_times || LITE) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const uint64_t t_begin_clk = (wave_times || LITE) ? __builtin_amdgcn_s_memtime() : 0ull;
     uint64_t t_empty_rt = 0ull;
     // diagnostic step statistics (wave-uniform; stored with the stamps)
     uint32_t st_walk_steps = 0, st_walk_lanes = 0, st_leaf_lanes = 0, st_service_steps = 0;
@@ -1389,8 +1439,51 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 // every lane with a parked leaf tests one -- or two, when it has two (L.tri_pair): the second triangle's
                 // loads are in flight with the first's, and the lane needs one triangle step less
                 const bool two = k_tri_pair && (CULL ? nl > 1 : (has_leaf && nl > 1));
-                u_tri += (uint32_t)n_leaf + (k_tri_pair ? (uint32_t)__popcll(__ballot(two)) : 0u);      // (wave-uniform count: scalar)
-                if (wave_times) { st_switch(1); st_tri_steps++; st_parked += wave_sum((uint32_t)(has_leaf ? nl : 0)); st_leaf_lanes += (uint32_t)n_leaf; if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
+                if (!CW) u_tri += (uint32_t)n_leaf + (k_tri_pair ? (uint32_t)__popcll(__ballot(two)) : 0u);      // (wave-uniform count: scalar; CW counts per lane: only the leaves whose own box passes)
+                if (wave_times) { st_switch(1); st_parked += wave_sum((uint32_t)(has_leaf ? nl : 0)); if (feed_empty) { st_tail_tri++; st_tail_lanes += (uint32_t)n_leaf; } }
+                if (count_on) { st_tri_steps++; st_leaf_lanes += (uint32_t)n_leaf; }
+                if constexpr (CW) {
+                  if (has_leaf) {
+                    // compressed-wide walk: a parked leaf is a CANDIDATE (its packet's box was rounded outward); the reference tests the
+                    // triangle iff the leaf's own box passes its exact test -- made here, from the 64-byte record that carries that box
+                    nl--;
+                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64];
+                    uint32_t tj = ti;
+                    if (two) { nl--; tj = stack[(DEPTH - 1 - nl) * 64]; }
+                    float4 pa = sc.tripk64[(size_t)ti * 4 + 0], pb = sc.tripk64[(size_t)ti * 4 + 1], pc = sc.tripk64[(size_t)ti * 4 + 2], pd = sc.tripk64[(size_t)ti * 4 + 3];
+                    float4 qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), qb = qa, qc = qa, qd = qa;
+                    if (two) { qa = sc.tripk64[(size_t)tj * 4 + 0]; qb = sc.tripk64[(size_t)tj * 4 + 1]; qc = sc.tripk64[(size_t)tj * 4 + 2]; qd = sc.tripk64[(size_t)tj * 4 + 3]; }
+                    asm volatile("" : "+v"(pa.x), "+v"(pa.y), "+v"(pa.z), "+v"(pa.w));
+                    asm volatile("" : "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w));
+                    asm volatile("" : "+v"(pc.x), "+v"(pc.y), "+v"(pc.z), "+v"(pc.w));
+                    asm volatile("" : "+v"(pd.x), "+v"(pd.y), "+v"(pd.z), "+v"(pd.w));
+                    {
+                        float t, u, v;
+                        const bool inbox = leaf_box_hit(o, d, pre, __float_as_uint(pd.w) != 0u, F3(pc.y, pc.z, pc.w), F3(pd.x, pd.y, pd.z));
+                        const bool hit = ray_triangle_flat_e(o, d, F3(pa.x, pa.y, pa.z), F3(pa.w, pb.x, pb.y), F3(pb.z, pb.w, pc.x), t, u, v) && inbox;
+                        cnt.tri += inbox ? 1u : 0u;
+                        bool take = hit && t < best.t;
+                        if (hit && t == best.t && best.tri >= 0) take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
+                        best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                        best.tri = take ? (int32_t)ti : best.tri;
+                    }
+                    if (two) {
+                        asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qa.z), "+v"(qa.w));
+                        asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
+                        asm volatile("" : "+v"(qc.x), "+v"(qc.y), "+v"(qc.z), "+v"(qc.w));
+                        asm volatile("" : "+v"(qd.x), "+v"(qd.y), "+v"(qd.z), "+v"(qd.w));
+                        float t, u, v;
+                        const bool inbox = leaf_box_hit(o, d, pre, __float_as_uint(qd.w) != 0u, F3(qc.y, qc.z, qc.w), F3(qd.x, qd.y, qd.z));
+                        const bool hit = ray_triangle_flat_e(o, d, F3(qa.x, qa.y, qa.z), F3(qa.w, qb.x, qb.y), F3(qb.z, qb.w, qc.x), t, u, v) && inbox;
+                        cnt.tri += inbox ? 1u : 0u;
+                        bool take = hit && t < best.t;
+                        if (hit && t == best.t && best.tri >= 0) take = sc.leaf_rank[tj] < sc.leaf_rank[best.tri];
+                        best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                        best.tri = take ? (int32_t)tj : best.tri;
+                    }
+                    if (sp == 0 && nl == 0) mode = M_SHADE;
+                  }
+                } else
                 if (has_leaf) {
                     if (DIAG) lane_cost += two ? 6u : 3u;
                     nl--;
@@ -1437,22 +1530,61 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 }
             } else {
                 if (!WIDE) u_box += 2u * (uint32_t)n_node;  // proper tree: both children of every popped node are tested (WIDE: per lane)
-                if (wave_times) { st_switch(0); st_walk_steps++; st_walk_lanes += (uint32_t)n_node; if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
+                if (wave_times) { st_switch(0); if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
+                if (count_on) { st_walk_steps++; st_walk_lanes += (uint32_t)n_node; }
                 // (CULL) can any lane's node entries leave the LDS part of its stack in this step?  One pop, then up to two / four pushes.
                 const bool shallow = CULL && __ballot(sp > NCAP - (WIDE ? 3 : 1)) == 0ull;
                 if (WIDE) {
                   if (has_node) {
                     if (DIAG) lane_cost += 4u;
                     const uint32_t ref = shallow ? flat_pop() : cull_pop();
-                    const float4 *P = sc.wide + (size_t)ref * 8;
-                    const float4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3], q4 = P[4], q5 = P[5], q6 = P[6], q7 = P[7];
-                    uint32_t cr[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
-                    const uint32_t wf = __float_as_uint(q7.z);
+                    uint32_t cr[4], w01, w23, nchild;
                     bool hit[4];
                     float key[4];                    // entry distance of each box (approximate with FILT): sort key and culling bound
                     f3 tn[4];                        // per-axis entry distances (!YMAX)
                     tn[0] = tn[1] = tn[2] = tn[3] = F3(-PT_INF, -PT_INF, -PT_INF);
                     key[0] = key[1] = key[2] = key[3] = -PT_INF;
+                    if constexpr (CW) {
+                        // compressed wide packet: 64 bytes, boxes on the node's 8-bit grid, rounded outward (CWidePacket; cwide_hit)
+                        const float4 *P = sc.cwide + (size_t)ref * 4;
+                        const float4 c0 = P[0], c1 = P[1], c2 = P[2], c3 = P[3];
+                        cr[0] = __float_as_uint(c3.x); cr[1] = __float_as_uint(c3.y); cr[2] = __float_as_uint(c3.z); cr[3] = __float_as_uint(c3.w);
+                        const uint32_t meta = __float_as_uint(c0.w);
+                        w01 = __float_as_uint(c2.z); w23 = __float_as_uint(c2.w); nchild = (meta >> 24) & 7u;
+                        const uint32_t lx = __float_as_uint(c1.x), ly = __float_as_uint(c1.y), lz = __float_as_uint(c1.z);
+                        const uint32_t hx = __float_as_uint(c1.w), hy = __float_as_uint(c2.x), hz = __float_as_uint(c2.y);
+                        const float cx = __uint_as_float((meta & 0xffu) << 23), cy = __uint_as_float(((meta >> 8) & 0xffu) << 23), cz = __uint_as_float(((meta >> 16) & 0xffu) << 23);
+                        if ((pre.flags & 8u) == 0u) {
+                            const float Ax = (c0.x - o.x) * pre.ix, Ay = (c0.y - o.y) * pre.iy, Az = (c0.z - o.z) * pre.iz;
+                            const float Bx = cx * pre.ix, By = cy * pre.iy, Bz = cz * pre.iz;
+#define PT_CBOX(K)                                                                                                          \
+                            {                                                                                              \
+                                const float ax_ = fmaf((float)((lx >> (8 * K)) & 0xffu), Bx, Ax), bx_ = fmaf((float)((hx >> (8 * K)) & 0xffu), Bx, Ax); \
+                                const float ay_ = fmaf((float)((ly >> (8 * K)) & 0xffu), By, Ay), by_ = fmaf((float)((hy >> (8 * K)) & 0xffu), By, Ay); \
+                                const float az_ = fmaf((float)((lz >> (8 * K)) & 0xffu), Bz, Az), bz_ = fmaf((float)((hz >> (8 * K)) & 0xffu), Bz, Az); \
+                                const f3 a_ = F3(fminf(ax_, bx_), fminf(ay_, by_), fminf(az_, bz_));                       \
+                                const float f_ = fminf(fminf(fminf(PT_INF, fmaxf(ax_, bx_)), fmaxf(ay_, by_)), fmaxf(az_, bz_)); \
+                                key[K] = fmaxf(fmaxf(a_.x, a_.y), a_.z);                                                   \
+                                if constexpr (!YMAX) tn[K] = a_;                                                           \
+                                hit[K] = cwide_hit(key[K], f_);                                                            \
+                            }
+                            PT_CBOX(0) PT_CBOX(1) PT_CBOX(2) PT_CBOX(3)
+#undef PT_CBOX
+                        } else {
+                            // a ray on the plain-division path (a parallel axis, an out-of-range component): the reference's test on the
+                            // decoded box -- exact fp32 coordinates (o + cell * q is representable: the builder keeps cells coarse
+                            // against the coordinates), a box that contains the child's: monotone, hence conservative too
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                hit[k] = ray_aabb(o, d, fmaf((float)((lx >> (8 * k)) & 0xffu), cx, c0.x), fmaf((float)((ly >> (8 * k)) & 0xffu), cy, c0.y), fmaf((float)((lz >> (8 * k)) & 0xffu), cz, c0.z),
+                                                  fmaf((float)((hx >> (8 * k)) & 0xffu), cx, c0.x), fmaf((float)((hy >> (8 * k)) & 0xffu), cy, c0.y), fmaf((float)((hz >> (8 * k)) & 0xffu), cz, c0.z));
+                        }
+                    } else {
+                    const float4 *P = sc.wide + (size_t)ref * 8;
+                    const float4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3], q4 = P[4], q5 = P[5], q6 = P[6], q7 = P[7];
+                    cr[0] = __float_as_uint(q6.x); cr[1] = __float_as_uint(q6.y); cr[2] = __float_as_uint(q6.z); cr[3] = __float_as_uint(q6.w);
+                    const uint32_t wf = __float_as_uint(q7.z);
+                    w01 = __float_as_uint(q7.x); w23 = __float_as_uint(q7.y); nchild = (wf >> 4) & 7u;
                     if (((pre.flags & 8u) | (wf & 15u)) == 0u) {
                         if constexpr (FILT) {
                             // filtered slab test (see slab_q0): one multiplication per quotient; box by box, the exact test of an
@@ -1488,10 +1620,10 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                         hit[2] = ray_aabb_pre(o, d, pre, (wf & 4u) != 0u, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y);
                         hit[3] = ray_aabb_pre(o, d, pre, (wf & 8u) != 0u, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w);
                     }
+                    }
                     // distance bound per child, entry distances as sort keys
                     const float rc = fmaf(cull_ka, best.t, cull_kb);
                     const float bt = best.t * 1.00000095367431640625f;
-                    const uint32_t w01 = __float_as_uint(q7.x), w23 = __float_as_uint(q7.y);
                     const float wgt[4] = { __uint_as_float(w01 & 0xffff0000u), __uint_as_float(w01 << 16),
                                            __uint_as_float(w23 & 0xffff0000u), __uint_as_float(w23 << 16) };
                     // YMAX: (S) on the axis that sets the entry distance, with |RN(1/d_i)| replaced by the largest of the
@@ -1507,7 +1639,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                         // pairs only -- selects, no branches, no lane masks to swap
                         cr[k] = (hit[k] && !(tc > bt)) ? cr[k] : PT_REF_NONE;
                     }
-                    cnt.box += (wf >> 4) & 7u;           // the packet's number of children
+                    cnt.box += nchild;           // the packet's number of children
                     // far first, near last (popped first): sort the four entries by entry distance, descending
 #define PT_CSWAP(A, B)                                                                         \
                     {                                                                          \
@@ -1602,7 +1734,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
         }
         {
             // ---- walk step: one pop per walking lane (raytrace.wgsl:166-200)
-            if (wave_times) { st_walk_steps++; st_walk_lanes += (uint32_t)nwalk; }
+            if (count_on) { st_walk_steps++; st_walk_lanes += (uint32_t)nwalk; }
             // Wave-uniform choice: when no walking lane needs the plain-division test or the
             // overflow part of the stack, the step runs a version without those branches
             // (stack accesses are plain LDS, both child boxes are tested and pushed without
@@ -1730,8 +1862,10 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
         }
         if (wave_times) {
             st_switch(2);
-            st_service_steps++;
             if (feed_empty) st_tail_service++;
+        }
+        if (count_on) {
+            st_service_steps++;
             if (do_hit) { st_hit_steps++; st_hit_lanes += (uint32_t)n_hit; }
             if (do_b) { st_b_steps++; st_shade_lanes += (uint32_t)__popcll(__ballot(mode == M_SHADE && best.tri < 0)); }
         }
@@ -1884,7 +2018,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
             }
         }
         PT_SERVICE_PART();
-        if (wave_times) st_path_lanes += (uint32_t)__popcll(__ballot(do_b && mode == M_PATH));
+        if (count_on) st_path_lanes += (uint32_t)__popcll(__ballot(do_b && mode == M_PATH));
         if (do_b && mode == M_PATH) {
             // raytrace.wgsl:441-455: next sample's camera path, or the pixel is finished
             mode = M_DEAD;
@@ -1938,7 +2072,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
         if (wave_times) st_switch(6);
 #endif
         PT_SERVICE_PART();
-        if (wave_times) st_segment_lanes += (uint32_t)__popcll(__ballot(need_segment));
+        if (count_on) st_segment_lanes += (uint32_t)__popcll(__ballot(need_segment));
         {
             const uint32_t nseg = (uint32_t)__popcll(__ballot(need_segment));
             if (DIAG) u_rays += nseg;          // (shipped kernels: every segment ends in a hit or a miss, counted there)
@@ -1992,6 +2126,23 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
 #undef PT_SERVICE_PART
     }
 
+    if constexpr (LITE && !DIAG) {
+        if (L.wave_times && lane == 0) {       // (the same slots as the diagnostic twin's below; what it does not measure stays 0)
+            uint64_t *w = L.wave_times + (size_t)blockIdx.x * 16;
+            w[8] = st_tri_steps;
+            w[9] = 0; w[10] = 0; w[11] = 0;
+            w[12] = ((uint64_t)st_hit_steps << 32) | st_b_steps;
+            w[13] = 0; w[14] = 0; w[15] = 0;
+            w[0] = t_begin_rt;
+            w[1] = 0;
+            w[2] = __builtin_amdgcn_s_memrealtime();
+            w[3] = __builtin_amdgcn_s_memtime() - t_begin_clk;
+            w[4] = ((uint64_t)st_walk_steps << 32) | st_walk_lanes;
+            w[5] = ((uint64_t)st_service_steps << 32) | st_leaf_lanes;
+            w[6] = ((uint64_t)st_shade_lanes << 32) | st_hit_lanes;
+            w[7] = ((uint64_t)st_path_lanes << 32) | st_segment_lanes;
+        }
+    }
     if (wave_times && lane == 0) {
         uint64_t *w = wave_times + (size_t)blockIdx.x * 16;
         st_switch(2);
@@ -2080,7 +2231,7 @@ static bool launch_packs(const RtLaunch &L)
 // memory) runs unless a diagnostic buffer is bound or a step-voting option was changed (mi3pt_debug_set_option).
 static bool launch_is_lean(const RtLaunch &L)
 {
-    return !L.wave_times && !L.tile_cost && L.walk_min == PT_DEFAULT_WALK_MIN && L.leaf_min == PT_DEFAULT_LEAF_MIN && L.shade_split == PT_DEFAULT_SHADE_SPLIT &&
+    return (!L.wave_times || L.diag_lite) && !L.tile_cost && L.walk_min == PT_DEFAULT_WALK_MIN && L.leaf_min == PT_DEFAULT_LEAF_MIN && L.shade_split == PT_DEFAULT_SHADE_SPLIT &&
            L.tail_policy == PT_DEFAULT_TAIL_POLICY && L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 && L.service != nullptr;
 }
 // What the lean builds of the culling walks have as constants (ASSUME in the kernel): a scene with nodes whose root is an
@@ -2109,8 +2260,9 @@ static RtRoute route_launch(const RtLaunch &L, int variant)
     if (!launch_packs(L)) return r;                      // per-pixel kernel 2, frame by frame
     r.kind = 1;
     r.lean = launch_is_lean(L);
-    if (variant >= 9 && variant <= 12 && r.lean && !launch_assumptions_hold(L)) variant = L.scene.leaf_cap >= 4 ? 7 : 4;
-    if (variant >= 10 && variant <= 12 && !r.lean) variant = 10;      // the diagnostic twin of the wide walks runs the exact slab test: same bits
+    if (variant == 13 && !(L.scene.cwide && L.scene.tripk64)) variant = 10;
+    if (variant >= 9 && variant <= 13 && r.lean && !launch_assumptions_hold(L)) variant = L.scene.leaf_cap >= 4 ? 7 : 4;
+    if (variant >= 10 && variant <= 13 && !r.lean) variant = 10;      // the diagnostic twin of the wide walks runs the exact slab test: same bits
 #ifndef MI3PT_EXPERIMENTS
     if (variant < 9 && !r.lean) {
         // release builds carry diagnostic twins for the culling walks only: the lean build runs (options and the diagnostic buffer
@@ -2164,6 +2316,17 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
         const dim3 grid(persistent_blocks_for(L, r));
 #define PT_SM(...) hipLaunchKernelGGL((k_raytrace_sm<__VA_ARGS__>), grid, block, 0, s, L)
         //                               DEFER  CULL   WIDE   FILT   YMAX   DIAG
+#ifdef MI3PT_EXPERIMENTS
+        if (r.lean && L.wave_times && L.diag_lite && r.variant >= 10) switch (r.variant) {      // the lean build + lane counts
+            case 12: PT_SM(true,  true,  true,  true,  true,  false, false, true); break;
+            case 11: PT_SM(true,  true,  true,  true,  false, false, false, true); break;
+            default: PT_SM(true,  true,  true,  false, false, false, false, true); break;
+        } else
+#endif
+        if (r.lean && r.variant == 13) {        // compressed wide packets (SceneRefs::flags bit 2: the one-axis culling condition suits this scene)
+            if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, false, false, true);
+            else PT_SM(true, true, true, true, false, false, false, false, true);
+        } else
         if (r.lean) switch (r.variant) {
             case 12: PT_SM(true,  true,  true,  true,  true,  false); break;
             case 11: PT_SM(true,  true,  true,  true,  false, false); break;

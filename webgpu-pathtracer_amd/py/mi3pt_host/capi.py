@@ -23,7 +23,7 @@ PRESENT_EXACT, PRESENT_LATEST = 0, 1
 # mi3pt_option (include/mi3pt.h): scheduling options; none changes a bit of any image
 (OPT_WALK_MIN, OPT_LEAF_MIN, OPT_SHADE_SPLIT, OPT_TAIL_POLICY, OPT_TOP_PACKETS, OPT_TRI_PAIR, OPT_JOB_REVERSE, OPT_JOB_GROUP,
  OPT_JOB_CHUNK, OPT_BATCH_LIMIT, OPT_BATCH, OPT_WAVES_PER_CU, OPT_CULL, OPT_WIDE, OPT_GATE, OPT_SLOT_SETS, OPT_PIPELINE,
- OPT_COST_ORDER, OPT_PRESENT_DEPTH, OPT_HOST_ANALYSES, OPT_GATHER_STAGED) = range(21)
+ OPT_COST_ORDER, OPT_PRESENT_DEPTH, OPT_HOST_ANALYSES, OPT_GATHER_STAGED, OPT_DIAG_LITE) = range(22)
 COUNTER_NAMES = ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels", "reserved")
 
 # every symbol include/mi3pt.h declares; tests/test_capi_symbols.py checks the header
