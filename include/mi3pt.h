@@ -373,6 +373,7 @@ int mi3pt_device_build_bvh(mi3pt_ctx *ctx, void *nodes_out, size_t nodes_capacit
  * triangles restores the shipped numbering. */
 int mi3pt_debug_set_packet_layout(mi3pt_ctx *ctx, int layout);
 
+#ifdef MI3PT_EXPERIMENTS       /* the experiment build only (make -C webgpu-pathtracer_amd/csrc experiments): not in libmi3pt.so */
 /* Design experiment, not part of the rendering path: walks `n` given rays (6 floats each) with the
  * deferred-leaf walk ALONE (no shading) as a persistent kernel with 4, 5, 6 or 8 resident waves
  * per SIMD, `passes` times over the list inside one launch (amortises the drain), and reports the
@@ -380,6 +381,7 @@ int mi3pt_debug_set_packet_layout(mi3pt_ctx *ctx, int layout);
  * ray = the hit raySceneIntersect would report. */
 int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t n, int waves_per_simd, int repeats, int passes,
                            float *out_tuvi, float *ms_out);
+#endif
 /* fn: 0 sin, 1 cos, 2 tan, 3 log, 4 exp, 5 atan2(a,b), 6 asin, 7 pow(a,b),
  * 8 fp16 round trip, 9 sqrt, 10 a/b; the kernels' reduced-instruction forms: 11 sqrt, 12 1/a,
  * 13..15 x/y/z of normalize(a, b, a - b).  b may be NULL for unary functions. */

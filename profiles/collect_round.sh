@@ -4,7 +4,7 @@
 # kernel stats + kernel trace of the bench command itself, the scaling model, the culling probe
 # on BASELINE configs 2 / 3 / 5, wave timelines, the Node render-loop bench, fullscreen timing.
 # bench.py runs its own PMC passes (roofline.traffic, valu_issue_frac, ...), so none are run here.
-# usage: bash profiles/collect_round.sh <tag>      (about 8 GPU-minutes)
+# usage: bash profiles/collect_round.sh <tag>      (about 10 GPU-minutes)
 set -u
 TAG=${1:-round}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -20,10 +20,18 @@ python profiles/scaling_model.py --steps 4 --warmup 1 > $OUT/${TAG}_scaling_mode
 echo "scaling model done"
 (python profiles/cull_probe.py demo; python profiles/cull_probe.py dragon; python profiles/cull_probe.py forest 3840x2160 8) > $OUT/${TAG}_cull_probe.log 2>&1
 echo "cull probe done"
-python profiles/wave_timeline.py 1920x1080 16 > $OUT/${TAG}_wave_timeline_demo.log 2>&1
-WORKLOAD=dragon python profiles/wave_timeline.py 1920x1080 16 > $OUT/${TAG}_wave_timeline_dragon.log 2>&1
-WORKLOAD=dragon TILE=0/8 python profiles/wave_timeline.py 1920x1080 20 > $OUT/${TAG}_wave_timeline_dragon_rank0of8_20frames.log 2>&1
-WORKLOAD=forest python profiles/wave_timeline.py 1920x1080 16 > $OUT/${TAG}_wave_timeline_forest.log 2>&1
+# wave timelines: the LEAN kernel with lane counts (experiment build: what ships + a dozen scalar counters, five waves) and the
+# four-wave diagnostic twin (clock stamps per step: cycle split and drain statistics; half the shipped kernel's speed)
+if [ -f webgpu-pathtracer_amd/libmi3pt_exp.so ]; then
+  for W in demo dragon forest; do
+    MI3PT_LIBRARY=$ROOT/webgpu-pathtracer_amd/libmi3pt_exp.so LITE=1 WORKLOAD=$W python profiles/wave_timeline.py 1920x1080 64 > $OUT/${TAG}_wave_timeline_${W}_lite.log 2>&1
+  done
+fi
+WORKLOAD=dragon python profiles/wave_timeline.py 1920x1080 64 > $OUT/${TAG}_wave_timeline_dragon_twin.log 2>&1
+WORKLOAD=dragon TILE=3/8 python profiles/wave_timeline.py 1920x1080 256 > $OUT/${TAG}_wave_timeline_dragon_rank3of8_256frames_twin.log 2>&1
+bash profiles/rank_timeline.sh ${TAG}_rank3of8 > $OUT/${TAG}_rank_timeline.log 2>&1
+python profiles/probe_spf.py dragon frames > $OUT/${TAG}_spf_same_frames.log 2>&1
+(for W in demo dragon; do echo "== $W"; WORKLOAD=$W python profiles/probe_interactive.py 64; done) > $OUT/${TAG}_interactive.log 2>&1
 python profiles/fullscreen_time.py > $OUT/${TAG}_fullscreen_time.log 2>&1
 python -c "
 import sys; sys.path.insert(0, 'webgpu-pathtracer_amd/py')

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Probe of the distance-culling walks (variant 9: binary packets, 10: 4-ary wide packets) against the reference-counter walk (variant 7):
+"""Probe of the distance-culling walks (variant 9: binary packets, 10 - 12: 4-ary wide packets, 13: compressed wide packets) against the reference-counter walk (variant 7):
 ms per frame, Mrays/s, box and triangle tests per ray, image identity.
 usage: python profiles/cull_probe.py [demo|dragon|forest[:instances]] [WxH] [frames]"""
 import os, sys, time
@@ -26,7 +26,7 @@ ctx = capi.Context(0)
 pc.upload_scene(ctx, sc, env)
 ctx.resize(w, h)
 images = {}
-for variant in (7, 9, 10):
+for variant in (7, 9, 10, 11, 12, 13):
     ctx.set_kernel_variant(variant)
     ctx.reset()
     f = 2
@@ -43,4 +43,4 @@ for variant in (7, 9, 10):
     images[variant] = ctx.read_texture(capi.TEX_ACCUMULATION)
     print(f"  variant {variant}: {dt / nframes * 1e3:.3f} ms/frame, {c['rays'] / dt / 1e6:.0f} Mrays/s, "
           f"box/ray {c['box_tests'] / c['rays']:.2f}, tri/ray {c['tri_tests'] / c['rays']:.2f}, slow {c['reserved']}", flush=True)
-print("  images identical:", pc.same_bits(images[7], images[9]) and pc.same_bits(images[7], images[10]), pc.describe_diff(images[9], images[7]), pc.describe_diff(images[10], images[7]))
+print("  images identical:", all(pc.same_bits(images[7], images[v]) for v in images), " ".join(pc.describe_diff(images[v], images[7]) for v in sorted(images) if v != 7))

@@ -4,7 +4,8 @@
   b) the same with a sync after every frame
   c) raytrace + accumulate + fullscreen per frame and a sync after every frame (what an interactive viewer does)
   d) c + the 8-bit canvas read back every frame
-usage: python profiles/probe_interactive.py [frames [waves per CU]]"""
+Per leg also: the GPU time of the raytrace launches alone (event pairs) -- what is left is launch latency, the other passes and the
+host's round trip.  usage: [WORKLOAD=dragon] python profiles/probe_interactive.py [frames [waves per CU]]"""
 import os
 import sys
 import time
@@ -18,7 +19,7 @@ from mi3pt_host import capi, scenes  # noqa: E402
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 waves_per_cu = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 0: the library's choice
 w, h = 1920, 1080
-sc = scenes.demo_scene()
+sc = scenes.dragon_class_scene() if os.environ.get("WORKLOAD") == "dragon" else scenes.demo_scene()
 sc.build_bvh()
 ctx = capi.Context(0)
 if waves_per_cu:
@@ -26,6 +27,7 @@ if waves_per_cu:
     print("waves per CU:", waves_per_cu)
 pc.upload_scene(ctx, sc, scenes.synthetic_env())
 ctx.resize(w, h)
+ctx.enable_timing(True)
 ctx.set_uniforms(capi.PASS_FULLSCREEN, pc.fs_uniforms(w, h, 1.0, 1, 1).tobytes())
 RT_ACC = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
 
@@ -48,7 +50,10 @@ for name, batch, mask, sync_each, read_each in (
     ctx.set_option(capi.OPT_BATCH, batch)
     loop(mask, sync_each, read_each, 2)
     ctx.reset_counters()
+    ctx.raytrace_launch_stats(reset=True)
     t0 = time.perf_counter()
     loop(mask, sync_each, read_each, 2 + frames)
     dt = time.perf_counter() - t0
-    print(f"{name:42s} {dt / frames * 1e3:7.4f} ms per frame  {ctx.counters()['rays'] / dt / 1e6:8.1f} Mrays/s")
+    ms, launches, nf = ctx.raytrace_launch_stats()
+    print(f"{name:42s} {dt / frames * 1e3:7.4f} ms per frame  {ctx.counters()['rays'] / dt / 1e6:8.1f} Mrays/s   raytrace launches: {launches} of {nf / max(launches, 1):.1f} frames, "
+          f"{ms / max(launches, 1):.4f} ms each on the GPU clock; waves {ctx.last_launch()['workgroups']}")

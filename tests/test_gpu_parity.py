@@ -689,6 +689,8 @@ def test_walk_probe_reports_the_same_hits(gpu_ctx, demo, env):
     """mi3pt_debug_walk_probe (the walk-only occupancy experiment of profiles/walk_probe.py) must
     find the hits raySceneIntersect finds, at every occupancy it offers."""
     ctx = gpu_ctx
+    if not hasattr(ctx.lib, "mi3pt_debug_walk_probe"):
+        pytest.skip("mi3pt_debug_walk_probe: experiment build only")
     pc.upload_scene(ctx, demo, env)
     rays = _random_rays(np.random.default_rng(21), 50000)
     ref = ctx.debug_intersect(rays)

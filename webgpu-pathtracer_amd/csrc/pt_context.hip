@@ -2529,6 +2529,7 @@ extern "C" int mi3pt_device_build_bvh(mi3pt_ctx *ctx, void *nodes_out, size_t no
     return MI3PT_OK;
 }
 
+#ifdef MI3PT_EXPERIMENTS
 extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t n, int waves_per_simd, int repeats, int passes,
                                       float *out_tuvi, float *ms_out)
 {
@@ -2574,6 +2575,7 @@ extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t 
     *ms_out = best_ms;
     return MI3PT_OK;
 }
+#endif      // MI3PT_EXPERIMENTS
 
 extern "C" int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n)
 {

@@ -259,8 +259,10 @@ void launch_fullscreen(const FsUniforms &fs, const float4 *tex, int tex_w, int t
 void launch_debug_intersect(const SceneRefs &scene, const float *rays, size_t n, float *out, int variant,
                             hipStream_t s);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s);
+#ifdef MI3PT_EXPERIMENTS
 int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, uint32_t total, uint32_t *counter, float4 *out, int waves_per_simd,
                       int lcap, int leaf_min, int num_cus, hipStream_t s);
+#endif
 int raytrace_grid_blocks(const Tile &tile);
 int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned = false);
 // packs the three position vectors of `ntris` 112-byte triangle records into 48-byte rows (the context's cull analysis)

@@ -2318,6 +2318,7 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
         //                               DEFER  CULL   WIDE   FILT   YMAX   DIAG
 #ifdef MI3PT_EXPERIMENTS
         if (r.lean && L.wave_times && L.diag_lite && r.variant >= 10) switch (r.variant) {      // the lean build + lane counts
+            case 13: if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, false, true, true); else PT_SM(true, true, true, true, false, false, false, true, true); break;
             case 12: PT_SM(true,  true,  true,  true,  true,  false, false, true); break;
             case 11: PT_SM(true,  true,  true,  true,  false, false, false, true); break;
             default: PT_SM(true,  true,  true,  false, false, false, false, true); break;
@@ -2861,6 +2862,7 @@ __global__ void __launch_bounds__(256) k_debug_math(int fn, const float *__restr
     out[i] = r;
 }
 
+#ifdef MI3PT_EXPERIMENTS
 // ---------------------------------------------------------------------------------
 // Experiment kernel: the deferred-leaf walk ALONE (no shading, no camera) over a given list of
 // rays, as a persistent kernel at a chosen occupancy.  It answers one design question -- how
@@ -2987,6 +2989,7 @@ int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, ui
     default: return 0;
     }
 }
+#endif      // MI3PT_EXPERIMENTS (walk probe)
 
 __global__ void __launch_bounds__(256) k_patch_cull(float4 *__restrict__ packets, const uint32_t *__restrict__ cull, uint32_t n)
 {

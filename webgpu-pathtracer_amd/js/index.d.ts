@@ -77,7 +77,7 @@ export interface RendererOptions {
   device?: number;
   enableTimestampQuery?: boolean;
   presentEveryFrame?: boolean;
-  /** default true: draw the canvas once per launched batch instead of once per render() (headless) */
+  /** default false: the reference's canvas semantics (a fullscreen pass per render()); true: draw the canvas once per launched batch (headless programs that only read the final canvas) */
   presentLatest?: boolean;
   verbose?: boolean;
   builderThreads?: number;

@@ -31,12 +31,14 @@ class Renderer {
     this.native = args.native;
     this.handle = args.handle;
     // presentEveryFrame: encode the fullscreen pass on every render() like renderer.ts:386 (false: never).
-    // presentLatest (headless default): a sample frame that also presents is queued like any other and
-    // the canvas is drawn once per launched batch (MI3PT_PRESENT_LATEST); reading the canvas, or a
-    // render() after sampling has stopped, shows every frame.  false = every render() gets its own accumulate and
-    // fullscreen pass, the canvas drawn from this very frame (MI3PT_PRESENT_EXACT: 2.5x the time per frame).
+    // presentLatest: false (the default since round 4: the reference's canvas semantics, renderer.ts:379-390) -- every render()
+    // gets its own accumulate and fullscreen pass and the canvas is drawn from the mean up to and including this very frame
+    // (MI3PT_PRESENT_EXACT; up to 16 such frames share one raytrace launch, every canvas the reference would draw is drawn).
+    // true (a headless program that only reads the final canvas): a sample frame that also presents is queued like any other
+    // and the canvas is drawn once per launched batch (MI3PT_PRESENT_LATEST: 2.4x the frame rate); reading the canvas, or a
+    // render() after sampling has stopped, shows every frame.
     this.options = Object.assign({ enableTimestampQuery: false, verbose: false, presentEveryFrame: true,
-      presentLatest: true }, args.options || {});
+      presentLatest: false }, args.options || {});
     this.native.setPresentMode(this.handle, this.options.presentLatest ? 1 : 0);
     this._width = 0;
     this._height = 0;

@@ -37,7 +37,7 @@ SYMBOLS = (
     "mi3pt_write_texture",
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
-    "mi3pt_set_env_sampling", "mi3pt_debug_walk_probe", "mi3pt_device_build_bvh",
+    "mi3pt_set_env_sampling", "mi3pt_device_build_bvh",
     "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_debug_active_variant", "mi3pt_debug_last_launch", "mi3pt_set_rows", "mi3pt_measure_tile_cost", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf", "mi3pt_debug_set_option", "mi3pt_debug_get_option",
@@ -113,7 +113,8 @@ def load_library(path=None):
     lib.mi3pt_debug_intersect.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.mi3pt_debug_math.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t]
     lib.mi3pt_device_build_bvh.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
-    lib.mi3pt_debug_walk_probe.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p]
+    if hasattr(lib, "mi3pt_debug_walk_probe"):        # (the experiment build only)
+        lib.mi3pt_debug_walk_probe.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.mi3pt_debug_wave_times.argtypes = [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]
     lib.mi3pt_host_build_bvh.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
     lib.mi3pt_host_build_bvh_f64.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
@@ -437,7 +438,9 @@ class Context:
         return nodes[: n.value], ms.value
 
     def walk_probe(self, rays, waves_per_simd, repeats=3, want_hits=False, passes=1):
-        """Walk-only occupancy experiment (mi3pt_debug_walk_probe): returns (ms, hits or None)."""
+        """Walk-only occupancy experiment (mi3pt_debug_walk_probe; the experiment build of the library only): returns (ms, hits or None)."""
+        if not hasattr(self.lib, "mi3pt_debug_walk_probe"):
+            raise Mi3ptError(2, "mi3pt_debug_walk_probe exists in the experiment build only: make -C webgpu-pathtracer_amd/csrc experiments")
         r = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         out = np.zeros((len(r), 4), np.float32) if want_hits else None
         ms = ctypes.c_float()

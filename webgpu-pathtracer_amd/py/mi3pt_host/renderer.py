@@ -175,9 +175,11 @@ class Renderer:
 
     def __init__(self, ctx, options=None):
         self.ctx = ctx
-        # presentLatest (headless default): the canvas is drawn once per launched batch instead of once
-        # per render(); reading it, or a render() after sampling stopped, shows every frame
-        self.options = {"enableTimestampQuery": False, "presentLatest": True}
+        # presentLatest False (the default since round 4): the reference's canvas semantics -- every render() that presents gets
+        # its own accumulate and fullscreen pass (renderer.ts:379-390).  True (a headless program that only reads the final
+        # canvas): the canvas is drawn once per launched batch instead of once per render(); reading it, or a render() after
+        # sampling stopped, shows every frame
+        self.options = {"enableTimestampQuery": False, "presentLatest": False}
         self.options.update(options or {})
         ctx.set_present_mode(capi.PRESENT_LATEST if self.options["presentLatest"] else capi.PRESENT_EXACT)
         self._width = self._height = 0
