@@ -509,7 +509,7 @@ def main():
             accum = torch.zeros((ctx.local_rows, width, 4), dtype=torch.float32, device="cuda")
             torch.cuda.synchronize()           # (the fill ran on torch's stream, the passes run on the context's)
             ctx.bind_accumulation(accum.data_ptr(), accum.numel() * 4)
-        max_rows = capi.tile_local_rows(height, 0, tile_world, BLOCK_ROWS)
+        max_rows = max(capi.tile_local_rows(height, r, tile_world, BLOCK_ROWS) for r in range(tile_world))      # (the deal goes back and forth: rank 0 need not hold the most rows)
         send = gathered = None
         ev_g0, ev_g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if world > 1 and gather:

@@ -156,9 +156,11 @@ int mi3pt_group_member(mi3pt_ctx *ctx, int index, mi3pt_ctx **member);
 int mi3pt_set_stream(mi3pt_ctx *ctx, void *hip_stream);
 int mi3pt_set_storage(mi3pt_ctx *ctx, int storage /* mi3pt_storage */);
 
-/* Tile split (multi-GPU): this context renders only the rows y with
- * (y / block_rows) % nranks == rank; its textures are compact local_rows x width
- * images.  Default rank 0 of 1.  Takes effect at the next mi3pt_resize(). */
+/* Tile split (multi-GPU): the image's rows are dealt to the ranks in blocks of block_rows, round after round, BACK AND
+ * FORTH: with gb = y / block_rows, round = gb / nranks, pos = gb % nranks this context renders the rows whose
+ * (round odd ? nranks - 1 - pos : pos) == rank -- a cost that rises or falls down the image (floor, model, sky) is shared out
+ * evenly (dealt one way only, rank 0 of eight had 5 % more work than rank 6).  Its textures are compact local_rows x width images,
+ * rows in image order.  Default rank 0 of 1.  Takes effect at the next mi3pt_resize(). */
 int mi3pt_set_tile(mi3pt_ctx *ctx, int rank, int nranks, int block_rows);
 int mi3pt_tile_local_rows(int height, int rank, int nranks, int block_rows); /* returns the count */
 /* The other split: this context renders the CONTIGUOUS band of rows [first_row, first_row + nrows) of the image (clipped to

@@ -455,15 +455,15 @@ static void raytrace_pixel(const orc_scene *sc, const rt_uniforms *un, uint32_t 
  * rows are dealt to ranks in blocks of `block_rows`, round robin. */
 static inline int local_to_global_row(int ly, int rank, int nranks, int block_rows)
 {
-    int b = ly / block_rows;
-    return (b * nranks + rank) * block_rows + (ly % block_rows);
+    int b = ly / block_rows;      /* rounds of the deal go back and forth (include/mi3pt.h, mi3pt_set_tile) */
+    return (b * nranks + ((b & 1) ? nranks - 1 - rank : rank)) * block_rows + (ly % block_rows);
 }
 
 int orc_tile_local_rows(int tex_h, int rank, int nranks, int block_rows)
 {
     int n = 0;
     for (int y = 0; y < tex_h; y++)
-        if ((y / block_rows) % nranks == rank) n++;
+        { int gb = y / block_rows, round = gb / nranks, pos = gb % nranks; if (((round & 1) ? nranks - 1 - pos : pos) == rank) n++; }
     return n;
 }
 

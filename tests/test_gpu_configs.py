@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import ptcommon as pc
-from mi3pt_host import capi, scenes
+from mi3pt_host import capi, tiles, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -98,7 +98,7 @@ def test_config4_dragon_dof_denoise_4k_tile_split(gpu_ctx, orc, dragon, env):
         ctx.set_tile(rank, 4, 8)
         ctx.resize(w, h)
         part, c = _render(ctx, dragon, w, h, frames, **kw)
-        rows = [y for y in range(h) if (y // 8) % 4 == rank]
+        rows = tiles.local_rows_of(h, rank, 4, 8)
         out[rows] = part
         rays += c["rays"]
     assert pc.same_bits(out, whole), pc.describe_diff(out, whole)
@@ -151,7 +151,7 @@ def test_config5_forest_10m_triangles_4k_tile_split_8(gpu_ctx, orc, forest, env)
         ctx.set_tile(rank, 8, 8)
         ctx.resize(w, h)
         part, c = _render(ctx, forest, w, h, frames)
-        out[[y for y in range(h) if (y // 8) % 8 == rank]] = part
+        out[tiles.local_rows_of(h, rank, 8, 8)] = part
         rays += c["rays"]
     assert pc.same_bits(out, whole), pc.describe_diff(out, whole)
     assert rays == cwhole["rays"]

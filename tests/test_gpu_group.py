@@ -105,7 +105,9 @@ def test_group_compiles_the_scene_once_and_gathers_through_the_host_when_it_must
         m5 = g.member(5)
         assert m5.local_rows == capi.tile_local_rows(h, 5, 8, 4)
         part = m5.read_texture(capi.TEX_ACCUMULATION)
-        rows = [b * 32 + 20 + r for b in range(h // 32 + 1) for r in range(4) if b * 32 + 20 + r < h]
+        from mi3pt_host import tiles
+        rows = tiles.local_rows_of(h, 5, 8, 4)              # (the deal goes back and forth: blocks 5, 8 + 2, 16 + 5, 24 + 2 of four rows)
+        assert rows[:8] == [20, 21, 22, 23, 40, 41, 42, 43]
         assert part.shape[0] == len(rows) and pc.same_bits(part, want[0][rows])
         # render on; gather staged through the host
         assert g.get_option(capi.OPT_GATHER_STAGED) == 0

@@ -626,7 +626,8 @@ def test_tile_split_reassembles_to_whole_image(gpu_ctx, orc, demo, env, nranks, 
         ctx.reset_counters()
         pc.gpu_frame(ctx, u, a, capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
         part = ctx.read_texture(capi.TEX_ACCUMULATION)
-        rows = [y for y in range(h) if (y // block_rows) % nranks == rank]
+        from mi3pt_host import tiles
+        rows = tiles.local_rows_of(h, rank, nranks, block_rows)
         assert part.shape[0] == len(rows)
         whole[rows] = part
         total_rays += ctx.counters()["rays"]

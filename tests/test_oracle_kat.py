@@ -379,7 +379,8 @@ def test_tile_split_matches_whole_image(orc, demo, env):
         rays = 0
         for rank in range(nranks):
             part, c = orc.raytrace(sc, u.tobytes(), w, h, rank, nranks, block)
-            rows = [y for y in range(h) if (y // block) % nranks == rank]
+            from mi3pt_host import tiles
+            rows = tiles.local_rows_of(h, rank, nranks, block)
             assert part.shape[0] == len(rows) == orc.tile_local_rows(h, rank, nranks, block)
             out[rows] = part
             rays += c["rays"]

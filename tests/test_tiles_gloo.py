@@ -42,7 +42,7 @@ def _worker(rank, world, port, w, h, block, outq):
     for frame in (2, 3):
         img, _ = orc.raytrace(osc, pc.rt_uniforms(sc, w, h, frame=frame, bounces=3).tobytes(), w, h, rank, world, block)
         acc = orc.accumulate(pc.acc_uniforms(w, h, frame).tobytes(), w, h, img, acc, rank, world, block)
-    max_rows = capi.tile_local_rows(h, 0, world, block)
+    max_rows = max(capi.tile_local_rows(h, r, world, block) for r in range(world))      # (the deal goes back and forth: rank 0 need not hold the most rows)
     send = torch.zeros((max_rows, w, 4))
     send[:rows] = torch.from_numpy(acc)
     gathered = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
@@ -82,7 +82,7 @@ def _gpu_worker(rank, world, port, w, h, block, frames, outq):
         pc.gpu_frame(ctx, pc.rt_uniforms(sc, w, h, frame=frame, bounces=5), pc.acc_uniforms(w, h, frame),
                      capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE)
     ctx.sync()
-    max_rows = capi.tile_local_rows(h, 0, world, block)
+    max_rows = max(capi.tile_local_rows(h, r, world, block) for r in range(world))      # (the deal goes back and forth: rank 0 need not hold the most rows)
     send = torch.zeros((max_rows, w, 4))
     send[: ctx.local_rows] = accum.cpu()
     gathered = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
@@ -157,7 +157,7 @@ def test_deinterleave_is_the_inverse_of_the_row_deal():
         for r in range(world):
             rows = local_rows_of(h, r, world, block)
             assert len(rows) == capi.tile_local_rows(h, r, world, block)
-            pad = np.zeros((capi.tile_local_rows(h, 0, world, block), w, 4), np.float32)
+            pad = np.zeros((max(capi.tile_local_rows(h, q, world, block) for q in range(world)), w, 4), np.float32)
             pad[:len(rows)] = img[rows]
             parts.append(pad)
         assert np.array_equal(deinterleave_rows(parts, h, world, block), img)

@@ -2751,6 +2751,13 @@ static int group_set_uniforms(mi3pt_ctx *g, int pass, const void *bytes, size_t 
     return group_each(g, false, [&](mi3pt_ctx *m) { return mi3pt_set_uniforms(m, pass, bytes, nbytes); });
 }
 
+// image row of local row `ly` of member i of n (mi3pt_set_tile's deal: rounds go back and forth)
+static size_t group_global_row(int ly, int i, int n, int br)
+{
+    const int b = ly / br;
+    return ((size_t)b * (size_t)n + (size_t)((b & 1) ? n - 1 - i : i)) * (size_t)br + (size_t)(ly % br);
+}
+
 // One scene buffer of `src` replicated into `dst` (another member, maybe another device): device to device, on dst's stream.
 static int clone_buffer(mi3pt_ctx *dst, void **dptr, const mi3pt_ctx *src, const void *sptr)
 {
@@ -2856,7 +2863,7 @@ static int gather_member(GroupState *gs, int i, bool direct)
     const int rows = m->local_rows;
     if (rows == 0) return MI3PT_OK;
     const int full = rows / br, tail = rows - full * br;      // whole blocks, rows of a last partial block (the image's bottom edge)
-    const size_t grow = ((size_t)full * (size_t)n + (size_t)i) * (size_t)br;      // global row of the partial block
+    const size_t grow = group_global_row(full * br, i, n, br);      // global row of the partial block
     if (tail > 0 && (int)grow + tail > H) return pt_set_error(MI3PT_ERR_STATE, "gather: tile geometry mismatch");
     hipMemcpyKind kind = hipMemcpyDeviceToDevice;
     if (!direct) {
@@ -2873,8 +2880,13 @@ static int gather_member(GroupState *gs, int i, bool direct)
         src = static_cast<const uint8_t *>(gs->stage);
         kind = hipMemcpyHostToDevice;
     }
-    if (full > 0)
-        HIP_TRY(hipMemcpy2DAsync(dst + (size_t)i * block_bytes, (size_t)n * block_bytes, src, block_bytes, block_bytes, (size_t)full, kind, p->stream));
+    // The deal goes back and forth: the member's even local blocks sit at image block (2 k n + i), its odd ones at
+    // ((2 k + 1) n + n - 1 - i) -- two strided sets, each ONE rect copy (source pitch = two blocks, destination pitch = 2 n blocks)
+    const int n_even = (full + 1) / 2, n_odd = full / 2;
+    if (n_even > 0)
+        HIP_TRY(hipMemcpy2DAsync(dst + (size_t)i * block_bytes, 2 * (size_t)n * block_bytes, src, 2 * block_bytes, block_bytes, (size_t)n_even, kind, p->stream));
+    if (n_odd > 0)
+        HIP_TRY(hipMemcpy2DAsync(dst + (size_t)(n + n - 1 - i) * block_bytes, 2 * (size_t)n * block_bytes, src + block_bytes, 2 * block_bytes, block_bytes, (size_t)n_odd, kind, p->stream));
     if (tail > 0)
         HIP_TRY(hipMemcpyAsync(dst + grow * row_bytes, src + (size_t)full * block_bytes, (size_t)tail * row_bytes, kind, p->stream));
     if (!direct) HIP_TRY(hipStreamSynchronize(p->stream));       // the staging buffer is free again
@@ -2954,7 +2966,7 @@ static int group_read_texture(mi3pt_ctx *g, int which, float *dst, size_t nfloat
         part.resize((size_t)m->local_rows * row);
         if (int rc = mi3pt_read_texture(m, which, part.data(), part.size())) return rc;
         for (int ly = 0; ly < m->local_rows; ly++) {
-            const size_t gy = ((size_t)(ly / br) * (size_t)n + (size_t)i) * (size_t)br + (size_t)(ly % br);
+            const size_t gy = group_global_row(ly, i, n, br);
             std::memcpy(dst + gy * row, part.data() + (size_t)ly * row, row * 4);
         }
     }
@@ -2974,7 +2986,7 @@ static int group_write_texture(mi3pt_ctx *g, int which, const float *src, size_t
         mi3pt_ctx *m = gs->members[(size_t)i];
         part.resize((size_t)m->local_rows * row);
         for (int ly = 0; ly < m->local_rows; ly++) {
-            const size_t gy = ((size_t)(ly / br) * (size_t)n + (size_t)i) * (size_t)br + (size_t)(ly % br);
+            const size_t gy = group_global_row(ly, i, n, br);
             std::memcpy(part.data() + (size_t)ly * row, src + gy * row, row * 4);
         }
         if (int rc = mi3pt_write_texture(m, which, part.data(), part.size())) return rc;

@@ -342,8 +342,12 @@ extern "C" int mi3pt_host_env_cdf(const float *rgba, int width, int height, floa
 extern "C" int mi3pt_tile_local_rows(int height, int rank, int nranks, int block_rows)
 {
     if (height < 0 || nranks <= 0 || rank < 0 || rank >= nranks || block_rows <= 0) return -1;
+    // rounds of the deal go back and forth: rank r owns block r of even rounds and block nranks - 1 - r of odd ones
+    // (include/mi3pt.h, mi3pt_set_tile)
     int n = 0;
-    for (int y = 0; y < height; y++)
-        if ((y / block_rows) % nranks == rank) n++;
+    for (int y = 0; y < height; y++) {
+        const int gb = y / block_rows, round = gb / nranks, pos = gb % nranks;
+        if (((round & 1) ? nranks - 1 - pos : pos) == rank) n++;
+    }
     return n;
 }

@@ -1,5 +1,6 @@
 """Image tile split across ranks: rows are dealt to ranks in blocks of
-`block_rows`, round robin; every rank keeps a compact [local_rows, width, 4] image.  The
+`block_rows`, round after round, back and forth (rank r owns block r of even rounds and block nranks - 1 - r of odd ones: a cost
+that rises or falls down the image is shared out evenly); every rank keeps a compact [local_rows, width, 4] image.  The
 seed of a pixel depends only on its GLOBAL index and the frame (raytrace.wgsl:435-436),
 so any split renders identical pixels; one gather of the HDR accumulation buffers plus
 this de-interleave reassembles the picture."""
@@ -8,7 +9,11 @@ import numpy as np
 
 def local_rows_of(height, rank, nranks, block_rows):
     """Global row indices held by `rank`, in local order."""
-    return [y for y in range(height) if (y // block_rows) % nranks == rank]
+    def owner(y):
+        gb = y // block_rows
+        rnd, pos = divmod(gb, nranks)
+        return nranks - 1 - pos if rnd & 1 else pos
+    return [y for y in range(height) if owner(y) == rank]
 
 
 def deinterleave_rows(parts, height, nranks, block_rows):
