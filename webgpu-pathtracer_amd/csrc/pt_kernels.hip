@@ -11,19 +11,25 @@
 //       VARIANT 1 walks the uploaded 48-B node records exactly like the WGSL,
 //       VARIANT 2 walks 64-B node packets (both child boxes in one line) and 48-B
 //       triangle packets -- same tests in the same order, a third of the loads.
-//       Kept as the on-device references of the parity tests (kernel variants 1 and 2).
-//   k_raytrace_persistent      variant 3: persistent waves with lane refill only
-//   k_raytrace_sm<FUSE, TOPLDS, DEFER, CULL, WIDE>
+//       The on-device references of the parity tests (kernel variants 1 and 2), and the fall-back
+//       for launches beyond the state-machine kernel's packing limits.
+//   k_raytrace_sm<DEFER, CULL, WIDE, FILT, YMAX, DIAG, TOPLDS, LITE, CW>
 //       the shipped kernel: persistent one-wave workgroups, per-lane state machine with node /
 //       triangle / service steps (the service step split into a hit-shading and a miss / path
-//       group), (frame slot, tile) jobs from a self-cleaning queue;
-//       DEFER = leaves parked and tested in steps of their own (variant 7: exactly the reference's
-//       tests), !DEFER = in-order walk (variant 4; 5 = other walk threshold),
-//       CULL = DEFER + exact-image distance culling, children near first (variant 9),
-//       WIDE = CULL on 4-ary wide packets (variant 10, the default when the tree allows it),
-//       TOPLDS = top of the tree staged in LDS (variants 6 and 8, measured no faster)
+//       group), (frame slot, tile) jobs from a self-cleaning queue; one packed per-lane state for
+//       every launch (texel index, frame slot | bounce; a multi-sample frame's sum lives in the texel);
+//       !DEFER = in-order walk (variant 4), DEFER = leaves parked and tested in steps of their own
+//       (variant 7: exactly the reference's tests), CULL = DEFER + exact-image distance culling,
+//       children near first (variant 9), WIDE = CULL on 4-ary wide packets (variant 10), FILT = the
+//       filtered slab test (11), YMAX = the one-axis culling condition (12), CW = compressed wide
+//       packets + 64-B triangle records with the leaf's box (13: the default where the tree admits it);
+//       DIAG = false: the lean build every ordinary launch runs (80 - 96 VGPRs, five waves per SIMD),
+//       true: the diagnostic twin (step statistics, clock stamps, step-voting options at run time);
+//       TOPLDS / LITE and k_raytrace_persistent (variant 3): experiment builds only
+//   k_rt_service_setup         the launch-invariant scalars of the service step, one block per launch
 //   k_accumulate[_batch]       accumulate.wgsl computeMain (one frame / an ordered batch of frames)
-//   k_fullscreen               fullscreen.wgsl fragmentMain (de-noise + tone-map)
+//   k_fullscreen[_setup]       fullscreen.wgsl fragmentMain (de-noise + tone-map) and its tap table
+//   k_pack_vertices, k_patch_cull   helpers of the context's cull analysis
 //   k_debug_intersect/_math    component probes for the parity tests
 #include "pt_kernels.h"
 #include "pt_devmath.h"
