@@ -109,7 +109,7 @@ def check_counters(cnt, want, culled=False, what=""):
 
 
 def set_variant_or_skip(ctx, variant):
-    """Kernel variants 3, 5, 6 and 8 (measured, not adopted) only exist in the experiment build of the library
+    """Kernel variants 3, 5, 6, 8 (measured, not adopted) and 11, 12 (superseded by 13) only exist in the experiment build of the library
     (`make -C webgpu-pathtracer_amd/csrc experiments`, loaded through MI3PT_LIBRARY): a release library refuses them."""
     import pytest
     from mi3pt_host import capi

@@ -199,7 +199,7 @@ def test_config2_demo_1080p_64spp(gpu_ctx, demo, env):
     got, cgot = _render_spp(ctx, demo, w, h, spp)
     assert ctx.active_variant() == 13          # the shipped choice: compressed wide packets (round 4) wherever the tree admits them
     _same_job(got, cgot, ref, cref, spp * w * h)
-    for v in (10, 11, 12):                     # (10: what `auto` picked among the exact-packet walks for this scene -- short walks, thin floor leaves)
+    for v in pc.variants_available(ctx, (10, 11, 12)):                     # (10: what `auto` picked among the exact-packet walks for this scene -- short walks, thin floor leaves)
         a, ca = _render_spp(ctx, demo, w, h, spp, variant=v)
         _same_job(a, ca, ref, cref, spp * w * h)
     ctx.resize(64, 64)
@@ -217,7 +217,7 @@ def test_config3_dragon_class_1080p_256spp(gpu_ctx, dragon, env):
     assert ctx.active_variant() == 13          # the shipped choice: compressed wide packets, one-axis culling condition (this scene's hint)
     _same_job(got, cgot, ref, cref, spp * w * h)
     assert cgot["tri_tests"] <= cref["tri_tests"]
-    for v in (10, 11, 12):                     # ... and the exact-packet wide walks, on a shorter job
+    for v in pc.variants_available(ctx, (10, 11, 12)):                     # ... and the exact-packet wide walks, on a shorter job
         a, ca = _render_spp(ctx, dragon, w, h, 16, variant=v)
         b, cb = _render_spp(ctx, dragon, w, h, 16)
         _same_job(a, ca, b, cb, 16 * w * h)

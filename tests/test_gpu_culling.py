@@ -64,7 +64,7 @@ def test_soups_culled_walk_is_bit_identical(gpu_ctx, env, name):
     for cam in ((0.0, 0.3, 2.5), (0.05, 0.02, 0.1), (3.0, 0.0, 0.0)):         # outside, inside the cloud, from the side
         kw = dict(position=cam, direction=tuple(-np.array(cam) / np.linalg.norm(cam)))
         ref, cref = _render(ctx, sc, w, h, (2, 3), variant=2, **kw)
-        for variant in (9, 10, 11, 12, 13):
+        for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
             ctx.set_kernel_variant(variant)
             assert ctx.active_variant() == variant
             got, cgot = _render(ctx, sc, w, h, (2, 3), variant=variant, **kw)
@@ -94,7 +94,7 @@ def test_grazing_views_over_a_tessellated_floor(gpu_ctx, env):
         cam = (0.0, height, 3.9)
         kw = dict(position=cam, direction=(0.0, 0.0, -1.0), fov=60.0)
         ref, cref = _render(ctx, sc, w, h, (2, 3, 4), variant=7, **kw)
-        for variant in (9, 10, 11, 12, 13):
+        for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
             got, cgot = _render(ctx, sc, w, h, (2, 3, 4), variant=variant, **kw)
             assert pc.same_bits(got, ref), f"camera height {height} variant {variant}: " + pc.describe_diff(got, ref)
             pc.check_counters(cgot, cref, culled=True, what=f"height {height}")
@@ -123,7 +123,7 @@ def test_boxes_that_do_not_bound_their_triangles_are_never_skipped(gpu_ctx, orc,
     ctx.resize(w, h)
     u = pc.rt_uniforms(demo, w, h, frame=2, bounces=6)
     want, ocnt = orc.raytrace(orc.OracleScene(demo.triangles, demo.material_bytes, broken, env), u.tobytes(), w, h)
-    for variant in (9, 10, 11, 12, 13):              # (10: a node whose box does not hold its children is not absorbed into a wide packet)
+    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):              # (10: a node whose box does not hold its children is not absorbed into a wide packet)
         ctx.set_kernel_variant(variant)
         ctx.reset_counters()
         pc.gpu_frame(ctx, u)
@@ -196,7 +196,7 @@ def test_node_stack_beyond_its_lds_part(gpu_ctx, orc, env):
     want, ocnt = orc.raytrace(orc.OracleScene(tris, mats, nodes, env), u.tobytes(), w, h)
     assert ocnt["stack_overflows"] == 0 and 0 < ocnt["hits"] < ocnt["rays"]
     assert ocnt["box_tests"] > 100 * ocnt["rays"]             # every ray enters (almost) every box
-    for variant in (9, 10, 11, 12, 13):
+    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
         ctx.set_kernel_variant(variant)
         assert ctx.active_variant() == variant            # no silent fall-back: this tree admits both walks
         ctx.reset_counters()
@@ -215,7 +215,7 @@ def test_demo_scene_1080p_and_the_share_of_boxes_skipped(gpu_ctx, demo, env):
     w, h = 1920, 1080
     ctx.resize(w, h)
     ref, cref = _render(ctx, demo, w, h, range(2, 8), variant=7)
-    for variant in (9, 10, 11, 12, 13):
+    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
         got, cgot = _render(ctx, demo, w, h, range(2, 8), variant=variant)
         assert pc.same_bits(got, ref), pc.describe_diff(got, ref)
         pc.check_counters(cgot, cref, culled=True)
@@ -249,7 +249,7 @@ def test_nan_rays_take_the_known_answer(gpu_ctx, orc, demo, env):
     ref, cref = _render(ctx, sc, w, h, frames, 2, bounces=4)
     assert pc.same_bits(ref, acc), pc.describe_diff(ref, acc)
     assert cref["rays"] == orays
-    for variant in (9, 10, 11, 12, 13):
+    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
         got, cgot = _render(ctx, sc, w, h, frames, variant, bounces=4)
         assert ctx.active_variant() in (variant, 10, 11, 12, 13)
         assert pc.same_bits(got, acc), pc.describe_diff(got, acc)

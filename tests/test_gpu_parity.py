@@ -470,7 +470,7 @@ def test_every_reference_setting_runs_the_lean_kernel(gpu_ctx, orc, demo, env, v
     osc = pc.oracle_scene(orc, demo, env)
     mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
     try:
-        ctx.set_kernel_variant(variant)
+        pc.set_variant_or_skip(ctx, variant)
         want_variant = ctx.active_variant()
         assert want_variant >= 4
         if variant:
@@ -1071,7 +1071,7 @@ def test_tuned_and_diagnostic_twins_render_the_same_bits(gpu_ctx, demo, env, sto
 
     try:
         ref, cref = job(2)                      # per-pixel kernel, the WGSL control flow
-        for variant in (9, 10, 11, 12, 13):
+        for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
             tuned, ct = job(variant)
             ctx.enable_wave_times(True)
             try:

@@ -153,7 +153,7 @@ struct mi3pt_ctx {
     int tail_policy = PT_DEFAULT_TAIL_POLICY;        // MI3PT_TAIL_POLICY: see RtLaunch::tail_policy
     int shade_split = PT_DEFAULT_SHADE_SPLIT;       // MI3PT_SHADE_SPLIT: see RtLaunch::shade_split (64: while lanes walk, only the larger group is served)
     int leaf_min = PT_DEFAULT_LEAF_MIN;          // deferred-leaf walk: lanes with a parked leaf that trigger a triangle step (MI3PT_LEAF_MIN)
-    int walk_min = PT_DEFAULT_WALK_MIN;          // tuning knobs of the persistent kernels (MI3PT_WALK_MIN / MI3PT_WAVES_PER_CU)
+    int walk_min = 0;           // MI3PT_OPT_WALK_MIN: walk while at least this many lanes walk; 0 = by the size of the tree (build_launch)
     int waves_per_cu = 0;       // one-wave workgroups per compute unit; 0 = what the kernel instantiation is compiled for (pt_kernels.h: 20 / 16)
     int top_packets = 64;       // MI3PT_TOP_PACKETS
 
@@ -520,8 +520,8 @@ extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
     if (variant < 0 || variant > 13) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..13");
 #ifndef MI3PT_EXPERIMENTS
-    if (variant == 3 || variant == 5 || variant == 6 || variant == 8)
-        return pt_set_error(MI3PT_ERR_INVALID, "kernel variants 3, 5, 6 and 8 (measured, not adopted) exist in the experiment build only: make -C webgpu-pathtracer_amd/csrc experiments");
+    if (variant == 3 || variant == 5 || variant == 6 || variant == 8 || variant == 11 || variant == 12)
+        return pt_set_error(MI3PT_ERR_INVALID, "kernel variants 3, 5, 6, 8 (measured, not adopted) and 11, 12 (superseded by 13) exist in the experiment build only: make -C webgpu-pathtracer_amd/csrc experiments");
 #endif
     if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
@@ -1672,6 +1672,18 @@ extern "C" int mi3pt_set_present_mode(mi3pt_ctx *ctx, int mode)
     return MI3PT_OK;
 }
 
+// the exact-packet wide walk `auto` falls back to where compressed packets could not be built: 10, 11 or 12 by the scene's statistics
+// in the experiment build; release builds carry 10 only (11 / 12 were superseded by 13; all of them render the same bits)
+static int auto_exact_wide(const mi3pt_ctx *ctx)
+{
+#ifdef MI3PT_EXPERIMENTS
+    return ctx->auto_wide_variant;
+#else
+    (void)ctx;
+    return 10;
+#endif
+}
+
 // 0 = auto -> the persistent kernel; the probes only know the two per-ray walks.
 static int pick_variant(const mi3pt_ctx *ctx)
 {
@@ -1687,8 +1699,8 @@ static int pick_variant(const mi3pt_ctx *ctx)
     // up +7 %, its stated view +0.5 %, the demo scene +-0 (profiles/r04_g_cwide_ab.log); 10 / 11 / 12 stay for the trees that do not
     // admit it and as the diagnostic twin's walk
     if (ctx->variant == 0)
-        return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? (ctx->cwide_ok ? 13 : ctx->auto_wide_variant) : 9) : (defer_ok ? 7 : 4);
-    if (ctx->variant == 13 && !(wide_ok && ctx->cwide_ok)) return wide_ok ? ctx->auto_wide_variant : (cull_ok ? 9 : (defer_ok ? 7 : 4));
+        return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? (ctx->cwide_ok ? 13 : auto_exact_wide(ctx)) : 9) : (defer_ok ? 7 : 4);
+    if (ctx->variant == 13 && !(wide_ok && ctx->cwide_ok)) return wide_ok ? auto_exact_wide(ctx) : (cull_ok ? 9 : (defer_ok ? 7 : 4));
     if (ctx->variant >= 10 && ctx->variant <= 12 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);
     if (ctx->variant == 9 && !cull_ok) return defer_ok ? 7 : 4;
     if ((ctx->variant == 7 || ctx->variant == 8) && !defer_ok) return ctx->variant == 8 ? 6 : 4;
@@ -1739,7 +1751,13 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.diag_lite = ctx->diag_lite;
     L.stack_overflow = ctx->d_stack_overflow;
     L.store_f16 = ctx->storage == MI3PT_STORAGE_F16;
-    L.walk_min = ctx->variant == 5 ? 48 : ctx->walk_min;
+    // walk_min: deep walks gain from a higher threshold -- more node steps between two service steps -- short ones lose
+    // (profiles/r04_o_walkmin.log, 32 / 40 / 44 / 48: forest 1 678 / 1 756 / 1 792 / 1 806 Mrays/s, the 870 k-triangle scene from
+    // close up 5 484 / 5 589 / 5 600 / 5 495, its stated view 16 110 / 16 000 / 15 930 / 15 690, demo 25 500 / 25 350 / 24 270 / 23 560):
+    // 44 for trees of a million wide packets and more (deep walks from every camera) on compressed packets, 32 otherwise -- both
+    // compile-time constants of their lean builds (as a launch parameter the threshold cost the other scenes 0.8 .. 1.5 %)
+    L.walk_min = ctx->variant == 5 ? 48 : (ctx->walk_min > 0 ? ctx->walk_min
+                                           : (ctx->nwide >= (1u << 20) && ctx->wide_ok && ctx->cwide_ok && pick_variant(ctx) == 13 ? PT_DEEP_WALK_MIN : PT_DEFAULT_WALK_MIN));
     L.leaf_min = ctx->leaf_min;
     L.shade_split = ctx->shade_split;
     L.tail_policy = ctx->tail_policy;

@@ -184,6 +184,9 @@ struct Tile {
 #ifndef PT_DEFAULT_WALK_MIN
 #define PT_DEFAULT_WALK_MIN 32
 #endif
+#ifndef PT_DEEP_WALK_MIN
+#define PT_DEEP_WALK_MIN 44        // walk_min for the deep walks of very large trees (the compressed-wide walk's second instantiation)
+#endif
 #ifndef PT_DEFAULT_LEAF_MIN
 #define PT_DEFAULT_LEAF_MIN 24
 #endif

@@ -1244,7 +1244,10 @@ PT_DEV T uniform_block(const T &v)
 // the lean build plus the wave-uniform lane counts per kind of step (scalar registers) and two clock reads, written once at exit
 // -- how many lanes each kind of step serves in the kernel that ships, not in its four-wave diagnostic twin (round-3 verdict).
 // CW (with WIDE): the walk on compressed wide packets and 64-byte triangle records (variant 13; cwide_hit above).
-template <bool DEFER, bool CULL, bool WIDE, bool FILT, bool YMAX, bool DIAG, bool TOPLDS = false, bool LITE = false, bool CW = false>
+// WMIN: the lean build's walk_min (a constant there: as a launch parameter in a scalar register it cost the 870 k-triangle scene 0.8 %
+// and the demo scene 1.5 %, profiles/r04_o_walkmin2.log): 32, or 44 for the deep walks of very large trees (compressed packets only).
+template <bool DEFER, bool CULL, bool WIDE, bool FILT, bool YMAX, bool DIAG, bool TOPLDS = false, bool LITE = false, bool CW = false,
+          int WMIN = PT_DEFAULT_WALK_MIN>
 __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_WAVES_PER_SIMD) k_raytrace_sm(const RtLaunch L)
 {
     static_assert(!CULL || DEFER, "the culling walks park their leaves");
@@ -1254,7 +1257,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     uint64_t *const wave_times = DIAG ? L.wave_times : nullptr;
     const bool count_on = DIAG ? wave_times != nullptr : LITE;        // the step / lane counts (LITE: always; the lean build: never)
     // ... and the step-voting knobs are the defaults as constants (launch_raytrace sends any other setting to the DIAG twin)
-    const int k_walk_min = DIAG ? L.walk_min : PT_DEFAULT_WALK_MIN, k_leaf_min = DIAG ? L.leaf_min : PT_DEFAULT_LEAF_MIN;
+    const int k_walk_min = DIAG ? L.walk_min : WMIN, k_leaf_min = DIAG ? L.leaf_min : PT_DEFAULT_LEAF_MIN;
     const int k_shade_split = DIAG ? L.shade_split : PT_DEFAULT_SHADE_SPLIT, k_tail_policy = DIAG ? L.tail_policy : PT_DEFAULT_TAIL_POLICY;
     const int k_job_chunk = DIAG ? L.job_chunk : PT_DEFAULT_JOB_CHUNK;
     const bool k_tri_pair = DIAG ? L.tri_pair != 0 : !PT_CW_NO_PAIR_TEST;
@@ -2243,7 +2246,7 @@ static bool launch_packs(const RtLaunch &L)
 // memory) runs unless a diagnostic buffer is bound or a step-voting option was changed (mi3pt_debug_set_option).
 static bool launch_is_lean(const RtLaunch &L)
 {
-    return (!L.wave_times || L.diag_lite) && !L.tile_cost && L.walk_min == PT_DEFAULT_WALK_MIN && L.leaf_min == PT_DEFAULT_LEAF_MIN && L.shade_split == PT_DEFAULT_SHADE_SPLIT &&
+    return (!L.wave_times || L.diag_lite) && !L.tile_cost && (L.walk_min == PT_DEFAULT_WALK_MIN || L.walk_min == PT_DEEP_WALK_MIN) && L.leaf_min == PT_DEFAULT_LEAF_MIN && L.shade_split == PT_DEFAULT_SHADE_SPLIT &&
            L.tail_policy == PT_DEFAULT_TAIL_POLICY && L.job_chunk == PT_DEFAULT_JOB_CHUNK && L.tri_pair == 1 && L.service != nullptr;
 }
 // What the lean builds of the culling walks have as constants (ASSUME in the kernel): a scene with nodes whose root is an
@@ -2273,6 +2276,10 @@ static RtRoute route_launch(const RtLaunch &L, int variant)
     r.kind = 1;
     r.lean = launch_is_lean(L);
     if (variant == 13 && !(L.scene.cwide && L.scene.tripk64)) variant = 10;
+    if (L.walk_min == PT_DEEP_WALK_MIN && variant != 13) r.lean = false;        // (the deep-walk threshold is instantiated for the compressed-wide walk only)
+#ifndef MI3PT_EXPERIMENTS
+    if (variant == 11 || variant == 12) variant = 10;       // (release builds: superseded by 13; the exact-packet walk with the exact slab test stands in -- same bits)
+#endif
     if (variant >= 9 && variant <= 13 && r.lean && !launch_assumptions_hold(L)) variant = L.scene.leaf_cap >= 4 ? 7 : 4;
     if (variant >= 10 && variant <= 13 && !r.lean) variant = 10;      // the diagnostic twin of the wide walks runs the exact slab test: same bits
 #ifndef MI3PT_EXPERIMENTS
@@ -2337,12 +2344,19 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
         } else
 #endif
         if (r.lean && r.variant == 13) {        // compressed wide packets (SceneRefs::flags bit 2: the one-axis culling condition suits this scene)
-            if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, false, false, true);
-            else PT_SM(true, true, true, true, false, false, false, false, true);
+            if (L.walk_min == PT_DEEP_WALK_MIN) {
+                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, false, false, true, PT_DEEP_WALK_MIN);
+                else PT_SM(true, true, true, true, false, false, false, false, true, PT_DEEP_WALK_MIN);
+            } else {
+                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, false, false, true);
+                else PT_SM(true, true, true, true, false, false, false, false, true);
+            }
         } else
         if (r.lean) switch (r.variant) {
+#ifdef MI3PT_EXPERIMENTS
             case 12: PT_SM(true,  true,  true,  true,  true,  false); break;
             case 11: PT_SM(true,  true,  true,  true,  false, false); break;
+#endif
             case 10: PT_SM(true,  true,  true,  false, false, false); break;
             case 9:  PT_SM(true,  true,  false, false, false, false); break;
             case 7:  PT_SM(true,  false, false, false, false, false); break;
