@@ -324,7 +324,10 @@ typedef enum mi3pt_option {
                                    * path the gather takes where peer access is unavailable or a direct copy failed (forced: tests) */
     MI3PT_OPT_COST_ORDER = 17  /* a launch's jobs in the order of the tiles' measured cost, costliest first: one launch adds up the path
                                 * segments per 8x8 tile, later launches with the same uniforms run the
-                                * cheapest quarter of the tiles last (0: measured +0.3 % on one GPU, -1.6 ... -4 % for a rank of a tile split) */
+                                * cheapest quarter of the tiles last (1), or every tile costliest first (2).  Default 0: measured +0.3 % on
+                                * one GPU and -1.6 ... -4 % for a rank of a tile split in batched launches; 2 is for hosts that launch
+                                * and wait frame by frame: 1.29 -> 1.205 ms per 1080p frame of the 870 k-triangle scene, the demo
+                                * scene +-0 (profiles/r04_r_interactive_cost_order.log) */
 } mi3pt_option;
 int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option /* mi3pt_option */, int value);
 int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option /* mi3pt_option */, int *value);

@@ -3,7 +3,7 @@
 MI3PT_LIBRARY, which the Python host reads).  The scenes are generated once and handed to the child processes as pickles; every
 (round, library) is a fresh process.  Per leg: the driver's job shape (80 warm-up frames, then 320 frames in 64-frame launches,
 1920x1080, 8 bounces), wall clock around submit .. sync, Mrays/s from the kernel's own ray count.
-usage: python profiles/ab_quick.py ROUNDS lib1.so lib2.so ... [--scenes dragon,demo,closeup,forest] [--tile R/N] [--frames 320] [--variants 0,13] [--walk-min N]"""
+usage: python profiles/ab_quick.py ROUNDS lib1.so lib2.so ... [--scenes dragon,demo,closeup,forest] [--tile R/N] [--frames 320] [--variants 0,13] [--walk-min N] [--batch FRAMES_PER_LAUNCH]"""
 import os, pickle, subprocess, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "webgpu-pathtracer_amd", "py")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -32,6 +32,8 @@ def child():
         ctx.set_kernel_variant(int(opt("--variant", "0")))
         if "--walk-min" in sys.argv:
             ctx.set_option(capi.OPT_WALK_MIN, int(opt("--walk-min", "0")))
+        if "--batch" in sys.argv:                  # frames per launch (MI3PT_OPT_BATCH; before resize)
+            ctx.set_option(capi.OPT_BATCH, int(opt("--batch", "64")))
         pc.upload_scene(ctx, sc, env)
         ctx.set_tile(tile[0], tile[1], 8)
         ctx.resize(W, H)
@@ -73,7 +75,7 @@ def main():
         sc = {"dragon": scenes.dragon_class_scene, "demo": scenes.demo_scene, "forest": scenes.forest_scene}[name]()
         sc.build_bvh()
         pickle.dump(sc, open(path, "wb"), protocol=4)
-    extra = [a for k in ("--tile", "--frames", "--walk-min") if k in sys.argv for a in (k, opt(k, ""))]
+    extra = [a for k in ("--tile", "--frames", "--walk-min", "--batch") if k in sys.argv for a in (k, opt(k, ""))]
     variants = opt("--variants", "0").split(",")          # several kernel variants of each library, e.g. --variants 0,13
     for r in range(rounds):
         for lib in libs:

@@ -50,11 +50,11 @@ python bench.py --workload demo --no-forest > $OUT/${TAG}_demo_1080p_bench.json 
 echo "bench (demo) done: $(cut -c1-120 $OUT/${TAG}_demo_1080p_bench.json)"
 STEPS=20; WARM=5
 bash profiles/pmc_passes.sh gpurun_out/${TAG}_pmc_dragon --steps $STEPS --warmup $WARM
-python profiles/pmc_summary.py $OUT/${TAG}_pmc_dragon k_raytrace $((STEPS / 4)) > $OUT/${TAG}_dragon_pmc_per_launch.txt
+python profiles/pmc_summary.py $OUT/${TAG}_pmc_dragon k_raytrace $(( (STEPS * 16 + 255) / 256 )) > $OUT/${TAG}_dragon_pmc_per_launch.txt
 rm -rf $OUT/${TAG}_pmc_dragon $OUT/${TAG}_pmc_dragon.pass*.log
 echo "pmc passes done: $(grep -c . $OUT/${TAG}_dragon_pmc_per_launch.txt) counters"
-# config 5's scene (the one larger than the Infinity Cache): the forest leg of bench.py, 1920x1080, 8 steps = two 64-frame launches
+# config 5's scene (the one larger than the Infinity Cache): the forest leg of bench.py, 1920x1080, 8 steps = one 128-frame launch
 bash profiles/pmc_passes.sh gpurun_out/${TAG}_pmc_forest --workload forest --steps 8 --warmup 4
-python profiles/pmc_summary.py $OUT/${TAG}_pmc_forest k_raytrace 2 > $OUT/${TAG}_forest_pmc_per_launch.txt
+python profiles/pmc_summary.py $OUT/${TAG}_pmc_forest k_raytrace 1 > $OUT/${TAG}_forest_pmc_per_launch.txt
 rm -rf $OUT/${TAG}_pmc_forest $OUT/${TAG}_pmc_forest.pass*.log
 echo "forest pmc passes done: $(grep -c . $OUT/${TAG}_forest_pmc_per_launch.txt) counters"

@@ -28,6 +28,9 @@ if waves_per_cu:
 pc.upload_scene(ctx, sc, scenes.synthetic_env())
 ctx.resize(w, h)
 ctx.enable_timing(True)
+if os.environ.get("COST_ORDER"):          # MI3PT_OPT_COST_ORDER: 1 = the cheapest quarter of the tiles last, 2 = all tiles costliest first
+    ctx.set_option(capi.OPT_COST_ORDER, int(os.environ["COST_ORDER"]))
+    print("cost order:", os.environ["COST_ORDER"])
 ctx.set_uniforms(capi.PASS_FULLSCREEN, pc.fs_uniforms(w, h, 1.0, 1, 1).tobytes())
 RT_ACC = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
 

@@ -20,7 +20,7 @@ def _line(out):
 
 
 def test_single_gpu_line():
-    """The driver's own arguments (--steps 20 --warmup 5; a step = 16 frames, four steps per launch): the headline is
+    """The driver's own arguments (--steps 20 --warmup 5; a step = 16 frames, up to sixteen steps per launch): the headline is
     the ~870k-triangle scene the target is quoted on; the roofline fraction comes from counter passes
     of this very command line and is a fraction; the launch statistics are consistent with the wall clock."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"],
@@ -36,13 +36,13 @@ def test_single_gpu_line():
     roof = j["roofline"]
     # the roof that binds: vector-ALU lane-operations (round-2 verdict: not "hbm" for a scene that fits the Infinity Cache)
     assert roof["bound"] == "valu" and roof["unit"] == "Tlane-op/s" and abs(roof["peak"] - 78.643) < 0.01
-    assert roof["kernel_ms"] > 0 and roof["launches_timed"] == 5 and roof["frames_per_launch"] == 64.0
+    # the 320 timed frames are a 256- and a 64-frame launch
+    assert roof["kernel_ms"] > 0 and roof["launches_timed"] == 2 and roof["frames_per_launch"] == 160.0
     # the non-overlapped kernel time per frame cannot exceed the wall clock per frame
-    assert roof["kernel_ms_exclusive"] / 4 <= j["ms_per_step"] * 1.02          # (one launch per four steps)
+    assert roof["kernel_ms_exclusive"] / 10 <= j["ms_per_step"] * 1.02         # (a launch per ten steps, on average)
     assert roof["kernel_ms_exclusive"] <= roof["kernel_ms"] * 1.02
-    # the average over every launch of the process (what `rocprofv3 --stats` averages): the warm-up's 80 frames are a
-    # 64- and a 16-frame launch
-    assert roof["launches_all"] == 7 and 0 < roof["kernel_ms_all_launches"] < roof["kernel_ms"]
+    # the average over every launch of the process (what `rocprofv3 --stats` averages): the warm-up's 80 frames are one launch
+    assert roof["launches_all"] == 3 and 0 < roof["kernel_ms_all_launches"] < roof["kernel_ms"]
     # measured by this run (rocprofv3 is on the box): the issue figures, HBM-side traffic, L2 requests -- all fractions
     assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 2e-3
     assert 0 < roof["valu_issue_frac"] < 1 and 0 < roof["lane_utilisation"] <= 1
@@ -81,7 +81,7 @@ def test_two_rank_rehearsal_line(scaling, image):
     j = _line(r.stdout)
     assert (j["n_gpus"], j["steps"], j["scaling"]) == (2, 4, scaling) and j["config"]["image"] == image and "cpu_baseline" not in j
     assert "tile-split x2" in j["config"]["parallelism"] and j["value"] > 100
-    assert j["config"]["frames_per_launch"] == 64.0         # 4 steps = 64 frames: one launch (a rank of a 2-way split batches up to 128)
+    assert j["config"]["frames_per_launch"] == 64.0         # 4 steps = 64 frames: one launch (a rank of a 2-way split batches up to 512)
     # per rank: wall time, host time until everything was launched, GPU-clock span of the raytrace launches, its part of the gather
     ranks = j["config"]["per_rank"]
     assert len(ranks) == 2 and sum(r["rows"] for r in ranks) == image[1]

@@ -206,7 +206,7 @@ def test_config2_demo_1080p_64spp(gpu_ctx, demo, env):
 
 
 def test_config3_dragon_class_1080p_256spp(gpu_ctx, dragon, env):
-    """Config 3 at its stated 256 spp (four 64-frame launches on alternating streams)."""
+    """Config 3 at its stated 256 spp: one 256-frame launch of the shipped kernel (the default batch depth)."""
     w, h, spp = 1920, 1080, 256
     ctx = gpu_ctx
     pc.upload_scene(ctx, dragon, env)
@@ -226,7 +226,7 @@ def test_config3_dragon_class_1080p_256spp(gpu_ctx, dragon, env):
 
 def test_config4_dragon_dof_4k_1024spp_one_rank_of_4(gpu_ctx, dragon, env):
     """Config 4 at its stated 1024 spp, for one rank of the 4-way tile split (the ranks share nothing
-    but the final gather; the reassembly is tested above): thin lens on, 256-frame launches."""
+    but the final gather; the reassembly is tested above): thin lens on, 512-frame launches."""
     w, h, spp = 3840, 2160, 1024
     ctx = gpu_ctx
     pc.upload_scene(ctx, dragon, env)
@@ -234,7 +234,7 @@ def test_config4_dragon_dof_4k_1024spp_one_rank_of_4(gpu_ctx, dragon, env):
     kw = dict(aperture=0.03, focal=focal)
     ctx.set_tile(1, 4, 8)
     ctx.resize(w, h)
-    assert ctx.batch_capacity() == 256
+    assert ctx.batch_capacity() == 512
     ref, cref = _render_spp(ctx, dragon, w, h, spp, variant=2, **kw)
     got, cgot = _render_spp(ctx, dragon, w, h, spp, **kw)
     _same_job(got, cgot, ref, cref, spp * w * ctx.local_rows)

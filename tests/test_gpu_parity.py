@@ -713,6 +713,8 @@ def test_repeated_runs_are_bit_identical(gpu_ctx, demo, env):
     pc.upload_scene(ctx, demo, env)
     ctx.set_tile(0, 1, 8)
     ctx.resize(w, h)
+    depth = ctx.get_option(capi.OPT_BATCH)
+    ctx.set_option(capi.OPT_BATCH, 64)
     runs = []
     for _ in range(3):
         ctx.reset()
@@ -737,6 +739,7 @@ def test_repeated_runs_are_bit_identical(gpu_ctx, demo, env):
         exact.append((ctx.read_texture(capi.TEX_ACCUMULATION).tobytes(), ctx.counters()))
     ctx.set_kernel_variant(0)
     assert exact[0] == exact[1] and exact[0][0] == runs[0][0]
+    ctx.set_option(capi.OPT_BATCH, depth)
     ctx.resize(64, 64)
 
 
@@ -832,6 +835,8 @@ def test_present_latest_shows_every_frame_once_the_canvas_is_looked_at(gpu_ctx, 
     everything = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE | capi.SUBMIT_FULLSCREEN
     fs = pc.fs_uniforms(w, h, 1.0, 1, 1)
     canvases = {}
+    depth = ctx.get_option(capi.OPT_BATCH)
+    ctx.set_option(capi.OPT_BATCH, 64)
     for mode in (capi.PRESENT_EXACT, capi.PRESENT_LATEST):
         ctx.set_present_mode(mode)
         ctx.reset()
@@ -843,6 +848,7 @@ def test_present_latest_shows_every_frame_once_the_canvas_is_looked_at(gpu_ctx, 
         ctx.submit(capi.SUBMIT_FULLSCREEN)
         assert np.array_equal(ctx.read_canvas_rgba8(), canvases[mode][0])
     ctx.set_present_mode(capi.PRESENT_EXACT)
+    ctx.set_option(capi.OPT_BATCH, depth)
     for k in range(3):
         assert np.array_equal(canvases[capi.PRESENT_EXACT][k], canvases[capi.PRESENT_LATEST][k])
     osc = pc.oracle_scene(orc, demo, env)
@@ -988,7 +994,7 @@ def test_batch_capacity_and_launch_statistics(gpu_ctx, demo, env):
     w, h = 640, 360
     ctx = gpu_ctx
     pc.upload_scene(ctx, demo, env)
-    for nranks, want in ((1, 64), (2, 128), (4, 256), (8, 512), (16, 512)):
+    for nranks, want in ((1, 256), (2, 512), (4, 512), (8, 512), (16, 512)):
         ctx.set_tile(0, nranks, 8)
         ctx.resize(w, h)
         assert ctx.batch_capacity() == want
@@ -1133,18 +1139,19 @@ def test_triangles_only_upload_after_the_debug_layout_restores_the_uploaded_numb
         ctx.resize(64, 64)
 
 
-@pytest.mark.parametrize("tile,size", [((0, 1), (640, 360)), ((1, 3), (328, 200))])
-def test_cost_ordered_jobs_lose_and_repeat_nothing(gpu_ctx, demo, env, tile, size):
+@pytest.mark.parametrize("tile,size,mode", [((0, 1), (640, 360), 1), ((1, 3), (328, 200), 1), ((0, 1), (640, 360), 2), ((2, 3), (328, 200), 2)])
+def test_cost_ordered_jobs_lose_and_repeat_nothing(gpu_ctx, demo, env, tile, size, mode):
     """MI3PT_OPT_COST_ORDER (an option; off by default -- it did not pay): the first launch for a set of uniforms adds up the
-    path segments per 8x8 tile, later launches run the cheapest quarter of the tiles last (a permutation of the tiles,
-    chunked into bands), so that a launch's last tickets are its cheapest tiles.  Whatever the order: every pixel of every frame
+    path segments per 8x8 tile, later launches run the cheapest quarter of the tiles last (mode 1; mode 2: every tile, costliest
+    first -- what a launch of a single frame wants) -- a permutation of the tiles,
+    chunked into bands, so that a launch's last tickets are its cheapest tiles.  Whatever the order: every pixel of every frame
     exactly once, image bit-identical to a context with the feature off -- through the measuring launch, the ordered
     ones, a camera change (measured again, the other permutation buffer) and back."""
     w, h = size
     mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
     plain = capi.Context(0)
-    gpu_ctx.set_option(capi.OPT_COST_ORDER, 1)
-    assert gpu_ctx.get_option(capi.OPT_COST_ORDER) == 1 and plain.get_option(capi.OPT_COST_ORDER) == 0
+    gpu_ctx.set_option(capi.OPT_COST_ORDER, mode)
+    assert gpu_ctx.get_option(capi.OPT_COST_ORDER) == mode and plain.get_option(capi.OPT_COST_ORDER) == 0
     try:
         for ctx in (gpu_ctx, plain):
             pc.upload_scene(ctx, demo, env)

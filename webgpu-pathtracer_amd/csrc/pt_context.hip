@@ -86,7 +86,7 @@ struct mi3pt_ctx {
     // uniforms (frame aside) use as their job order (RtLaunch::tile_perm) -- their last tickets are then their cheapest tiles and
     // the drain after the queue has run empty is short.  Two permutation buffers: a new order never overwrites the one that
     // launches in flight may still read.  Any order renders the same bits.
-    bool cost_order = false;              // MI3PT_OPT_COST_ORDER: off -- measured ± 0 on one GPU and −1.6 … −4 % for a rank of a split (profiles/r03_h_cost_order.log)
+    int cost_order = 0;                   // (1: the cheapest quarter last; 2: all tiles, costliest first) MI3PT_OPT_COST_ORDER: off -- measured ± 0 on one GPU and −1.6 … −4 % for a rank of a split (profiles/r03_h_cost_order.log)
     int cost_state = 0;                   // 0: nothing measured for the current uniforms, 1: the measuring launch is in flight, 2: a permutation is in use
     uint32_t *d_tile_cost = nullptr, *d_tile_perm[2] = { nullptr, nullptr };
     size_t cost_tiles = 0;                // entries of each of the three arrays
@@ -179,7 +179,8 @@ struct mi3pt_ctx {
     std::vector<PendingFrame> pending;
     int batch_limit_frames = 512;        // MI3PT_OPT_BATCH_LIMIT (512: a rank of an 8-way split runs its 320-frame job as ONE launch instead of 256 + 64: 11.16 instead of 11.62 ms, profiles/r03_d_job_split.log): upper bound of frames per launch, THIS context's (round 3 kept one value per process:
                                          // contexts other than the caller's went on with a stale capacity)
-    int batch_max = 64;                  // MI3PT_BATCH (1 = no batching); x nranks for a tile split, see batch_limit().  16 -> 32: +3 % (fewer drains), 32 -> 64: +2 %, 64 -> 128: +1 %
+    int batch_max = 256;                 // MI3PT_BATCH (1 = no batching); x nranks for a tile split, see batch_limit().  16 -> 32: +3 % (fewer drains), 32 -> 64: +2 %, 64 -> 128: +1.5 %,
+                                         // 128 -> 256 / 320: +0.3 ... +1 % (profiles/r04_s_batch_depth.log); a quarter of the free memory bounds it (recompute_batch_cap)
     // per-launch GPU time of the batched raytrace kernel (HIP events on its own stream)
     hipEvent_t ev_rt[2][2] = {};
     bool ev_rt_pending[2] = { false, false };
@@ -580,7 +581,7 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
         ctx->slot_sets = value;
         break;
     case MI3PT_OPT_PIPELINE: ctx->pipeline = value != 0; break;
-    case MI3PT_OPT_COST_ORDER: ctx->cost_order = value != 0; ctx->cost_state = 0; break;
+    case MI3PT_OPT_COST_ORDER: ctx->cost_order = value < 0 ? 0 : (value > 2 ? 2 : value); ctx->cost_state = 0; break;
     case MI3PT_OPT_HOST_ANALYSES: return pt_set_error(MI3PT_ERR_INVALID, "MI3PT_OPT_HOST_ANALYSES is read-only");
     case MI3PT_OPT_DIAG_LITE:
 #ifdef MI3PT_EXPERIMENTS
@@ -627,7 +628,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_GATE: *value = ctx->gate_enabled ? 1 : 0; break;
     case MI3PT_OPT_SLOT_SETS: *value = ctx->slot_sets; break;
     case MI3PT_OPT_PIPELINE: *value = ctx->pipeline ? 1 : 0; break;
-    case MI3PT_OPT_COST_ORDER: *value = ctx->cost_order ? 1 : 0; break;
+    case MI3PT_OPT_COST_ORDER: *value = ctx->cost_order; break;
     case MI3PT_OPT_PRESENT_DEPTH: *value = ctx->present_depth; break;
     default:
         return pt_set_error(MI3PT_ERR_INVALID, "unknown option");
@@ -1874,8 +1875,16 @@ static int cost_order_collect(mi3pt_ctx *ctx, bool wait)
     std::nth_element(sorted.begin(), sorted.begin() + (std::ptrdiff_t)q, sorted.end());
     const uint32_t cut = sorted[q];          // tiles cheaper than this go last (ties stay in the main part)
     size_t at = 0;
-    for (size_t t = n; t-- > 0;) if (cost[t] >= cut) perm[at++] = (uint32_t)t;
-    for (size_t t = n; t-- > 0;) if (cost[t] < cut) perm[at++] = (uint32_t)t;
+    if (ctx->cost_order == 2) {
+        // every tile, costliest first (ties in image order): what a launch of ONE frame wants -- its time is its work plus its
+        // longest paths' dependent chains, which then start at once instead of when their tile's turn comes
+        for (size_t t = 0; t < n; t++) perm[t] = (uint32_t)t;
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+        at = n;
+    } else {
+        for (size_t t = n; t-- > 0;) if (cost[t] >= cut) perm[at++] = (uint32_t)t;
+        for (size_t t = n; t-- > 0;) if (cost[t] < cut) perm[at++] = (uint32_t)t;
+    }
     HIP_TRY(hipMemcpyAsync(ctx->d_tile_perm[target], perm.data(), n * 4, hipMemcpyHostToDevice, ctx->cost_stream));
     HIP_TRY(hipStreamSynchronize(ctx->cost_stream));
     ctx->perm_cur = target;
