@@ -306,7 +306,7 @@ typedef enum mi3pt_option {
     MI3PT_OPT_JOB_GROUP = 7,   /* tiles per job group; 0 frame-major, -1 the library's choice (-1) */
     MI3PT_OPT_JOB_CHUNK = 8,   /* job tickets per draw while the queue is long (4) */
     MI3PT_OPT_BATCH_LIMIT = 9, /* upper bound of frames per launch, of this context -- or of every member of this group (512) */
-    MI3PT_OPT_BATCH = 10,      /* frames per launch on one GPU; x nranks for a rank of a tile split (64); 1 = no batching */
+    MI3PT_OPT_BATCH = 10,      /* frames per launch on one GPU; x nranks for a rank of a tile split (256; the product is capped by MI3PT_OPT_BATCH_LIMIT); 1 = no batching */
     MI3PT_OPT_WAVES_PER_CU = 11, /* resident one-wave workgroups per compute unit (0 = what the kernel is compiled for: 20 for the shipped batched launch, 16 otherwise) */
     MI3PT_OPT_CULL = 12,       /* 0: `auto` stops at variant 7 */
     MI3PT_OPT_WIDE = 13,       /* 0: `auto` stops at variant 9 */
