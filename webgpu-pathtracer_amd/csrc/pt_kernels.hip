@@ -1321,7 +1321,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     };
     auto cull_push = [&](uint32_t ref, bool take) {
         const bool lf = (ref & PT_REF_LEAF) != 0u;
-        if (lf || sp < NCAP) stack[(lf ? DEPTH - 1 - nl : sp) * 64] = lf ? (ref & 0x7fffffffu) : ref;
+        if (lf || sp < NCAP) stack[(lf ? DEPTH - 1 - nl : sp) * 64] = ref;       // (a leaf entry keeps its leaf bit: stripped where the triangle step reads it)
         else if (take) ovf[(sp - NCAP) * 64] = ref;
         nl += (take && lf) ? 1 : 0;
         sp += (take && !lf) ? 1 : 0;
@@ -1332,7 +1332,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     auto flat_pop = [&]() -> uint32_t { sp--; return stack[sp * 64]; };
     auto flat_push = [&](uint32_t ref) {
         const bool lf = (ref & PT_REF_LEAF) != 0u;
-        stack[(lf ? DEPTH - 1 - nl : sp) * 64] = lf ? (ref & 0x7fffffffu) : ref;
+        stack[(lf ? DEPTH - 1 - nl : sp) * 64] = ref;
         nl += (lf && ref != PT_REF_NONE) ? 1 : 0;
         sp += lf ? 0 : 1;
     };
@@ -1462,9 +1462,9 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     // compressed-wide walk: a parked leaf is a CANDIDATE (its packet's box was rounded outward); the reference tests the
                     // triangle iff the leaf's own box passes its exact test -- made here, from the 64-byte record that carries that box
                     nl--;
-                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64];
+                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu;
                     uint32_t tj = ti;
-                    if (two) { nl--; tj = stack[(DEPTH - 1 - nl) * 64]; }
+                    if (two) { nl--; tj = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu; }
                     float4 pa = sc.tripk64[(size_t)ti * 4 + 0], pb = sc.tripk64[(size_t)ti * 4 + 1], pc = sc.tripk64[(size_t)ti * 4 + 2], pd = sc.tripk64[(size_t)ti * 4 + 3];
                     float4 qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), qb = qa, qc = qa, qd = qa;
                     if (two) { qa = sc.tripk64[(size_t)tj * 4 + 0]; qb = sc.tripk64[(size_t)tj * 4 + 1]; qc = sc.tripk64[(size_t)tj * 4 + 2]; qd = sc.tripk64[(size_t)tj * 4 + 3]; }
@@ -1502,9 +1502,9 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                 if (has_leaf) {
                     if (DIAG) lane_cost += two ? 6u : 3u;
                     nl--;
-                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64];
+                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu;
                     uint32_t tj = ti;
-                    if (two) { nl--; tj = stack[(DEPTH - 1 - nl) * 64]; }
+                    if (two) { nl--; tj = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu; }
                     // (the opaque statements keep each of these ONE 16-byte load: left alone, the compiler fetches the nine
                     // coordinates as five overlapping 8- and 12-byte pieces to feed packed multiplies -- five divergent
                     // requests per lane instead of three)
@@ -1572,13 +1572,20 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                         if ((pre.flags & 8u) == 0u) {
                             const float Ax = (c0.x - o.x) * pre.ix, Ay = (c0.y - o.y) * pre.iy, Az = (c0.z - o.z) * pre.iz;
                             const float Bx = cx * pre.ix, By = cy * pre.iy, Bz = cz * pre.iz;
+                            // near and far plane per axis by the SIGN of the ray's reciprocal: with B >= 0 the quotient fma(q, B, A) rises with
+                            // the index q, with B < 0 it falls, and neither quotient is a NaN here (A and q B are finite: coordinates below 1e30,
+                            // |1/d| <= 1e6) -- so min(a, b) / max(a, b) of the two planes' quotients ARE the quotient of the lower / upper index
+                            // (B >= 0) or the other way round, bit for bit; chosen once per axis for the four children (six selects on the packed
+                            // index words) instead of a min and a max per axis and child (24)
+                            const bool nx_ = pre.ix < 0.0f, ny_ = pre.iy < 0.0f, nz_ = pre.iz < 0.0f;
+                            const uint32_t ex = nx_ ? hx : lx, fx = nx_ ? lx : hx, ey = ny_ ? hy : ly, fy = ny_ ? ly : hy, ez = nz_ ? hz : lz, fz = nz_ ? lz : hz;
 #define PT_CBOX(K)                                                                                                          \
                             {                                                                                              \
-                                const float ax_ = fmaf((float)((lx >> (8 * K)) & 0xffu), Bx, Ax), bx_ = fmaf((float)((hx >> (8 * K)) & 0xffu), Bx, Ax); \
-                                const float ay_ = fmaf((float)((ly >> (8 * K)) & 0xffu), By, Ay), by_ = fmaf((float)((hy >> (8 * K)) & 0xffu), By, Ay); \
-                                const float az_ = fmaf((float)((lz >> (8 * K)) & 0xffu), Bz, Az), bz_ = fmaf((float)((hz >> (8 * K)) & 0xffu), Bz, Az); \
-                                const f3 a_ = F3(fminf(ax_, bx_), fminf(ay_, by_), fminf(az_, bz_));                       \
-                                const float f_ = fminf(fminf(fminf(PT_INF, fmaxf(ax_, bx_)), fmaxf(ay_, by_)), fmaxf(az_, bz_)); \
+                                const float ax_ = fmaf((float)((ex >> (8 * K)) & 0xffu), Bx, Ax), bx_ = fmaf((float)((fx >> (8 * K)) & 0xffu), Bx, Ax); \
+                                const float ay_ = fmaf((float)((ey >> (8 * K)) & 0xffu), By, Ay), by_ = fmaf((float)((fy >> (8 * K)) & 0xffu), By, Ay); \
+                                const float az_ = fmaf((float)((ez >> (8 * K)) & 0xffu), Bz, Az), bz_ = fmaf((float)((fz >> (8 * K)) & 0xffu), Bz, Az); \
+                                const f3 a_ = F3(ax_, ay_, az_);                                                           \
+                                const float f_ = fminf(fminf(bx_, by_), bz_);        /* (no NaN among them: min(INF, .) drops out) */ \
                                 key[K] = fmaxf(fmaxf(a_.x, a_.y), a_.z);                                                   \
                                 if constexpr (!YMAX) tn[K] = a_;                                                           \
                                 hit[K] = cwide_hit(key[K], f_);                                                            \
