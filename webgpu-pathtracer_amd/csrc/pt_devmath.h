@@ -140,6 +140,38 @@ PT_DEV float log1(float x)
     return r;
 }
 
+// log1 for x = 0 or x in [2^-32, 1] -- everything rand() returns (raytrace.wgsl:253-259: an integer below 2^32, rounded to
+// binary32, times 2^-32): never a NaN, negative, infinite or subnormal, so log1's tests for those and its subnormal scaling
+// drop out; the remaining operations are log1's own, in its order.
+PT_DEV float log1_unit(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    int e = (int)(u >> 23) - 126;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    const float z = m * m;
+    float p = fmaf(7.0376836292e-2f, m, -1.1514610310e-1f);
+    p = fmaf(p, m, 1.1676998740e-1f);
+    p = fmaf(p, m, -1.2420140846e-1f);
+    p = fmaf(p, m, 1.4249322787e-1f);
+    p = fmaf(p, m, -1.6668057665e-1f);
+    p = fmaf(p, m, 2.0000714765e-1f);
+    p = fmaf(p, m, -2.4999993993e-1f);
+    p = fmaf(p, m, 3.3333331174e-1f);
+    float y = (p * m) * z;
+    const float fe = (float)e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = fmaf(0.693359375f, fe, r);
+    return x == 0.0f ? -__builtin_inff() : r;
+}
+
 PT_DEV float exp1(float x)
 {
     if (x != x) return x;

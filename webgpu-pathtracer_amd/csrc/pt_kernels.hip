@@ -554,7 +554,9 @@ PT_DEV float rand1(uint32_t &seed)
 PT_DEV float rand_normal(uint32_t &seed)
 {
     const float theta = PT_TWOPI * rand1(seed);
-    const float rho = ptm::sqrt_exact(-2.0f * ptm::log1(rand1(seed)));
+    // (rand() returns 0 or a value in [2^-32, 1]: log1_unit is log1 without the tests no such value needs -- the same bits for
+    // every one of the 2^32 values, profiles/log_unit_proof.hip)
+    const float rho = ptm::sqrt_exact(-2.0f * ptm::log1_unit(rand1(seed)));
     return rho * ptm::cos1(theta);
 }
 
@@ -1907,14 +1909,24 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
 #endif
             if (shade_hit) {          // trace(), raytrace.wgsl:380-395
                 
-                f3 position, normal;
-                int32_t mi;
-                finish_hit(sc, o, d, best, position, normal, mi);
+                // finish_hit() (raytrace.wgsl:105-112) taken apart so that the two dependent round trips -- the triangle's normals and
+                // material index, then the material -- are in flight while work that needs neither runs: the normals are requested
+                // first, randDirection's ~300 instructions run, the material is requested as soon as its index is back, and the
+                // normal's interpolation runs while that is in flight.  Same operations on the same values in the seed's order.
+                float4 q3 = sc.tris[(size_t)best.tri * 7 + 3];
+                float4 q4 = sc.tris[(size_t)best.tri * 7 + 4];
+                float4 q5 = sc.tris[(size_t)best.tri * 7 + 5];
+                const f3 rdir = rand_direction(seed);
+                asm volatile("" : "+v"(q5.w));         // (the index is waited for HERE, not where the loads were issued, nor later)
+                const int32_t mi = __float_as_int(q5.w);
                 const float4 m0 = sc.mats[(size_t)mi * 4 + 0];
                 const float4 m1 = sc.mats[(size_t)mi * 4 + 1];
                 const float4 m2 = sc.mats[(size_t)mi * 4 + 2];
                 const float4 m3 = sc.mats[(size_t)mi * 4 + 3];
-                const f3 diffuse_dir = normalize(normal + rand_direction(seed));
+                const float w = 1.0f - best.u - best.v;
+                const f3 position = o + d * best.t;
+                const f3 normal = normalize((xyz(q3) * w + xyz(q4) * best.u) + xyz(q5) * best.v);
+                const f3 diffuse_dir = normalize(normal + rdir);
                 const f3 specular_dir = reflect(d, normal);
                 float is_specular = 0.0f;
                 if (m2.x >= rand1(seed)) is_specular = 1.0f;
