@@ -389,7 +389,8 @@ int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t n, int wave
 #endif
 /* fn: 0 sin, 1 cos, 2 tan, 3 log, 4 exp, 5 atan2(a,b), 6 asin, 7 pow(a,b),
  * 8 fp16 round trip, 9 sqrt, 10 a/b; the kernels' reduced-instruction forms: 11 sqrt, 12 1/a,
- * 13..15 x/y/z of normalize(a, b, a - b).  b may be NULL for unary functions. */
+ * 13..15 x/y/z of normalize(a, b, a - b), 16 log for a = 0 or a in [2^-32, 1] (rand()'s values: what randNormal
+ * calls).  b may be NULL for unary functions. */
 int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n);
 
 /* Diagnostic record of the last persistent raytrace launch: 16 x uint64 per resident wave

@@ -59,6 +59,23 @@ def _edge_values(rng, n):
     return np.concatenate([v, special]).astype(np.float32)
 
 
+def test_log_for_rand_values_equals_the_oracles_log(gpu_ctx, orc):
+    """ptm::log1_unit (pt_devmath.h: randNormal's log without the tests no value of rand() needs) against the oracle's log
+    (fn 3) on values of the form f32(r) / 2^32 -- every exponent, the ends 0, 2^-32 and 1.0, the rounding up to 1.0 -- and
+    against the device's own log1 (the exhaustive comparison is profiles/log_unit_proof.hip; this is the regression test)."""
+    rng = np.random.default_rng(4242)
+    r = np.concatenate([rng.integers(0, 2 ** 32, 600000, dtype=np.uint64),
+                        (rng.integers(1, 2 ** 24, 200000, dtype=np.uint64) << rng.integers(0, 9, 200000).astype(np.uint64)),
+                        rng.integers(0, 2 ** 12, 100000, dtype=np.uint64),
+                        np.array([0, 1, 2, 3, 2 ** 32 - 1, 2 ** 32 - 128, 2 ** 32 - 129, 2 ** 31, 2 ** 31 - 1, 3037000500], dtype=np.uint64)])
+    x = (r.astype(np.float32) / np.float32(4294967296.0)).astype(np.float32)
+    assert x.min() == 0.0 and x.max() == 1.0 and x[x > 0].min() == np.float32(2.0 ** -32)
+    got = gpu_ctx.debug_math(16, x)
+    with np.errstate(all="ignore"):
+        assert pc.same_bits(got, orc.math_fn(3, x, None)), pc.describe_diff(got, orc.math_fn(3, x, None))
+    assert pc.same_bits(got, gpu_ctx.debug_math(3, x))
+
+
 def test_reduced_sqrt_rcp_normalize_equal_the_ieee_operations(gpu_ctx):
     """ptm::sqrt_exact / rcp_exact / the normalize built on them (pt_devmath.h) against numpy's
     correctly rounded float32 sqrt and division, over all exponents and the guard boundaries

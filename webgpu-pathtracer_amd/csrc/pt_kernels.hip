@@ -2902,6 +2902,7 @@ __global__ void __launch_bounds__(256) k_debug_math(int fn, const float *__restr
     case 13: r = normalize(F3(x, y, x - y)).x; break;
     case 14: r = normalize(F3(x, y, x - y)).y; break;
     case 15: r = normalize(F3(x, y, x - y)).z; break;
+    case 16: r = ptm::log1_unit(x); break;           // (only for x = 0 or x in [2^-32, 1]: what rand() returns)
     default: r = x / y; break;
     }
     out[i] = r;
