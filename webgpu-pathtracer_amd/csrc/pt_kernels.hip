@@ -54,6 +54,22 @@ struct f3 { float x, y, z; };
 using ptm::div_pre;
 using ptm::rcp_exact;
 
+// An opaque use-and-redefinition of a 16-byte value: keeps the load that produced it ONE dwordx4 (left alone, the compiler narrows
+// and splits such loads to feed packed operations).  WHOLE: as one 128-bit operand, so that its four dwords are not tied to four
+// separate registers -- which costs a copy per dword out of the load's register tuple; !WHOLE: four 32-bit operands (the registers
+// may part ways: what the instantiations without a register to spare for whole tuples keep -- they spill with WHOLE).
+typedef float pt_keep4 __attribute__((ext_vector_type(4)));
+template <bool WHOLE>
+PT_DEV void keep16(float4 &v)
+{
+    if constexpr (WHOLE) {
+        pt_keep4 t = { v.x, v.y, v.z, v.w };
+        asm volatile("" : "+v"(t));
+        v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+    } else {
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    }
+}
 PT_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 xyz(const float4 &v) { return F3(v.x, v.y, v.z); }
 PT_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -1468,12 +1484,19 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     uint32_t tj = ti;
                     if (two) { nl--; tj = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu; }
                     float4 pa = sc.tripk64[(size_t)ti * 4 + 0], pb = sc.tripk64[(size_t)ti * 4 + 1], pc = sc.tripk64[(size_t)ti * 4 + 2], pd = sc.tripk64[(size_t)ti * 4 + 3];
-                    float4 qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), qb = qa, qc = qa, qd = qa;
+                    // (the second triangle's registers are only read under `two`.  Left unset otherwise, and with whole-tuple barriers below,
+                    // the step loses ~40 register moves -- 15 to zero-fill them, 15 to copy the loaded values into the filled registers, a dozen
+                    // out of the first triangle's load tuples -- where the instantiation has registers for that: the one-axis-culling builds
+                    // (YMAX).  The others, which carry the per-axis entry distances of four children through the node step, spill 2 .. 6
+                    // registers with either change and keep the zero fill and the per-dword barriers; forming their culling value inside the
+                    // box test to free those twelve registers was tried and costs the forest 11 %: profiles/r04_w_ab_tuple_barriers.log)
+                    float4 qa, qb, qc, qd;
+                    if constexpr (!YMAX) { qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f); qb = qa; qc = qa; qd = qa; }
                     if (two) { qa = sc.tripk64[(size_t)tj * 4 + 0]; qb = sc.tripk64[(size_t)tj * 4 + 1]; qc = sc.tripk64[(size_t)tj * 4 + 2]; qd = sc.tripk64[(size_t)tj * 4 + 3]; }
-                    asm volatile("" : "+v"(pa.x), "+v"(pa.y), "+v"(pa.z), "+v"(pa.w));
-                    asm volatile("" : "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w));
-                    asm volatile("" : "+v"(pc.x), "+v"(pc.y), "+v"(pc.z), "+v"(pc.w));
-                    asm volatile("" : "+v"(pd.x), "+v"(pd.y), "+v"(pd.z), "+v"(pd.w));
+                    keep16<YMAX>(pa);
+                    keep16<YMAX>(pb);
+                    keep16<YMAX>(pc);
+                    keep16<YMAX>(pd);
                     {
                         float t, u, v;
                         const bool inbox = leaf_box_hit(o, d, pre, __float_as_uint(pd.w) != 0u, F3(pc.y, pc.z, pc.w), F3(pd.x, pd.y, pd.z));
@@ -1485,10 +1508,10 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                         best.tri = take ? (int32_t)ti : best.tri;
                     }
                     if (two) {
-                        asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qa.z), "+v"(qa.w));
-                        asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
-                        asm volatile("" : "+v"(qc.x), "+v"(qc.y), "+v"(qc.z), "+v"(qc.w));
-                        asm volatile("" : "+v"(qd.x), "+v"(qd.y), "+v"(qd.z), "+v"(qd.w));
+                        keep16<YMAX>(qa);
+                        keep16<YMAX>(qb);
+                        keep16<YMAX>(qc);
+                        keep16<YMAX>(qd);
                         float t, u, v;
                         const bool inbox = leaf_box_hit(o, d, pre, __float_as_uint(qd.w) != 0u, F3(qc.y, qc.z, qc.w), F3(qd.x, qd.y, qd.z));
                         const bool hit = ray_triangle_flat_e(o, d, F3(qa.x, qa.y, qa.z), F3(qa.w, qb.x, qb.y), F3(qb.z, qb.w, qc.x), t, u, v) && inbox;
