@@ -1582,8 +1582,12 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     bool hit[4];
                     float key[4];                    // entry distance of each box (approximate with FILT): sort key and culling bound
                     f3 tn[4];                        // per-axis entry distances (!YMAX)
-                    tn[0] = tn[1] = tn[2] = tn[3] = F3(-PT_INF, -PT_INF, -PT_INF);
-                    key[0] = key[1] = key[2] = key[3] = -PT_INF;
+                    // (a ray on the plain-division path leaves them at -PT_INF: never skipped, order of no consequence; the compressed-wide
+                    // walk: see that branch)
+                    if constexpr (!(CW && !YMAX)) {
+                        tn[0] = tn[1] = tn[2] = tn[3] = F3(-PT_INF, -PT_INF, -PT_INF);
+                        key[0] = key[1] = key[2] = key[3] = -PT_INF;
+                    }
                     if constexpr (CW) {
                         // compressed wide packet: 64 bytes, boxes on the node's 8-bit grid, rounded outward (CWidePacket; cwide_hit)
                         const float4 *P = sc.cwide + (size_t)ref * 4;
@@ -1618,6 +1622,18 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                             PT_CBOX(0) PT_CBOX(1) PT_CBOX(2) PT_CBOX(3)
 #undef PT_CBOX
                         } else {
+                            // (builds without the one-axis culling condition: its sort keys and entry distances are left UNSET -- an empty statement
+                            // that "defines" them, no instruction; with that condition the four keys keep their -PT_INF from above: there the
+                            // unset form spills two registers.  Such
+                            // a ray's culling constants are +inf (cull_setup), so that its culling value is -inf or a NaN whatever these hold
+                            // and no child is skipped; the order of its children is of no consequence.  Set to -PT_INF here or up front they
+                            // are 4 (16 without the one-axis culling condition) moves in EVERY node step: the compiler puts a branch's constant
+                            // assignments where both branches meet)
+                            if constexpr (!YMAX) {
+                                asm("" : "=v"(key[0]), "=v"(key[1]), "=v"(key[2]), "=v"(key[3]));
+                                asm("" : "=v"(tn[0].x), "=v"(tn[0].y), "=v"(tn[0].z), "=v"(tn[1].x), "=v"(tn[1].y), "=v"(tn[1].z),
+                                         "=v"(tn[2].x), "=v"(tn[2].y), "=v"(tn[2].z), "=v"(tn[3].x), "=v"(tn[3].y), "=v"(tn[3].z));
+                            }
                             // a ray on the plain-division path (a parallel axis, an out-of-range component): the reference's test on the
                             // decoded box -- exact fp32 coordinates (o + cell * q is representable: the builder keeps cells coarse
                             // against the coordinates), a box that contains the child's: monotone, hence conservative too
@@ -2079,7 +2095,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
         if (do_b && mode == M_PATH) {
             // raytrace.wgsl:441-455: next sample's camera path, or the pixel is finished
             mode = M_DEAD;
-            do {
+            {
                 float uvx, uvy;
                 uint32_t pxx = job_px, pyy = job_py;
                 {
@@ -2092,11 +2108,9 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     // no sample to take (samplesPerFrame < 1: the shader's loop does not run and the sum, 0, is divided by
                     // f32(samplesPerFrame), :441-455) or no segment to trace (maxBounces < 1: every path returns 0, :376-377):
                     // the pixel is 0 / f32(samplesPerFrame)
-                    if (un.samples_per_frame < 1 || un.max_bounces < 1) {
-                        const float z = un.samples_per_frame == 1 ? 0.0f : 0.0f / spf_f;
-                        write_radiance(L, gx, slot >> 16, F3(z, z, z));
-                        break;
-                    }
+                    // (the launch-uniform test sits BEHIND the camera ray below, which such a launch forms for nothing -- its lanes are dead
+                    // afterwards and what it leaves in them is never read: a branch around the ray makes the compiler form o, d, the slot word,
+                    // light and throughput in temporaries and copy them home where the two paths meet, 22 moves per step in EVERY launch)
                 }
                 if (ASSUME || res_ordinary_ != 0) { uvx = div_pre((float)pxx, un.res_x, inv_res_x); uvy = div_pre((float)pyy, un.res_y, inv_res_y); }
                 else { uvx = (float)pxx / un.res_x; uvy = (float)pyy / un.res_y; }
@@ -2119,11 +2133,16 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     o = cam_pos + jitter2;
                 }
                 d = normalize(focal - o);
+                if (un.samples_per_frame < 1 || un.max_bounces < 1) {
+                    const float z = un.samples_per_frame == 1 ? 0.0f : 0.0f / spf_f;
+                    write_radiance(L, gx, slot >> 16, F3(z, z, z));
+                } else {
+                    need_segment = true;
+                }
                 slot &= 0xffff0000u;
                 light = F3(0.0f, 0.0f, 0.0f);
                 ray_color = F3(1.0f, 1.0f, 1.0f);
-                need_segment = true;
-            } while (false);
+            }
         }
 #ifdef PT_DIAG_SERVICE
         if (wave_times) st_switch(6);
@@ -2140,8 +2159,9 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
             park[0] = ray_color.x; park[64] = ray_color.y; park[128] = ray_color.z;
             park[192] = light.x; park[256] = light.y; park[320] = light.z;
         }
-        ray_color = F3(0.0f, 0.0f, 0.0f);       // (dead until the lane's next shading: nothing to keep in registers)
-        light = F3(0.0f, 0.0f, 0.0f);
+        ray_color = F3(0.0f, 0.0f, 0.0f);       // (dead until the lane's next shading: nothing to keep in registers -- zeros, which cost
+        light = F3(0.0f, 0.0f, 0.0f);           // six moves per service step where they meet the values read back from the park, can be made
+                                                // anew; an unset value would have to live in six registers through the whole walk: it spills)
         if (need_segment) {
             // raySceneIntersect + the root test of rayBVHIntersect, raytrace.wgsl:155-164, 205-211
             best.t = PT_INF; best.u = 0.0f; best.v = 0.0f; best.tri = -1;
