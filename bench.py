@@ -212,7 +212,7 @@ class Job:
 
 def cpu_baseline(job, budget_s=20.0):
     """The CPU oracle timed on 1/16-image shards (8-row blocks dealt round robin, like the GPU tile split) of the same
-    frames, with 1, 4, 16, 64 and all hardware threads in turn, each for its share of the budget; one OpenMP team
+    frames, with 1, 4, 16, 64 threads and the box's CPU share (cgroup quota, `pt_oracle.default_threads`) in turn, each for its share of the budget; one OpenMP team
     per shard call (tens to hundreds of ms of work each; the team's threads are kept between calls).  `value` is the
     best leg, `cores` its thread count: on a box whose CPU share is smaller than its processor count (a container
     quota) more threads than the share only add contention.  kind = "port": the oracle is a restatement, not the
@@ -221,7 +221,8 @@ def cpu_baseline(job, budget_s=20.0):
     sc = job.sc
     osc = orc.OracleScene(sc.triangles, sc.material_bytes, sc.nodes, job.env)
     procs = max(orc.num_procs(), 1)
-    legs = sorted({t for t in (1, 4, 16, 64, procs) if t <= procs})
+    share = orc.default_threads()            # the cgroup CPU quota where one is set, else the affinity mask (capped)
+    legs = sorted({t for t in (1, 4, 16, 64, share) if t <= procs})
     shards = 16
     per_leg = budget_s / len(legs)
     scaling, n = {}, 0
@@ -244,10 +245,11 @@ def cpu_baseline(job, budget_s=20.0):
         scaling[str(threads)] = round(rate, 4)
         if rate > best[0]:
             best = (rate, threads, rays, pixels, dt)
-    orc.set_num_threads(procs)
+    orc.set_num_threads(share)
     rate, threads, rays, pixels, dt = best
     return {"value": round(rate, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
             "thread_scaling_Mrays_per_s": scaling, "processors_visible": procs,
+            "cpu_quota": orc.cpu_quota(), "oracle_default_threads": share,
             "sample": f"1/{shards}-image shards (8-row blocks, round robin) of the same {job.width}x{job.height} {BOUNCES}-bounce "
                       f"frames of the {job.workload} workload, {per_leg:.1f} s per thread count ({', '.join(str(t) for t in legs)}); "
                       f"best leg: {threads} threads, {pixels} pixel jobs, {rays} rays in {dt:.1f} s "

@@ -309,7 +309,7 @@ FRAME_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 13, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])      # 0 = `auto`, 13 = what it ships
 @pytest.mark.parametrize("case", FRAME_CASES, ids=[f"{c[0]}x{c[1]}-b{c[2]}-s{c[3]}-a{c[4]}" for c in FRAME_CASES])
 def test_raytrace_pass_bit_identical(gpu_ctx, orc, demo, env, case, variant):
     w, h, bounces, spf, aperture, focal, frame, rotation = case
@@ -328,11 +328,11 @@ def test_raytrace_pass_bit_identical(gpu_ctx, orc, demo, env, case, variant):
     want, ocnt = orc.raytrace(pc.oracle_scene(orc, demo, env), u.tobytes(), w, h)
     assert pc.max_rel_err(got, want) <= REL_TOL
     assert pc.same_bits(got, want), pc.describe_diff(got, want)
-    pc.check_counters(cnt, ocnt, culled=variant >= 9)
+    pc.check_counters(cnt, ocnt, culled=variant >= 9 or variant == 0)
     ctx.set_kernel_variant(0)
 
 
-@pytest.mark.parametrize("variant", [2, 9, 10])
+@pytest.mark.parametrize("variant", [0, 2, 9, 10, 13])
 def test_pinhole_camera_with_a_negative_zero_coordinate(gpu_ctx, orc, demo, env, variant):
     """aperture == 0 lets the shipped kernels drop the lens sample's arithmetic (its two rand()
     calls stay): cam_pos + (+-0) is cam_pos -- unless a coordinate of cam_pos is -0, where
