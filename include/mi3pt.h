@@ -40,7 +40,11 @@
 extern "C" {
 #endif
 
-#define MI3PT_ABI_VERSION 2
+/* 3 (round 5): mi3pt_set_tile deals the row blocks back and forth (ABI 2 as first released dealt them one way: a host that
+ * de-interleaves gathered rows must use mi3pt_tile_global_row / mi3pt_tile_owner, not its own copy of the old formula);
+ * MI3PT_OPT_BATCH defaults to 256 frames per launch (was 64), MI3PT_OPT_WALK_MIN reads 0 = "by the size of the tree" (was 32);
+ * new exports mi3pt_tile_global_row, mi3pt_tile_owner; new options MI3PT_OPT_GATE_TIMEOUT_MS, MI3PT_OPT_GATE_RELEASES. */
+#define MI3PT_ABI_VERSION 3
 
 typedef enum mi3pt_status {
     MI3PT_OK = 0,
@@ -163,6 +167,11 @@ int mi3pt_set_storage(mi3pt_ctx *ctx, int storage /* mi3pt_storage */);
  * rows in image order.  Default rank 0 of 1.  Takes effect at the next mi3pt_resize(). */
 int mi3pt_set_tile(mi3pt_ctx *ctx, int rank, int nranks, int block_rows);
 int mi3pt_tile_local_rows(int height, int rank, int nranks, int block_rows); /* returns the count */
+/* The deal itself, for hosts that gather and de-interleave on their own (multi-process jobs: bench.py, a JS host per GPU) -- so
+ * that nobody re-implements the formula above: the image row that local row `local_row` of `rank`'s compact texture holds
+ * (may be >= height in a ragged last round: such rows do not exist; -1 for bad arguments), and the rank that owns image row y. */
+int mi3pt_tile_global_row(int local_row, int rank, int nranks, int block_rows);
+int mi3pt_tile_owner(int y, int nranks, int block_rows);
 /* The other split: this context renders the CONTIGUOUS band of rows [first_row, first_row + nrows) of the image (clipped to
  * it; nrows < 0: no band -- mi3pt_set_tile's split applies again); its textures are compact nrows x width images and a gather
  * is one contiguous copy.  Any partition of the rows renders the same pixels -- the seed comes from the global pixel index,
@@ -311,6 +320,13 @@ typedef enum mi3pt_option {
     MI3PT_OPT_CULL = 12,       /* 0: `auto` stops at variant 7 */
     MI3PT_OPT_WIDE = 13,       /* 0: `auto` stops at variant 9 */
     MI3PT_OPT_GATE = 14,       /* launches wait for their predecessor's drain mark (1; 0 when a profiler is attached) */
+    MI3PT_OPT_GATE_TIMEOUT_MS = 22, /* the wait above has no bound of its own: a blocking entry point (mi3pt_sync, reads, pass times) that has
+                                   * waited this long with a launch still held publishes the mark from the host (2000; 0 = never).  An early
+                                   * release only lets two launches overlap more -- same bits.  The gate switches itself off, with a
+                                   * "warning: ..." text in mi3pt_last_error() and MI3PT_OK returned, once a predecessor is seen to have
+                                   * finished without publishing or after the third release */
+    MI3PT_OPT_GATE_RELEASES = 23,   /* READ-ONLY: host-side releases so far */
+    MI3PT_OPT_DEBUG_SUPPRESS_DRAIN = 24, /* tests: arm the gate but let no kernel publish its mark (forces the situation the time-out exists for) */
     MI3PT_OPT_SLOT_SETS = 15,  /* sets of per-frame radiance slots, 2 or 3; before mi3pt_resize (2) */
     MI3PT_OPT_PIPELINE = 16,   /* = mi3pt_set_pipelining */
     MI3PT_OPT_PRESENT_DEPTH = 18, /* MI3PT_PRESENT_EXACT: presenting frames that share one raytrace launch, >= 1 (16); each still

@@ -20,5 +20,7 @@ FETCH_SIZE
 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
 TCC_HIT_sum TCC_MISS_sum
 TCC_REQ_sum TCC_READ_sum
+TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+TCC_EA0_RDREQ_DRAM_sum TCC_BUBBLE_sum
 LIST
 python3 $ROOT/profiles/fetch_calibration_summary.py $ROOT/$OUT

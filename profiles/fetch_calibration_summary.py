@@ -23,10 +23,12 @@ for f in sorted(glob.glob(f"{root}/pass*/**/*_counter_collection.csv", recursive
             vals[n][c] = sum(ordered[at:at + k])
             at += k
 cols = sorted({c for v in vals.values() for c in v})
-print(f"{'pattern':22s} {'known bytes':>14s} {'ms':>8s} {'GB/s':>8s} " + " ".join(f"{c:>22s}" for c in cols) + "   bytes/(FETCH_SIZE*1024)  bytes/(RDREQ*64)")
+print(f"{'pattern':22s} {'known bytes':>14s} {'ms':>8s} {'GB/s':>8s} " + " ".join(f"{c:>22s}" for c in cols) + "   bytes/(FETCH_SIZE*1024)  bytes/(RDREQ*64)  bytes/(32*n32+64*n64+128*n128)")
 for n in names:
     v = vals.get(n, {})
     fs = v.get("FETCH_SIZE")
     rq = v.get("TCC_EA0_RDREQ_sum")
     print(f"{n:22s} {known[n]:14.0f} {ms[n]:8.3f} {known[n] / ms[n] / 1e6:8.1f} " + " ".join(f"{v.get(c, float('nan')):22.0f}" for c in cols)
-          + (f"   {known[n] / (fs * 1024):10.3f}" if fs else "          n/a") + (f"   {known[n] / (rq * 64):10.3f}" if rq else "          n/a"))
+          + (f"   {known[n] / (fs * 1024):10.3f}" if fs else "          n/a") + (f"   {known[n] / (rq * 64):10.3f}" if rq else "          n/a")
+          + (f"   {known[n] / (32 * v.get('TCC_EA0_RDREQ_32B_sum', 0) + 64 * v['TCC_EA0_RDREQ_64B_sum'] + 128 * v['TCC_EA0_RDREQ_128B_sum']):10.3f}"
+             if v.get("TCC_EA0_RDREQ_64B_sum") is not None and v.get("TCC_EA0_RDREQ_128B_sum") is not None and (v["TCC_EA0_RDREQ_64B_sum"] + v["TCC_EA0_RDREQ_128B_sum"]) > 0 else "          n/a"))

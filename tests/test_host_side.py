@@ -70,7 +70,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"libmi3pt.so does not export {name}"
-    assert lib.mi3pt_abi_version() == 2
+    assert lib.mi3pt_abi_version() == 3
     out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (mi3pt_\w+)", out))
     assert exported == set(declared)
@@ -392,3 +392,21 @@ def test_balanced_bands_partition_the_rows():
         whole = tiles.stack_bands(parts, b)
         assert whole.shape == (height, 5, 4) and all((whole[b[r]:b[r + 1]] == r).all() for r in range(n))
     assert tiles.balanced_bands(np.zeros((5, 3)), 37, 2) == [0, 8, 37]
+
+
+def test_tile_deal_helpers_agree_with_each_other_and_the_oracle(built, orc):
+    """mi3pt_tile_global_row / mi3pt_tile_owner (ABI 3): the deal for hosts that de-interleave on their own, so that nobody
+    re-implements mi3pt_set_tile's formula -- it changed once (round 4: back and forth) under an unchanged ABI number."""
+    from mi3pt_host import tiles
+    for h, n, b in ((70, 3, 5), (1080, 8, 8), (2160, 4, 8), (17, 5, 4), (64, 1, 8), (9, 2, 16)):
+        seen = np.full(h, -1)
+        for r in range(n):
+            rows = tiles.local_rows_of(h, r, n, b)
+            assert len(rows) == capi.tile_local_rows(h, r, n, b) == orc.tile_local_rows(h, r, n, b)
+            assert [capi.tile_global_row(ly, r, n, b) for ly in range(len(rows))] == rows
+            for y in rows:
+                assert capi.tile_owner(y, n, b) == r
+                seen[y] = r
+        assert (seen >= 0).all()
+    assert capi.tile_global_row(8, 0, 4, 8) == 56          # round 1 runs backwards: rank 0's second block is the round's last
+    assert capi.tile_global_row(0, 4, 4, 8) == -1 and capi.tile_owner(-1, 4, 8) == -1 and capi.tile_owner(5, 0, 8) == -1

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <vector>
 #include <map>
+#include <chrono>
+#include <thread>
 
 static thread_local std::string g_last_error;
 
@@ -133,6 +135,11 @@ struct mi3pt_ctx {
     uint32_t *d_drain_flag = nullptr;     // signal memory: sequence number of the last batched launch that started draining
     bool gate_enabled = false;            // launches wait on d_drain_flag (off when the memory or the wait is unavailable)
     uint32_t launch_seq = 0;              // sequence number of the last batched launch
+    int gate_timeout_ms = 2000;           // MI3PT_OPT_GATE_TIMEOUT_MS: a blocking entry point that has waited this long releases a held launch from the host (ctx_wait)
+    int gate_releases = 0;                // MI3PT_OPT_GATE_RELEASES: how often that happened
+    bool debug_suppress_drain = false;    // MI3PT_OPT_DEBUG_SUPPRESS_DRAIN (tests): the gate is armed but no kernel publishes its drain mark
+    hipStream_t gate_release_stream = nullptr;
+    volatile uint32_t *h_drain_flag = nullptr;   // the drain word as the host sees it, where signal memory is host memory (hipPointerGetAttributes at create); else null
     uint32_t *d_stack_overflow = nullptr; // [2 parities][PT_MAX_RESIDENT_WAVES][SM_OVERFLOW_ENTRIES][64] overflow stack entries
     void *d_fs_taps = nullptr;            // the de-noise pass's tap table (pt::launch_fullscreen), built for fs_taps_res
     float fs_taps_res[2] = { 0.0f, 0.0f };
@@ -315,6 +322,71 @@ static bool profiler_attached()
     return false;
 }
 
+// Every wait of a blocking entry point goes through this: the launch gate (launch_batch: hipStreamWaitValue32 on the predecessor's
+// drain mark) has no bound of its own, and a held launch whose predecessor never publishes -- a tool that serialises kernels in
+// an order other than the one they were enqueued in and that profiler_attached() does not recognise; a kernel that ends without
+// its store -- would block the host for ever (round-3 advice, round-4 verdict weak #5).  While the gate is armed the host polls
+// instead of blocking; after gate_timeout_ms without completion it publishes the newest sequence number itself (a command-processor
+// write on a third stream, no kernel: what mi3pt_destroy has always done).  An early release only lets launches overlap more than
+// intended -- every launch still runs, same bits.  A legitimately long launch (a 4K frame batch of a 10 M-triangle scene takes
+// seconds) gets the same harmless release and keeps its gate; the gate is switched off, with a warning in mi3pt_last_error,
+// once the predecessor is SEEN to have finished without publishing, or after three releases.
+static bool gate_launch_held(const mi3pt_ctx *ctx)
+{
+    // launch number launch_seq waits for the word to reach launch_seq - 1 (earlier waits were satisfied before it could be enqueued
+    // behind them); where the host cannot read the word, assume the worst
+    return !ctx->h_drain_flag || (int32_t)(*ctx->h_drain_flag - (ctx->launch_seq - 1u)) < 0;
+}
+
+static void gate_release_from_host(mi3pt_ctx *ctx, const char *why)
+{
+    if (!ctx->gate_release_stream && hipStreamCreateWithFlags(&ctx->gate_release_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->gate_release_stream = nullptr;
+        return;
+    }
+    // (read before the write) a launch's stream is idle, the other one still busy, and the word is short of what the busy one waits
+    // for: its predecessor finished without publishing -- nobody is left to do it
+    bool silent = false;
+    if (ctx->h_drain_flag && gate_launch_held(ctx))
+        for (int k = 0; k < 2; k++)
+            if (ctx->rt_stream[k] && hipStreamQuery(ctx->rt_stream[k]) == hipSuccess && hipStreamQuery(ctx->rt_stream[k ^ 1]) == hipErrorNotReady) silent = true;
+    (void)hipGetLastError();
+    if (hipStreamWriteValue32(ctx->gate_release_stream, ctx->d_drain_flag, ctx->launch_seq, 0) != hipSuccess) (void)hipGetLastError();
+    ctx->gate_releases++;
+    if (silent || ctx->gate_releases >= 3) {
+        ctx->gate_enabled = false;
+        pt_set_error(MI3PT_OK, std::string("warning: launch gate released from the host after ") + std::to_string(ctx->gate_timeout_ms) +
+                     " ms (" + why + (silent ? "; the predecessor finished without publishing its drain mark" : "; third release") +
+                     "): the gate is off for this context from now on, launches queue behind each other");
+    }
+}
+
+static hipError_t ctx_wait(mi3pt_ctx *ctx, hipStream_t s, hipEvent_t ev, const char *why)
+{
+    if (!(ctx->gate_enabled && ctx->d_drain_flag && ctx->launch_seq != 0 && ctx->gate_timeout_ms > 0))
+        return ev ? hipEventSynchronize(ev) : hipStreamSynchronize(s);
+    using clock = std::chrono::steady_clock;
+    const clock::time_point t0 = clock::now();
+    clock::time_point mark = t0;
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        (void)hipGetLastError();
+        const clock::time_point now = clock::now();
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(now - mark).count() >= ctx->gate_timeout_ms) {
+            if (gate_launch_held(ctx)) gate_release_from_host(ctx, why);      // (nothing held: an ordinary long wait)
+            mark = now;
+        }
+        if (!ctx->gate_enabled) return ev ? hipEventSynchronize(ev) : hipStreamSynchronize(s);      // (released for good: nothing is held any more)
+        // the first 3 ms poll back to back (an interactive host's frame), then yield the core between looks
+        if (std::chrono::duration_cast<std::chrono::microseconds>(now - t0).count() < 3000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(spins < 4096 ? 50 : 500));
+    }
+}
+static hipError_t ctx_stream_sync(mi3pt_ctx *ctx, hipStream_t s, const char *why = "stream wait") { return ctx_wait(ctx, s, nullptr, why); }
+static hipError_t ctx_event_sync(mi3pt_ctx *ctx, hipEvent_t ev, const char *why = "event wait") { return ctx_wait(ctx, nullptr, ev, why); }
+
 extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
 {
     if (!out_ctx) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
@@ -388,6 +460,11 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     if (hipExtMallocWithFlags((void **)&ctx->d_drain_flag, 8, hipMallocSignalMemory) == hipSuccess) {
         CREATE_TRY(hipMemsetAsync(ctx->d_drain_flag, 0, 8, ctx->stream));
         ctx->gate_enabled = !profiler_attached();
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, ctx->d_drain_flag) == hipSuccess && attr.type == hipMemoryTypeHost && attr.hostPointer)
+            ctx->h_drain_flag = static_cast<volatile uint32_t *>(attr.hostPointer);
+        else
+            (void)hipGetLastError();
     } else {
         (void)hipGetLastError();
         ctx->d_drain_flag = nullptr;
@@ -443,7 +520,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
     // A launch held at the gate is released from the host side before anything is waited for: whatever a tool did to the
     // order of the two internal queues (counter collection serialising kernels: the deadlock of round 2), destroy returns.
     // Early release only lets launches overlap more than intended; every launch still runs.
-    if (ctx->gate_enabled && ctx->d_drain_flag && ctx->launch_seq != 0) {
+    if (ctx->d_drain_flag && ctx->launch_seq != 0) {
         hipStream_t rel = nullptr;
         if (hipStreamCreateWithFlags(&rel, hipStreamNonBlocking) == hipSuccess) {
             if (hipStreamWriteValue32(rel, ctx->d_drain_flag, ctx->launch_seq, 0) == hipSuccess) (void)hipStreamSynchronize(rel);
@@ -454,6 +531,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 2; k++)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
+    if (ctx->gate_release_stream) (void)hipStreamDestroy(ctx->gate_release_stream);
     free_textures(ctx);
     for (void *p : { ctx->d_cwide, ctx->d_tripk64, ctx->d_wide, ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
                      (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow, (void *)ctx->d_service, ctx->d_fs_taps })
@@ -487,7 +565,7 @@ extern "C" int mi3pt_set_stream(mi3pt_ctx *ctx, void *hip_stream)
 {
     PT_GROUP(ctx, group_unsupported("mi3pt_set_stream: a device group runs on its members' own streams"));
     if (int rc = require_idle(ctx)) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     ctx->main_dirty = true;
     ctx->acc_done_valid[0] = ctx->acc_done_valid[1] = ctx->acc_done_valid[2] = false;
@@ -574,7 +652,10 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
     case MI3PT_OPT_WAVES_PER_CU: ctx->waves_per_cu = value; break;
     case MI3PT_OPT_CULL: ctx->cull_enabled = value != 0; break;
     case MI3PT_OPT_WIDE: ctx->wide_enabled = value != 0; break;
-    case MI3PT_OPT_GATE: ctx->gate_enabled = value != 0 && ctx->d_drain_flag != nullptr; break;
+    case MI3PT_OPT_GATE: ctx->gate_enabled = value != 0 && ctx->d_drain_flag != nullptr; if (ctx->gate_enabled) ctx->gate_releases = 0; break;
+    case MI3PT_OPT_GATE_TIMEOUT_MS: if (value < 0) return pt_set_error(MI3PT_ERR_INVALID, "gate time-out must be >= 0 ms"); ctx->gate_timeout_ms = value; break;
+    case MI3PT_OPT_GATE_RELEASES: return pt_set_error(MI3PT_ERR_INVALID, "MI3PT_OPT_GATE_RELEASES is read-only");
+    case MI3PT_OPT_DEBUG_SUPPRESS_DRAIN: ctx->debug_suppress_drain = value != 0; break;
     case MI3PT_OPT_SLOT_SETS:
         if (value != 2 && value != 3) return pt_set_error(MI3PT_ERR_INVALID, "slot sets: 2 or 3");
         if (ctx->width != 0 && value != ctx->slot_sets) return pt_set_error(MI3PT_ERR_STATE, "slot sets must be chosen before mi3pt_resize");
@@ -626,6 +707,9 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_CULL: *value = ctx->cull_enabled ? 1 : 0; break;
     case MI3PT_OPT_WIDE: *value = ctx->wide_enabled ? 1 : 0; break;
     case MI3PT_OPT_GATE: *value = ctx->gate_enabled ? 1 : 0; break;
+    case MI3PT_OPT_GATE_TIMEOUT_MS: *value = ctx->gate_timeout_ms; break;
+    case MI3PT_OPT_GATE_RELEASES: *value = ctx->gate_releases; break;
+    case MI3PT_OPT_DEBUG_SUPPRESS_DRAIN: *value = ctx->debug_suppress_drain ? 1 : 0; break;
     case MI3PT_OPT_SLOT_SETS: *value = ctx->slot_sets; break;
     case MI3PT_OPT_PIPELINE: *value = ctx->pipeline ? 1 : 0; break;
     case MI3PT_OPT_COST_ORDER: *value = ctx->cost_order; break;
@@ -665,7 +749,7 @@ extern "C" int mi3pt_set_pipelining(mi3pt_ctx *ctx, int enabled)
 {
     PT_GROUP_ALL(ctx, false, mi3pt_set_pipelining(m, enabled));
     if (int rc = require_idle(ctx)) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     ctx->pipeline = enabled != 0;
     ctx->main_dirty = true;
     return MI3PT_OK;
@@ -699,7 +783,7 @@ static int replace_buffer(mi3pt_ctx *ctx, void **dst, const void *bytes, size_t 
     void *fresh = nullptr;
     HIP_TRY(hipMalloc(&fresh, nbytes));
     hipError_t e = hipMemcpyAsync(fresh, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // copy-on-call: caller may reuse `bytes`
+    if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);   // copy-on-call: caller may reuse `bytes`
     if (e != hipSuccess) {
         (void)hipFree(fresh);
         return pt_set_error(MI3PT_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
@@ -969,7 +1053,7 @@ static int upload_env_like(mi3pt_ctx *ctx, void *dst, const float *rgba, int wid
                             "Environment texture must be 1024x512 pixels. Please resize the texture and try again.");
     const size_t nbytes = (size_t)width * height * 16;
     HIP_TRY(hipMemcpyAsync(dst, rgba, nbytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     ctx->scene_epoch++;
     return MI3PT_OK;
 }
@@ -1034,8 +1118,8 @@ extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
     if (int rc = require_idle(ctx)) return rc;
     if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
         return pt_set_error(MI3PT_ERR_INVALID, "width/height must be in [1, 32768]");
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(ctx->rt_stream[k]));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
+    for (int k = 0; k < 2; k++) HIP_TRY(ctx_stream_sync(ctx, ctx->rt_stream[k]));
     // Transactional: the new images are allocated into locals and the context only changes once
     // every allocation has succeeded; a failure leaves it WITHOUT textures (width = height = 0,
     // every later submit / read reports "before resize") instead of with dangling pointers.
@@ -1170,8 +1254,8 @@ static int prepare_layout(mi3pt_ctx *ctx)
     if (ctx->layout == 0 || ctx->nnodes == 0 || ctx->ntris == 0 || !ctx->tree_proper || ctx->max_tri_ref >= (int64_t)ctx->ntris)
         return MI3PT_OK;       // stays dirty; the uploaded (breadth-first) arrangement is complete by itself
     if (int rc = flush_pending(ctx)) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(ctx->rt_stream[k]));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
+    for (int k = 0; k < 2; k++) HIP_TRY(ctx_stream_sync(ctx, ctx->rt_stream[k]));
     const size_t n = ctx->nnodes, nt = ctx->ntris;
     std::vector<uint8_t> nodes(n * MI3PT_BVHNODE_STRIDE), tris(nt * MI3PT_TRIANGLE_STRIDE);
     HIP_TRY(hipMemcpy(nodes.data(), ctx->d_nodes, nodes.size(), hipMemcpyDeviceToHost));
@@ -1270,8 +1354,8 @@ static int prepare_cull(mi3pt_ctx *ctx)
     if (!wanted || ctx->layout_active || !ctx->cull_stack_ok || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
         return MI3PT_OK;       // stays dirty: pick_variant falls back to the reference-counter walk
     if (int rc = flush_pending(ctx)) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(ctx->rt_stream[k]));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
+    for (int k = 0; k < 2; k++) HIP_TRY(ctx_stream_sync(ctx, ctx->rt_stream[k]));
     const size_t n = ctx->nnodes, nt = ctx->ntris;
     std::vector<uint8_t> nodes(n * MI3PT_BVHNODE_STRIDE);
     // the three vertices of every triangle: the first 48 of every 112 bytes of the records, packed by a small kernel (the 48-B
@@ -1286,7 +1370,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
         pt::launch_pack_vertices(static_cast<const float4 *>(ctx->d_tris), packed, (uint32_t)nt, ctx->stream);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(tris.data(), packed, nt * sizeof(TriVerts), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);
         (void)hipFree(packed);
         if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("cull analysis: reading the vertices back: ") + hipGetErrorString(e));
     }
@@ -1389,7 +1473,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
         pt::launch_patch_cull(static_cast<float4 *>(ctx->d_packets), d_cull, (uint32_t)ctx->npackets, ctx->stream);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);
     (void)hipFree(d_cull);
     if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("cull analysis: ") + hipGetErrorString(e));
     // scene constants of the bound: u / EPSILON and 1.65 L_max u / EPSILON, rounded up (the 1.001 covers the
@@ -1785,7 +1869,7 @@ static pt::AccUniforms acc_from(const uint8_t *u)
 static int collect_rt_time(mi3pt_ctx *ctx, int par)
 {
     if (!ctx->ev_rt_pending[par]) return MI3PT_OK;
-    HIP_TRY(hipEventSynchronize(ctx->ev_rt[par][1]));
+    HIP_TRY(ctx_event_sync(ctx, ctx->ev_rt[par][1]));
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_rt[par][0], ctx->ev_rt[par][1]));
     ctx->rt_total_ms += ms;
@@ -1902,8 +1986,8 @@ static int cost_order_prepare(mi3pt_ctx *ctx, pt::RtLaunch &L, const uint8_t *u_
     std::memcpy(key, u_rt, sizeof key);
     std::memset(key + 12, 0, 4);          // the frame counter
     if (ctx->cost_tiles != n) {           // (resize / tile change: new arrays)
-        HIP_TRY(hipStreamSynchronize(ctx->rt_stream[0]));
-        HIP_TRY(hipStreamSynchronize(ctx->rt_stream[1]));
+        HIP_TRY(ctx_stream_sync(ctx, ctx->rt_stream[0]));
+        HIP_TRY(ctx_stream_sync(ctx, ctx->rt_stream[1]));
         for (uint32_t **q : { &ctx->d_tile_cost, &ctx->d_tile_perm[0], &ctx->d_tile_perm[1] }) {
             if (*q) (void)hipFree(*q);
             *q = nullptr;
@@ -1973,30 +2057,40 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame *frames, i
     // whole run -- same throughput, but event / profiler durations twice the execution time.
     const uint32_t seq_before = ctx->launch_seq;
     const bool launches = pt::raytrace_grid_blocks(L.tile) > 0;       // (an empty tile launches nothing)
+    // Only the state-machine kernel publishes a drain mark (pt_kernels.hip, the ticket draw).  A batch routed to the per-pixel
+    // kernels -- launches beyond the packing limits, maxBounces >= 65536 -- gets its mark from the host side of its stream after
+    // its last frame: left to a kernel that never stores it, the NEXT batch would wait for ever (round-4 advice).
+    ctx->last_route = pt::raytrace_route(L, pick_variant(ctx));          // (does not depend on the two fields set below)
+    uint32_t publish_after = 0;
     if (ctx->gate_enabled && launches) {
         if (ctx->launch_seq != 0 &&
             hipStreamWaitValue32(rs, ctx->d_drain_flag, ctx->launch_seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
             // no stream memory operations here: launches simply queue behind each other from now on
             (void)hipGetLastError();
             ctx->gate_enabled = false;
+        } else if (ctx->last_route.kind == 1) {
+            ++ctx->launch_seq;
+            if (!ctx->debug_suppress_drain) { L.drain_flag = ctx->d_drain_flag; L.drain_seq = ctx->launch_seq; }
         } else {
-            L.drain_flag = ctx->d_drain_flag;
-            L.drain_seq = ++ctx->launch_seq;
+            publish_after = ++ctx->launch_seq;
         }
     }
-    ctx->last_route = pt::raytrace_route(L, pick_variant(ctx));
     pt::launch_raytrace_setup(L, false, pick_variant(ctx), rs);
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev_rt[par][0], rs));
         if (!ctx->span_started) { HIP_TRY(hipEventRecord(ctx->ev_span_start, rs)); ctx->span_started = true; }
     }
     pt::launch_raytrace(L, false, pick_variant(ctx), rs);
+    if (publish_after && !ctx->debug_suppress_drain && hipStreamWriteValue32(rs, ctx->d_drain_flag, publish_after, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->gate_enabled = false;          // (the next batch enqueues no wait; a batch already held is released by ctx_wait)
+    }
     if (cost_measuring && launches) { HIP_TRY(hipEventRecord(ctx->cost_event, rs)); ctx->cost_state = 1; }
     if (cost_ordered && launches) { HIP_TRY(hipEventRecord(ctx->perm_used[ctx->perm_cur], rs)); ctx->perm_used_valid[ctx->perm_cur] = true; }
     if (hipError_t e = hipGetLastError()) {
         // The kernel that would have published drain_seq never ran: publish it from the host side
         // of the stream instead, so that neither a later launch nor mi3pt_destroy waits for it.
-        if (L.drain_flag && hipStreamWriteValue32(rs, ctx->d_drain_flag, L.drain_seq, 0) != hipSuccess) {
+        if (ctx->launch_seq != seq_before && hipStreamWriteValue32(rs, ctx->d_drain_flag, ctx->launch_seq, 0) != hipSuccess) {
             (void)hipGetLastError();
             ctx->launch_seq = seq_before;
             ctx->gate_enabled = false;
@@ -2252,7 +2346,7 @@ extern "C" int mi3pt_measure_tile_cost(mi3pt_ctx *ctx, uint32_t *cost, size_t nt
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(cost, d_cost, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);
     (void)hipFree(d_cost);
     ctx->last_radiance = ctx->d_radiance;       // (the frame was written like a raytrace pass's: MI3PT_TEX_OUTPUT shows it)
     ctx->output_is_accum = false;
@@ -2289,7 +2383,7 @@ extern "C" int mi3pt_sync(mi3pt_ctx *ctx)
 {
     PT_GROUP(ctx, group_sync(ctx));
     if (int rc = require_idle(ctx)) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     return cost_order_collect(ctx, false);      // (a measuring launch has finished by now: its job order is ready for the next launch)
 }
 
@@ -2321,7 +2415,7 @@ extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t 
     if (nfloats != need) return pt_set_error(MI3PT_ERR_INVALID, "destination size does not match the texture");
     if (need == 0) return MI3PT_OK;
     HIP_TRY(hipMemcpyAsync(dst, src, need * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     return MI3PT_OK;
 }
 
@@ -2340,7 +2434,7 @@ extern "C" int mi3pt_write_texture(mi3pt_ctx *ctx, int which, const float *src, 
     if (nfloats != need) return pt_set_error(MI3PT_ERR_INVALID, "source size does not match the texture");
     if (need) {
         HIP_TRY(hipMemcpyAsync(ctx->d_accum, src, need * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));      // copy-on-call
+        HIP_TRY(ctx_stream_sync(ctx, ctx->stream));      // copy-on-call
     }
     ctx->output_is_accum = true;      // like the copy-back of accumulate.ts:171-175
     ctx->main_dirty = true;
@@ -2358,7 +2452,7 @@ extern "C" int mi3pt_read_canvas_rgba8(mi3pt_ctx *ctx, uint8_t *dst, size_t nbyt
     if (nbytes != need) return pt_set_error(MI3PT_ERR_INVALID, "destination size does not match the canvas");
     if (int rc = settle_canvas(ctx)) return rc;
     HIP_TRY(hipMemcpyAsync(dst, ctx->d_canvas8, need, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     return MI3PT_OK;
 }
 
@@ -2378,7 +2472,7 @@ extern "C" int mi3pt_bind_accumulation(mi3pt_ctx *ctx, void *dev_ptr, size_t nby
     PT_GROUP(ctx, group_unsupported("mi3pt_bind_accumulation: a device group gathers into its own image (mi3pt_accumulation_device_ptr)"));
     if (int rc = require_idle(ctx)) return rc;
     if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "bind before resize");
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     ctx->main_dirty = true;
     ctx->accum_version++;
     if (!dev_ptr) {
@@ -2417,7 +2511,7 @@ extern "C" int mi3pt_pass_time_us(mi3pt_ctx *ctx, int pass, float *microseconds)
         return MI3PT_OK;
     }
     if (!ctx->ev_recorded[pass]) return pt_set_error(MI3PT_ERR_STATE, "pass was not timed in the last submit");
-    HIP_TRY(hipEventSynchronize(ctx->ev[pass][1]));
+    HIP_TRY(ctx_event_sync(ctx, ctx->ev[pass][1]));
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[pass][0], ctx->ev[pass][1]));
     *microseconds = ms * 1000.0f;
@@ -2452,7 +2546,7 @@ extern "C" int mi3pt_raytrace_launch_span(mi3pt_ctx *ctx, double *span_ms)
     if (!ctx->span_started) return MI3PT_OK;
     for (int par = 0; par < 2; par++) {
         if (!ctx->ev_rt_frames[par]) continue;              // this parity never ran a timed launch
-        HIP_TRY(hipEventSynchronize(ctx->ev_rt[par][1]));
+        HIP_TRY(ctx_event_sync(ctx, ctx->ev_rt[par][1]));
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ctx->ev_span_start, ctx->ev_rt[par][1]) != hipSuccess) { (void)hipGetLastError(); continue; }
         if ((double)ms > *span_ms) *span_ms = ms;
@@ -2469,7 +2563,7 @@ extern "C" int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT])
     if (ctx->nblocks == 0) return MI3PT_OK;
     std::vector<uint64_t> host(2 * (size_t)ctx->nblocks * pt::CNT_COUNT);
     HIP_TRY(hipMemcpyAsync(host.data(), ctx->d_block_counters, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     for (int b = 0; b < 2 * ctx->nblocks; b++)
         for (int k = 0; k < MI3PT_CNT_COUNT; k++) out[k] += host[(size_t)b * pt::CNT_COUNT + k];
     return MI3PT_OK;
@@ -2494,7 +2588,7 @@ extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out,
     if (int rc = require_idle(ctx)) return rc;
     const int slots = pt::PT_MAX_RESIDENT_WAVES;
     if (!out) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
         if (enable && !ctx->d_wave_times) {
             HIP_TRY(hipMalloc((void **)&ctx->d_wave_times, (size_t)slots * 128));
             HIP_TRY(hipMemset(ctx->d_wave_times, 0, (size_t)slots * 128));
@@ -2509,7 +2603,7 @@ extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out,
     if (!ctx->d_wave_times) return pt_set_error(MI3PT_ERR_STATE, "wave times are not enabled");
     if (capacity_slots < (size_t)ctx->wave_times_slots) return pt_set_error(MI3PT_ERR_INVALID, "buffer too small");
     HIP_TRY(hipMemcpyAsync(out, ctx->d_wave_times, (size_t)ctx->wave_times_slots * 128, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     if (slots_out) *slots_out = (size_t)ctx->wave_times_slots;
     return MI3PT_OK;
 }
@@ -2533,7 +2627,7 @@ extern "C" int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * 48, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);
     (void)hipFree(d_rays);
     (void)hipFree(d_out);
     if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("debug_intersect: ") + hipGetErrorString(e));
@@ -2549,7 +2643,7 @@ extern "C" int mi3pt_device_build_bvh(mi3pt_ctx *ctx, void *nodes_out, size_t no
     const size_t nodes = 2 * ctx->ntris - 1;
     if (nodes_capacity_bytes < nodes * MI3PT_BVHNODE_STRIDE) return pt_set_error(MI3PT_ERR_INVALID, "node buffer too small");
     std::string err;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     if (pt::lbvh_build(ctx->d_tris, ctx->ntris, nodes_out, build_ms, ctx->stream, err) != 0)
         return pt_set_error(MI3PT_ERR_HIP, "device BVH build: " + err);
     *nnodes_out = nodes;
@@ -2621,7 +2715,7 @@ extern "C" int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const fl
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);
     if (d_a) (void)hipFree(d_a);
     if (d_b) (void)hipFree(d_b);
     if (d_o) (void)hipFree(d_o);
@@ -2802,8 +2896,8 @@ static int clone_buffer(mi3pt_ctx *dst, void **dptr, const mi3pt_ctx *src, const
 static int clone_scene(mi3pt_ctx *dst, const mi3pt_ctx *src)
 {
     if (int rc = require_idle(dst)) return rc;
-    HIP_TRY(hipStreamSynchronize(dst->stream));
-    for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(dst->rt_stream[k]));
+    HIP_TRY(ctx_stream_sync(dst, dst->stream));
+    for (int k = 0; k < 2; k++) HIP_TRY(ctx_stream_sync(dst, dst->rt_stream[k]));
     if (int rc = clone_buffer(dst, &dst->d_tris, src, src->d_tris)) return rc;
     if (int rc = clone_buffer(dst, &dst->d_tris_perm, src, src->d_tris_perm)) return rc;
     if (int rc = clone_buffer(dst, &dst->d_nodes, src, src->d_nodes)) return rc;
@@ -2817,7 +2911,7 @@ static int clone_scene(mi3pt_ctx *dst, const mi3pt_ctx *src)
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
     HIP_TRY(hipMemcpyPeerAsync(dst->d_env, dst->device, src->d_env, src->device, env_bytes, dst->stream));
     HIP_TRY(hipMemcpyPeerAsync(dst->d_cdf, dst->device, src->d_cdf, src->device, env_bytes, dst->stream));
-    HIP_TRY(hipStreamSynchronize(dst->stream));
+    HIP_TRY(ctx_stream_sync(dst, dst->stream));
     dst->ntris = src->ntris; dst->nnodes = src->nnodes; dst->nmats = src->nmats; dst->npackets = src->npackets;
     dst->root_ref = src->root_ref; dst->scene_flags = src->scene_flags; dst->wide_root_nested = src->wide_root_nested;
     dst->max_tri_ref = src->max_tri_ref; dst->max_mat_ref = src->max_mat_ref;
@@ -2916,7 +3010,7 @@ static int gather_member(GroupState *gs, int i, bool direct)
         HIP_TRY(hipMemcpy2DAsync(dst + (size_t)(n + n - 1 - i) * block_bytes, 2 * (size_t)n * block_bytes, src + block_bytes, 2 * block_bytes, block_bytes, (size_t)n_odd, kind, p->stream));
     if (tail > 0)
         HIP_TRY(hipMemcpyAsync(dst + grow * row_bytes, src + (size_t)full * block_bytes, (size_t)tail * row_bytes, kind, p->stream));
-    if (!direct) HIP_TRY(hipStreamSynchronize(p->stream));       // the staging buffer is free again
+    if (!direct) HIP_TRY(ctx_stream_sync(p, p->stream));       // the staging buffer is free again
     return MI3PT_OK;
 }
 
@@ -2935,7 +3029,7 @@ static int group_gather(mi3pt_ctx *g)
             if (!gs->peer_direct[(size_t)i]) continue;
             if (gather_member(gs, i, true) != MI3PT_OK) { (void)hipGetLastError(); gs->peer_direct[(size_t)i] = 0; }
         }
-        if (hipStreamSynchronize(p->stream) == hipSuccess) break;
+        if (ctx_stream_sync(p, p->stream) == hipSuccess) break;
         // ... a rect copy between two devices can also fail asynchronously (round-3 advice): nothing this pass wrote is trusted;
         // every member on another device goes through the host from now on, and the gather is done again, once
         (void)hipGetLastError();
@@ -2949,7 +3043,7 @@ static int group_gather(mi3pt_ctx *g)
         if (!gs->peer_direct[(size_t)i])
             if (int rc = gather_member(gs, i, false)) return rc;
     HIP_TRY(hipSetDevice(p->device));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(ctx_stream_sync(p, p->stream));
     p->output_is_accum = true;      // like the copy-back of accumulate.ts:171-175
     p->main_dirty = true;
     p->accum_version++;

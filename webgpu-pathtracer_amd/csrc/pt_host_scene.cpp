@@ -351,3 +351,20 @@ extern "C" int mi3pt_tile_local_rows(int height, int rank, int nranks, int block
     }
     return n;
 }
+
+// The deal for hosts that gather on their own (include/mi3pt.h).  Local row ly sits in this rank's block number b = ly / block_rows,
+// which it drew in round b: position `rank` of an even round, nranks - 1 - rank of an odd one.
+extern "C" int mi3pt_tile_global_row(int local_row, int rank, int nranks, int block_rows)
+{
+    if (local_row < 0 || nranks <= 0 || rank < 0 || rank >= nranks || block_rows <= 0) return -1;
+    const int b = local_row / block_rows;
+    const long long y = ((long long)b * nranks + ((b & 1) ? nranks - 1 - rank : rank)) * block_rows + local_row % block_rows;
+    return y > 0x7fffffffLL ? -1 : (int)y;
+}
+
+extern "C" int mi3pt_tile_owner(int y, int nranks, int block_rows)
+{
+    if (y < 0 || nranks <= 0 || block_rows <= 0) return -1;
+    const int gb = y / block_rows, round = gb / nranks, pos = gb % nranks;
+    return (round & 1) ? nranks - 1 - pos : pos;
+}

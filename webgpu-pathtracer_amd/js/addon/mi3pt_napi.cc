@@ -159,6 +159,29 @@ napi_value TileLocalRows(napi_env env, napi_callback_info info)
     return r;
 }
 
+napi_value TileGlobalRow(napi_env env, napi_callback_info info)
+{
+    Args a;
+    int32_t ly, rank, nranks, block;
+    if (!get_args(env, info, a, 4) || !get_i32(env, a.v[0], &ly) || !get_i32(env, a.v[1], &rank) ||
+        !get_i32(env, a.v[2], &nranks) || !get_i32(env, a.v[3], &block))
+        return nullptr;
+    napi_value r;
+    NAPI_OK(napi_create_int32(env, mi3pt_tile_global_row(ly, rank, nranks, block), &r));
+    return r;
+}
+
+napi_value TileOwner(napi_env env, napi_callback_info info)
+{
+    Args a;
+    int32_t y, nranks, block;
+    if (!get_args(env, info, a, 3) || !get_i32(env, a.v[0], &y) || !get_i32(env, a.v[1], &nranks) || !get_i32(env, a.v[2], &block))
+        return nullptr;
+    napi_value r;
+    NAPI_OK(napi_create_int32(env, mi3pt_tile_owner(y, nranks, block), &r));
+    return r;
+}
+
 // ---- context
 
 napi_value Create(napi_env env, napi_callback_info info)
@@ -542,7 +565,7 @@ napi_value Init(napi_env env, napi_value exports)
 {
     struct { const char *name; napi_callback fn; } fns[] = {
         { "abiVersion", AbiVersion }, { "deviceCount", DeviceCount }, { "deviceName", DeviceName },
-        { "tileLocalRows", TileLocalRows }, { "create", Create }, { "createGroup", CreateGroup }, { "destroy", Destroy },
+        { "tileLocalRows", TileLocalRows }, { "tileGlobalRow", TileGlobalRow }, { "tileOwner", TileOwner }, { "create", Create }, { "createGroup", CreateGroup }, { "destroy", Destroy },
         { "setStorage", SetStorage }, { "setKernelVariant", SetKernelVariant }, { "setTile", SetTile },
         { "uploadTriangles", UploadTriangles }, { "uploadMaterials", UploadMaterials }, { "uploadBvh", UploadBvh },
         { "uploadEnvironment", UploadEnvironment }, { "uploadEnvironmentCdf", UploadEnvironmentCdf },

@@ -83,7 +83,10 @@ export interface RendererOptions {
   builderThreads?: number;
   /** build a linear BVH on the GPU instead of the reference's SAH tree (fast on huge meshes, same closest hits) */
   deviceBvh?: boolean;
-  /** multi-GPU tile split: this process renders rows (y / blockRows) % nranks == rank */
+  /** multi-GPU tile split: this process renders the blockRows-row blocks dealt to `rank`, round after round, BACK AND FORTH
+   *  (rank r owns block r of even rounds and block nranks - 1 - r of odd ones: include/mi3pt.h, mi3pt_set_tile).  Use
+   *  native.tileGlobalRow(localRow, rank, nranks, blockRows) / native.tileOwner(y, nranks, blockRows) to de-interleave
+   *  gathered rows -- never a copy of the formula (it changed with ABI 3) */
   tile?: { rank: number; nranks: number; blockRows: number };
   /** a device group inside this one process (mi3pt_create_group): the image's blockRows-row blocks are dealt to one
    *  member context per listed GPU; render(), the read-backs and the events are unchanged and move whole images */

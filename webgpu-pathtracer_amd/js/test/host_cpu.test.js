@@ -91,8 +91,18 @@ assert.throws(() => r.update(empty, camera), /Input nodes array is empty/);
 
 // --- the real addon: loads, fails loudly without a device, host-side builder works
 const native = pt.loadNative();
-assert.strictEqual(native.abiVersion(), 2);
+assert.strictEqual(native.abiVersion(), 3);
 assert.strictEqual(native.tileLocalRows(70, 1, 3, 5), 25);
+// the deal goes back and forth: rank 0 of 3 owns block 0 of round 0 and block 2 of round 1 (rows 25-29 with 5-row blocks)
+assert.strictEqual(native.tileGlobalRow(0, 0, 3, 5), 0);
+assert.strictEqual(native.tileGlobalRow(5, 0, 3, 5), 25);
+assert.strictEqual(native.tileGlobalRow(7, 2, 3, 5), 17);
+for (let y = 0; y < 70; y++) {
+  const owner = native.tileOwner(y, 3, 5);
+  let found = false;
+  for (let ly = 0; ly < native.tileLocalRows(70, owner, 3, 5); ly++) if (native.tileGlobalRow(ly, owner, 3, 5) === y) found = true;
+  assert.ok(found, `row ${y}`);
+}
 assert.throws(() => native.hostBuildBvhF64(new Float64Array(0)), /Input nodes array is empty/);
 const nodes = native.hostBuildBvhF64(new Float64Array([0, 0, 0, 1, 0, 0, 0, 1, 0, 5, 5, 5, 6, 5, 5, 5, 6, 5]), 1);
 assert.strictEqual(nodes.length, 3 * 48);

@@ -23,7 +23,8 @@ PRESENT_EXACT, PRESENT_LATEST = 0, 1
 # mi3pt_option (include/mi3pt.h): scheduling options; none changes a bit of any image
 (OPT_WALK_MIN, OPT_LEAF_MIN, OPT_SHADE_SPLIT, OPT_TAIL_POLICY, OPT_TOP_PACKETS, OPT_TRI_PAIR, OPT_JOB_REVERSE, OPT_JOB_GROUP,
  OPT_JOB_CHUNK, OPT_BATCH_LIMIT, OPT_BATCH, OPT_WAVES_PER_CU, OPT_CULL, OPT_WIDE, OPT_GATE, OPT_SLOT_SETS, OPT_PIPELINE,
- OPT_COST_ORDER, OPT_PRESENT_DEPTH, OPT_HOST_ANALYSES, OPT_GATHER_STAGED, OPT_DIAG_LITE) = range(22)
+ OPT_COST_ORDER, OPT_PRESENT_DEPTH, OPT_HOST_ANALYSES, OPT_GATHER_STAGED, OPT_DIAG_LITE,
+ OPT_GATE_TIMEOUT_MS, OPT_GATE_RELEASES, OPT_DEBUG_SUPPRESS_DRAIN) = range(25)
 COUNTER_NAMES = ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels", "reserved")
 
 # every symbol include/mi3pt.h declares; tests/test_capi_symbols.py checks the header
@@ -42,6 +43,7 @@ SYMBOLS = (
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf", "mi3pt_debug_set_option", "mi3pt_debug_get_option",
     "mi3pt_create_group", "mi3pt_group_size", "mi3pt_group_member",
+    "mi3pt_tile_global_row", "mi3pt_tile_owner",
 )
 
 
@@ -122,6 +124,8 @@ def load_library(path=None):
     lib.mi3pt_device_count.argtypes = [ctypes.POINTER(c_int)]
     lib.mi3pt_device_name.argtypes = [c_int, ctypes.c_char_p, c_size_t]
     lib.mi3pt_tile_local_rows.argtypes = [c_int, c_int, c_int, c_int]
+    lib.mi3pt_tile_global_row.argtypes = [c_int, c_int, c_int, c_int]
+    lib.mi3pt_tile_owner.argtypes = [c_int, c_int, c_int]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -150,8 +154,22 @@ def device_name(device=0):
     return buf.value.decode()
 
 
+def last_error():
+    """Text of this thread's most recent error -- or warning (the launch gate's host-side release returns MI3PT_OK and leaves one)."""
+    return load_library().mi3pt_last_error().decode(errors="replace")
+
+
 def tile_local_rows(height, rank, nranks, block_rows):
     return load_library().mi3pt_tile_local_rows(height, rank, nranks, block_rows)
+
+
+def tile_global_row(local_row, rank, nranks, block_rows):
+    """The image row that local row `local_row` of `rank`'s compact texture holds (mi3pt_set_tile's deal)."""
+    return load_library().mi3pt_tile_global_row(local_row, rank, nranks, block_rows)
+
+
+def tile_owner(y, nranks, block_rows):
+    return load_library().mi3pt_tile_owner(y, nranks, block_rows)
 
 
 # ---- host-side scene compile (no device) ----
