@@ -142,12 +142,13 @@ def frames_per_launch(cap):
 class Job:
     """Scene + context + the frame loop, shared by the timed run and the PMC child runs."""
 
-    def __init__(self, workload, width, height, rank=0, world=1, device=0, variant=0, stream_ptr=None, group=None, nthreads=0):
-        """group = [d0, d1, ...]: one device group (mi3pt_create_group) instead of one context; rank / world then stay 0 / 1."""
+    def __init__(self, workload, width, height, rank=0, world=1, device=0, variant=0, stream_ptr=None, group=None, nthreads=0, scene=None):
+        """group = [d0, d1, ...]: one device group (mi3pt_create_group) instead of one context; rank / world then stay 0 / 1.
+        scene = (scene, env) of another Job of the same workload: not built again."""
         from mi3pt_host import capi, layout
         self.capi, self.layout = capi, layout
         self.workload, self.width, self.height = workload, width, height
-        self.sc, self.env = build_scene(workload, nthreads)
+        self.sc, self.env = scene if scene is not None else build_scene(workload, nthreads)
         self.ctx = capi.Context(devices=group, block_rows=BLOCK_ROWS) if group else capi.Context(device)
         if stream_ptr is not None:
             self.ctx.set_stream(stream_ptr)
@@ -331,15 +332,28 @@ def collect_pmc(args, timed_launches, log, workload=None, steps=None, warmup=Non
 
 
 def traffic_from_file(key):
-    """Fallback when no live PMC pass is possible (under a profiler, N > 1, rocprofv3 missing):
-    the committed measurement for exactly this launch shape, else nothing."""
+    """Fallback when no live PMC pass is possible (under a profiler, N > 1, rocprofv3 missing): the committed measurement
+    for exactly this launch shape; for N > 1 -- where a rank cannot run counter passes of its own inside the job -- the
+    entry of the same split measured rank by rank on ONE GPU (`bench.py --tile R/N`, profiles/pmc_rank_shapes.sh: the ranks
+    of a tile split share nothing but the final gather, so a rank's kernel does the same work alone), with the nearest
+    launch depth, its counters scaled to this job's frames per launch (they are proportional to the frames rendered)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            for e in json.load(f).get("entries", []):
-                if all(e.get(k) == v for k, v in key.items()):
-                    return e
+            entries = json.load(f).get("entries", [])
     except (OSError, ValueError):
-        pass
+        return None
+    for e in entries:
+        if all(e.get(k) == v for k, v in key.items()):
+            return e
+    if key.get("n_gpus", 1) > 1:
+        rest = {k: v for k, v in key.items() if k != "frames_per_launch"}
+        near = [e for e in entries if all(e.get(k) == v for k, v in rest.items()) and e.get("frames_per_launch")]
+        if near and key.get("frames_per_launch"):
+            e = min(near, key=lambda e: abs(e["frames_per_launch"] - key["frames_per_launch"]))
+            f = key["frames_per_launch"] / e["frames_per_launch"]
+            unscaled = ("SQ_WAVES",)
+            return dict(e, counters={k: (v if k in unscaled else v * f) for k, v in e["counters"].items()},
+                        source=e.get("source", "") + f"; counters of a {e['frames_per_launch']:g}-frame launch scaled x{f:.3f} to {key['frames_per_launch']:g} frames")
     return None
 
 
@@ -513,6 +527,7 @@ def main():
             ctx.bind_accumulation(accum.data_ptr(), accum.numel() * 4)
         max_rows = max(capi.tile_local_rows(height, r, tile_world, BLOCK_ROWS) for r in range(tile_world))      # (the deal goes back and forth: rank 0 need not hold the most rows)
         send = gathered = None
+        gathered_host = []                 # (rehearsal: the gloo gather's host tensors on rank 0)
         ev_g0, ev_g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if world > 1 and gather:
             send = torch.zeros((max_rows, width, 4), dtype=torch.float32, device="cuda")
@@ -527,7 +542,9 @@ def main():
                 if rehearsal:
                     stream.synchronize()
                     host = send.cpu()
-                    dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
+                    if rank == 0:
+                        gathered_host[:] = [torch.empty_like(host) for _ in range(world)]
+                    dist.gather(host, gathered_host if rank == 0 else None, dst=0)
                 else:
                     dist.gather(send, gathered, dst=0)
                 ev_g1.record(stream)
@@ -599,6 +616,38 @@ def main():
                         + (": COMPRESSED packets (64 B, boxes on an 8-bit grid rounded outward, conservative test; the exact test on the leaf's own box in the triangle step)" if v == 13 else "")
                         + "; lean build, five waves per SIMD; batched frames)")(ctx.last_launch()["variant"] if not use_group else ctx.active_variant()),
              "lean": (ctx.last_launch()["lean"] if not use_group else None)}
+        # ---- is the gathered image the right image?  (outside the timed region; round-4 verdict: the N > 1 line gathered and
+        # discarded.)  Rank 0 renders the shares of two OTHER ranks again, alone, on its own GPU -- every row, every frame of the
+        # job (warm-up included: the accumulation image is the mean since frame 2) -- and compares them bit for bit with what
+        # arrived; its own rows against its own image.  A rank's pixels depend on nothing but (global pixel, frame).
+        if gather and not args.tile and (send is not None or use_group):
+            verdict = None
+            if rank == 0:
+                import numpy as np
+                from mi3pt_host import tiles
+                nframes = (warmup + steps) * FRAMES_PER_STEP
+                if use_group:
+                    whole = ctx.read_texture(capi.TEX_ACCUMULATION)
+                    parts = {r: whole[tiles.local_rows_of(height, r, len(use_group), BLOCK_ROWS)] for r in range(len(use_group))}
+                    n_split = len(use_group)
+                else:
+                    got = gathered_host if rehearsal else gathered
+                    n_split = world
+                    parts = {r: got[r].cpu().numpy()[: capi.tile_local_rows(height, r, world, BLOCK_ROWS)] for r in range(world)}
+                    own = accum.cpu().numpy()
+                    verdict = {"own_rows_identical": bool(np.array_equal(parts[0].view(np.uint32), own.view(np.uint32)))}
+                checked = sorted({1, n_split - 1} - {0})
+                same = True
+                for r in checked:
+                    cj = Job(workload, width, height, r, n_split, local_rank, args.variant, nthreads=threads, scene=(job.sc, job.env))
+                    cj.frames(nframes, frames_per_launch(cj.ctx.batch_capacity()))
+                    img = cj.ctx.read_texture(capi.TEX_ACCUMULATION)
+                    cj.ctx.close()
+                    same = same and img.shape == parts[r].shape and bool(np.array_equal(img.view(np.uint32), parts[r].view(np.uint32)))
+                verdict = dict(verdict or {}, ranks_rerendered=checked, frames=nframes, rows=[int(parts[r].shape[0]) for r in checked],
+                               identical=same)
+                m["gather_verified"] = same and verdict.get("own_rows_identical", True)
+                m["gather_check"] = verdict
         if accum is not None:
             ctx.bind_accumulation(None, 0)
         return m
@@ -623,12 +672,18 @@ def main():
                                       (f"tile-split x{n_gpus} (8-row blocks, round robin) inside ONE process: device group (mi3pt_create_group), "
                                        "scene replicated, one strided peer copy per member as the gather") if group_devices else "single GPU",
                        "per_rank": m["per_rank"], "host_threads_per_rank": m["host_threads"],
+                       **({"tile": args.tile} if args.tile else {}),
                        "rays_per_step": rays // steps,
                        "frames_per_launch": m["frames_per_launch"],
                        "scheduling": "consecutive frames are batched into one persistent launch over (frame, tile) "
                                      "jobs; batches alternate between two streams; one ordered multi-frame "
                                      "accumulate per batch on the main stream"},
         }
+        if "gather_verified" in m:
+            # the gathered image against shares rendered again on rank 0 (measure(): outside the timed region)
+            out["gather_verified"] = m["gather_verified"]
+            out["gather_check"] = dict(m["gather_check"], what="rank 0 rendered the listed ranks' shares again, alone (every row, every frame of "
+                                       "the job incl. warm-up), and compared them bit for bit with the gathered buffers; its own rows with its own image")
     job.ctx.close()
 
     # ---- secondary workloads (N = 1): BASELINE.json configs[1], the default demo mesh; and the headline scene seen from
@@ -684,6 +739,9 @@ def main():
                 pmc = dict(e["counters"])
                 source = "profiles/traffic.json entry for this launch shape (" + e.get("source", "") + ")"
         out["roofline"] = roofline_block(m, pmc, source, capi_num_cus())
+        if n_gpus > 1:
+            out["roofline"]["scope"] = (f"ONE GPU of the {n_gpus}: rank 0's raytrace kernel (its live HIP-event times; counters per launch from the "
+                                        "same split measured rank by rank on one GPU -- a rank cannot run rocprofv3 passes of its own inside the job)")
         if log:
             out["roofline"]["pmc_log"] = log
         if forest is not None:
@@ -718,6 +776,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and out is not None and out.get("gather_verified") is False:
+        raise SystemExit("bench.py: the gathered image differs from the shares rendered again on rank 0 (gather_check in the line above)")
 
 
 def capi_num_cus():

@@ -177,15 +177,17 @@ int mi3pt_tile_owner(int y, int nranks, int block_rows);
  * is one contiguous copy.  Any partition of the rows renders the same pixels -- the seed comes from the global pixel index,
  * raytrace.wgsl:435-436.  Bands of equal height are badly balanced (the model sits in the middle of the image: 3x between the
  * ranks of an 8-way split of the headline view); mi3pt_measure_tile_cost + mi3pt_host.tiles.balanced_bands cut them by measured
- * cost.  Measured against the round-robin tiles (profiles/r04_*_bands.log) the tiles stay the default of the bench and of
+ * cost.  MEASURED SLOWER than the round-robin tiles (slowest rank of eight 34.9 against 32.5 us per frame,
+ * profiles/r04_e_bands.log): kept for experiments and for hosts that need contiguous bands, not used by the bench or by
  * device groups.  Takes effect at the next mi3pt_resize(). */
 int mi3pt_set_rows(mi3pt_ctx *ctx, int first_row, int nrows);
-/* One frame of this context's share of the image at the current raytrace uniforms, measured: cost[ty * ceil(width / 8) + tx]
+/* (Experiments, like mi3pt_set_rows: it runs the 128-VGPR diagnostic twin of the walk, and its frame does not count towards
+ * mi3pt_get_counters.)  One frame of this context's share of the image at the current raytrace uniforms, measured: cost[ty * ceil(width / 8) + tx]
  * receives what the paths of 8x8 tile (tx, ty) cost -- 4 per BVH packet popped, 3 per triangle tested, 10 per path segment
  * (about their shares of a wave's time).  ntiles = ceil(width / 8) * ceil(local rows / 8).  Repeatable to a fraction of a per
  * cent, not to the unit (the number of boxes a culling walk tests depends on which rays share its wave), so in a multi-process
  * job ONE rank measures and broadcasts the bands it cut.  Overwrites MI3PT_TEX_OUTPUT like a raytrace pass; needs a scene that admits kernel variants
- * 9 .. 12 (MI3PT_ERR_STATE otherwise). */
+ * 9 .. 13 (MI3PT_ERR_STATE otherwise). */
 int mi3pt_measure_tile_cost(mi3pt_ctx *ctx, uint32_t *cost, size_t ntiles);
 
 /* ---- scene upload: queue.writeBuffer of the structured views ----
@@ -229,9 +231,9 @@ int mi3pt_sync(mi3pt_ctx *ctx);   /* queue.onSubmittedWorkDone(), renderer.ts:42
 /* Default MI3PT_PRESENT_EXACT.  See mi3pt_present_mode. */
 int mi3pt_set_present_mode(mi3pt_ctx *ctx, int mode /* mi3pt_present_mode */);
 /* RAYTRACE|ACCUMULATE submits may be queued inside the library and launched together (up to
- * 64 consecutive frames whose uniforms differ only in `frame` -- 64 x nranks for a rank of a tile
- * split, at most 512, less when memory is short -- run as one kernel + one ordered
- * accumulate).  Every call that observes or changes device state launches the queue first;
+ * 256 consecutive frames whose uniforms differ only in `frame` -- 256 x nranks for a rank of a tile
+ * split, at most 512 (MI3PT_OPT_BATCH, MI3PT_OPT_BATCH_LIMIT), less when memory is short: a quarter of
+ * the free memory bounds the radiance slots -- run as one kernel + one ordered accumulate).  Every call that observes or changes device state launches the queue first;
  * mi3pt_flush does only that, without waiting -- use it before synchronising the stream
  * yourself (e.g. torch.cuda.synchronize()). */
 int mi3pt_flush(mi3pt_ctx *ctx);
@@ -292,11 +294,21 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
  * (one multiplication instead of an exact division each) whenever the two ends of the approximate interval lie more
  * than 2^-21 (relative) apart, which PROVES the reference's decision (csrc/pt_kernels.hip slab_q0; tests/test_slab_filter.py);
  * any other box runs the exact test.  12 = 11 with the culling condition evaluated on one axis only (cheaper, skips
- * less).  Launch flavours other than the batched one (fused, diagnostic, samplesPerFrame != 1) run 10's code under 11 / 12.
- * auto = 10, 11 or 12 when the scene allows the wide walk -- chosen per scene from the tree's statistics (thin leaves
- * met per step; size of the culling margins: csrc/pt_context.hip prepare_cull), speed only -- else 9 (else 7, else 4);
- * MI3PT_OPT_WIDE / MI3PT_OPT_CULL = 0 make auto stop at 9 / 7.  Variants 1-8 execute exactly the reference's tests
- * (counters equal the oracle's); all variants produce the same bits. */
+ * less).  11 and 12 exist in the experiment build only (superseded by 13; a release library runs 10 for them).
+ * 13 = THE SHIPPED WALK (round 4): 10 on COMPRESSED wide packets -- 64 bytes per 4-ary node: a grid origin, three cell exponents
+ * and the four child boxes as 8-bit cell indices rounded OUTWARD by at least one cell -- and 64-byte triangle records that carry
+ * the leaf's own box as uploaded.  Above the leaves a box test only has to never reject what the reference's exact test passes
+ * (boxes nest: a leaf that passes has every ancestor pass), so the node step runs a conservative test on the decoded planes
+ * (one v_cvt_f32_ubyte + one fma per quotient); the leaf's own box is tested EXACTLY in the triangle step, and only leaves that
+ * pass it count as triangle tests.  Half the bytes and half the loads of 10 per node step.  Two instantiations per culling
+ * condition (one axis / three axes, chosen per scene like 12 / 11) x two walk thresholds (32 lanes; 44 for very large trees).
+ * Needs every box of the tree nested in its parent's and finite (any tree of the reference's builder); otherwise 10 runs.
+ * Every reference-legal setting (samplesPerFrame 1 .. 2^24, maxBounces 0 .. 65535, F16 storage, pipelining off) runs this
+ * kernel; launches beyond those packing limits run the per-pixel kernel (2), frame by frame.
+ * auto = 13 when the scene allows the wide walk and its compressed packets could be built -- else 10 (an experiment build: 10,
+ * 11 or 12 by the tree's statistics), else 9, else 7, else 4; MI3PT_OPT_WIDE / MI3PT_OPT_CULL = 0 make auto stop at 9 / 7.
+ * Variants 1-8 execute exactly the reference's tests (counters equal the oracle's); all variants produce the same bits.
+ * mi3pt_debug_active_variant says what a submit would run now, mi3pt_debug_last_launch what the last one ran. */
 int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant);
 /* Scheduling options: how the same work is cut into launches, steps and jobs.  NONE of them changes a bit of any image
  * or a path counter (tests/test_gpu_parity.py holds each to the defaults' output); they exist for the sweeps under
@@ -326,6 +338,9 @@ typedef enum mi3pt_option {
                                    * "warning: ..." text in mi3pt_last_error() and MI3PT_OK returned, once a predecessor is seen to have
                                    * finished without publishing or after the third release */
     MI3PT_OPT_GATE_RELEASES = 23,   /* READ-ONLY: host-side releases so far */
+    MI3PT_OPT_CAMERA_BASE = 25,     /* batched launches load the pixel-only part of a camera ray (uv, cameraToRay's direction, cam_pos + dir0 x
+                                   * focalDistance) from an image formed once per camera, size and tile instead of forming it in every frame of
+                                   * every pixel (1); costs 2 x 16 bytes per pixel of this context's share; 0 = formed in the kernel */
     MI3PT_OPT_DEBUG_SUPPRESS_DRAIN = 24, /* tests: arm the gate but let no kernel publish its mark (forces the situation the time-out exists for) */
     MI3PT_OPT_SLOT_SETS = 15,  /* sets of per-frame radiance slots, 2 or 3; before mi3pt_resize (2) */
     MI3PT_OPT_PIPELINE = 16,   /* = mi3pt_set_pipelining */
@@ -365,8 +380,8 @@ int mi3pt_debug_last_launch(mi3pt_ctx *ctx, int *kind, int *variant, int *lean, 
  * the path's light by the pdf); it needs the CDF texture and uses the per-pixel kernel (no
  * batching).  Default 0 = the shipped behaviour. */
 int mi3pt_set_env_sampling(mi3pt_ctx *ctx, int enabled);
-/* Frame pipelining (default on): RAYTRACE|ACCUMULATE submits are queued; up to 64 consecutive
- * frames whose uniforms differ only in `frame` run as one raytrace launch plus one ordered
+/* Frame pipelining (default on): RAYTRACE|ACCUMULATE submits are queued; up to 256 consecutive
+ * frames (mi3pt_batch_capacity) whose uniforms differ only in `frame` run as one raytrace launch plus one ordered
  * multi-frame running mean, and launches alternate between two internal streams so the next
  * one fills the CUs while the last paths of this one drain.  Any call that observes or
  * changes device state flushes the queue first; results are bit-identical.  Off: one fused

@@ -22,7 +22,7 @@ def run(tile):
 base = run(None)
 print(f"N=1: {base['value']:.0f} Mrays/s, {base['ms_per_step'] * base['steps']:.3f} ms for {base['steps']} steps", flush=True)
 for n in (2, 4, 8):
-    ranks = [run(f"{r}/{n}") for r in (range(n) if n <= 4 else (0, 3, 7))]
+    ranks = [run(f"{r}/{n}") for r in range(n)]          # every rank (round 4 rendered three of the eight)
     t = [j["ms_per_step"] * j["steps"] for j in ranks]
     rays = sum(j["config"]["rays_per_step"] for j in ranks) * (n / len(ranks)) * base["steps"]
     gather_ms = 0.06 + (1920 * 1080 * 16 / n) * (n - 1) / (min(n - 1, 7) * 45e9) * 1e3

@@ -17,6 +17,22 @@ for path in sys.argv[1:]:
             continue
         workload = "demo" if "demo mesh" in name else ("forest" if "forest" in name else ("closeup" if "close-up" in name else "dragon"))
         key = {"workload": workload, "image": image, "frames_per_launch": r["frames_per_launch"], "variant": 0, "n_gpus": j["n_gpus"]}
+        tile = j["config"].get("tile")
+        if tile:
+            # `bench.py --tile R/N`: rank R's share of an N-way split rendered alone on one GPU -- the shape an N-GPU line falls
+            # back to (a rank cannot run counter passes inside the job).  One entry per (N, launch depth): the mean over the ranks measured.
+            rk, n = (int(v) for v in tile.split("/"))
+            key["n_gpus"] = n
+            old = [e for e in entries if all(e[k] == v for k, v in key.items())]
+            ranks = (old[0]["ranks_measured"] if old else []) + [rk]
+            cnt = r["pmc_counters"]
+            if old:
+                k0 = len(old[0]["ranks_measured"])
+                cnt = {c: (old[0]["counters"][c] * k0 + v) / (k0 + 1) for c, v in cnt.items() if c in old[0]["counters"]}
+            entries = [e for e in entries if any(e[k] != v for k, v in key.items())]
+            entries.append(dict(key, counters=cnt, kernel_ms=r["kernel_ms"], ranks_measured=ranks,
+                                source=f"rank-of-{n} shape measured on one GPU (bench.py --tile R/{n}, ranks {ranks}): " + os.path.relpath(os.path.dirname(path), ROOT)))
+            continue
         entries = [e for e in entries if any(e[k] != v for k, v in key.items())]
         entries.append(dict(key, counters=r["pmc_counters"], kernel_ms=r["kernel_ms"], source=os.path.relpath(path, ROOT)))
 with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:

@@ -1198,3 +1198,57 @@ def test_cost_ordered_jobs_lose_and_repeat_nothing(gpu_ctx, demo, env, tile, siz
         gpu_ctx.set_option(capi.OPT_COST_ORDER, 0)
         gpu_ctx.set_tile(0, 1, 8)
         gpu_ctx.resize(64, 64)
+
+
+def test_camera_rays_from_the_precomputed_base_equal_the_in_kernel_ones(gpu_ctx, orc, demo, env):
+    """MI3PT_OPT_CAMERA_BASE (round 5): batched launches load the pixel-only part of a camera ray -- uv, cameraToRay's
+    direction, cam_pos + dir0 * focalDistance (raytrace.wgsl:219-238, 446) -- from an image formed once per camera instead of
+    forming it in every frame.  Same bits with it on and off, against the oracle, and the image follows the camera, the lens,
+    the resolution and the tile split (its cache key) from one launch to the next."""
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+    osc = pc.oracle_scene(orc, demo, env)
+
+    def job(w, h, n, **kw):
+        ctx.reset()
+        ctx.set_uniforms(capi.PASS_RAYTRACE, pc.rt_uniforms(demo, w, h, frame=2, bounces=4, **kw).tobytes())
+        ctx.set_uniforms(capi.PASS_ACCUMULATE, pc.acc_uniforms(w, h, 2).tobytes())
+        ctx.submit_frames(mask, n)
+        return ctx.read_texture(capi.TEX_ACCUMULATION)
+
+    def oracle(w, h, n, rank=0, nranks=1, **kw):
+        acc = np.zeros((orc.tile_local_rows(h, rank, nranks, 8), w, 4), np.float32)
+        for f in range(2, 2 + n):
+            part, _ = orc.raytrace(osc, pc.rt_uniforms(demo, w, h, frame=f, bounces=4, **kw).tobytes(), w, h, rank, nranks, 8)
+            acc = orc.accumulate(pc.acc_uniforms(w, h, f).tobytes(), w, h, part, acc, rank, nranks, 8)
+        return acc
+
+    assert ctx.get_option(capi.OPT_CAMERA_BASE) == 1
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(100, 52)
+    cases = [dict(), dict(position=[0.4, 1.3, 3.0]), dict(position=[0.4, 1.3, 3.0], fov=30.0), dict(aperture=0.05, focal=4.1),
+             dict(aperture=0.05, focal=2.0), dict(aspect=1.0), dict()]
+    for kw in cases:                                    # one context, launch after launch: the key must follow every change
+        got = job(100, 52, 5, **kw)
+        want = oracle(100, 52, 5, **kw)
+        assert pc.same_bits(got, want), (kw, pc.describe_diff(got, want))
+    ctx.set_option(capi.OPT_CAMERA_BASE, 0)
+    off = job(100, 52, 5)
+    ctx.set_option(capi.OPT_CAMERA_BASE, 1)
+    assert pc.same_bits(off, oracle(100, 52, 5))
+    for spf in (2, 3):                                   # a multi-sample frame's later samples take the same base
+        got = job(100, 52, 3, spf=spf)
+        ctx.set_option(capi.OPT_CAMERA_BASE, 0)
+        off = job(100, 52, 3, spf=spf)
+        ctx.set_option(capi.OPT_CAMERA_BASE, 1)
+        assert pc.same_bits(got, off), pc.describe_diff(got, off)
+    # a rank of a tile split, then another size
+    ctx.set_tile(2, 3, 8)
+    ctx.resize(100, 52)
+    got = job(100, 52, 4)
+    assert pc.same_bits(got, oracle(100, 52, 4, 2, 3))
+    ctx.set_tile(0, 1, 8)
+    ctx.resize(64, 64)
+    got = job(64, 64, 4)
+    assert pc.same_bits(got, oracle(64, 64, 4))

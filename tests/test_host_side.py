@@ -410,3 +410,21 @@ def test_tile_deal_helpers_agree_with_each_other_and_the_oracle(built, orc):
         assert (seen >= 0).all()
     assert capi.tile_global_row(8, 0, 4, 8) == 56          # round 1 runs backwards: rank 0's second block is the round's last
     assert capi.tile_global_row(0, 4, 4, 8) == -1 and capi.tile_owner(-1, 4, 8) == -1 and capi.tile_owner(5, 0, 8) == -1
+
+
+def test_balanced_bands_never_cut_twice_at_one_row():
+    """One tile row that holds several ranks' shares of the cost: every rank still gets at least one tile row, no bound repeats
+    (round-4 advice: the same bound was emitted several times and those ranks idled)."""
+    from mi3pt_host import tiles
+    rng = np.random.default_rng(5)
+    for nranks in (2, 4, 8):
+        for trows in (nranks + 1, 17, 135):
+            cost = rng.integers(1, 50, (trows, 30))
+            cost[trows // 3] *= 4000                      # the model's row: far more than a rank's share
+            h = trows * 8 - 3
+            b = tiles.balanced_bands(cost, h, nranks)
+            assert b[0] == 0 and b[-1] == h and len(b) == nranks + 1
+            assert all(b[i] < b[i + 1] for i in range(nranks)), b
+    # a flat cost is split evenly
+    b = tiles.balanced_bands(np.ones((16, 4), np.int64), 128, 4)
+    assert b == [0, 32, 64, 96, 128]

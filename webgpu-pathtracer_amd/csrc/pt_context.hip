@@ -124,6 +124,13 @@ struct mi3pt_ctx {
     int slot_sets = 2;
     int batch_cap = 1;                   // frames per launch at this size (batch limit, tile split, free memory)
     float4 *last_radiance = nullptr;     // the radiance image the most recent raytrace pass wrote
+    // RtLaunch::cam_base: the pixel-only part of the camera rays, one image per launch parity (a launch only ever reads the image
+    // of its own stream, so a moving camera needs no wait: the refill is enqueued on that stream in front of the launch), valid for
+    // the camera / size / tile in cam_base_key
+    float4 *d_cam_base[2] = { nullptr, nullptr };
+    uint8_t cam_base_key[2][80] = {};
+    bool cam_base_valid[2] = { false, false };
+    bool cam_base_enabled = true;        // MI3PT_OPT_CAMERA_BASE
     uint32_t *d_canvas8 = nullptr;
     bool output_is_accum = false;
     uint64_t *d_block_counters = nullptr;
@@ -502,8 +509,10 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
 static void free_textures(mi3pt_ctx *ctx)
 {
     for (void *p : { (void *)ctx->d_radiance, (void *)ctx->d_slots[0], (void *)ctx->d_slots[1], (void *)ctx->d_slots[2], (void *)ctx->d_accum_own,
-                     (void *)ctx->d_canvas, (void *)ctx->d_canvas8, (void *)ctx->d_block_counters })
+                     (void *)ctx->d_canvas, (void *)ctx->d_canvas8, (void *)ctx->d_block_counters, (void *)ctx->d_cam_base[0], (void *)ctx->d_cam_base[1] })
         if (p) (void)hipFree(p);
+    ctx->d_cam_base[0] = ctx->d_cam_base[1] = nullptr;
+    ctx->cam_base_valid[0] = ctx->cam_base_valid[1] = false;
     ctx->d_radiance = ctx->d_slots[0] = ctx->d_slots[1] = ctx->d_slots[2] = ctx->last_radiance = nullptr;
     ctx->slots_alloc[0] = ctx->slots_alloc[1] = ctx->slots_alloc[2] = 0;
     ctx->d_accum_own = ctx->d_accum = ctx->d_canvas = nullptr;
@@ -653,6 +662,7 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
     case MI3PT_OPT_CULL: ctx->cull_enabled = value != 0; break;
     case MI3PT_OPT_WIDE: ctx->wide_enabled = value != 0; break;
     case MI3PT_OPT_GATE: ctx->gate_enabled = value != 0 && ctx->d_drain_flag != nullptr; if (ctx->gate_enabled) ctx->gate_releases = 0; break;
+    case MI3PT_OPT_CAMERA_BASE: ctx->cam_base_enabled = value != 0; break;
     case MI3PT_OPT_GATE_TIMEOUT_MS: if (value < 0) return pt_set_error(MI3PT_ERR_INVALID, "gate time-out must be >= 0 ms"); ctx->gate_timeout_ms = value; break;
     case MI3PT_OPT_GATE_RELEASES: return pt_set_error(MI3PT_ERR_INVALID, "MI3PT_OPT_GATE_RELEASES is read-only");
     case MI3PT_OPT_DEBUG_SUPPRESS_DRAIN: ctx->debug_suppress_drain = value != 0; break;
@@ -707,6 +717,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_CULL: *value = ctx->cull_enabled ? 1 : 0; break;
     case MI3PT_OPT_WIDE: *value = ctx->wide_enabled ? 1 : 0; break;
     case MI3PT_OPT_GATE: *value = ctx->gate_enabled ? 1 : 0; break;
+    case MI3PT_OPT_CAMERA_BASE: *value = ctx->cam_base_enabled ? 1 : 0; break;
     case MI3PT_OPT_GATE_TIMEOUT_MS: *value = ctx->gate_timeout_ms; break;
     case MI3PT_OPT_GATE_RELEASES: *value = ctx->gate_releases; break;
     case MI3PT_OPT_DEBUG_SUPPRESS_DRAIN: *value = ctx->debug_suppress_drain ? 1 : 0; break;
@@ -782,7 +793,8 @@ static int replace_buffer(mi3pt_ctx *ctx, void **dst, const void *bytes, size_t 
 {
     void *fresh = nullptr;
     HIP_TRY(hipMalloc(&fresh, nbytes));
-    hipError_t e = hipMemcpyAsync(fresh, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = ctx_stream_sync(ctx, ctx->stream, "upload");      // (bounded; a large copy from pageable memory blocks the host until the stream gets there)
+    if (e == hipSuccess) e = hipMemcpyAsync(fresh, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);   // copy-on-call: caller may reuse `bytes`
     if (e != hipSuccess) {
         (void)hipFree(fresh);
@@ -1052,6 +1064,7 @@ static int upload_env_like(mi3pt_ctx *ctx, void *dst, const float *rgba, int wid
         return pt_set_error(MI3PT_ERR_INVALID,
                             "Environment texture must be 1024x512 pixels. Please resize the texture and try again.");
     const size_t nbytes = (size_t)width * height * 16;
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream, "upload"));
     HIP_TRY(hipMemcpyAsync(dst, rgba, nbytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     ctx->scene_epoch++;
@@ -1369,6 +1382,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
         HIP_TRY(hipMalloc((void **)&packed, nt * sizeof(TriVerts)));
         pt::launch_pack_vertices(static_cast<const float4 *>(ctx->d_tris), packed, (uint32_t)nt, ctx->stream);
         hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream, "read-back");      // (a copy to pageable memory blocks the host until the stream gets there: the bounded wait comes first)
         if (e == hipSuccess) e = hipMemcpyAsync(tris.data(), packed, nt * sizeof(TriVerts), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);
         (void)hipFree(packed);
@@ -1851,6 +1865,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.waves_per_cu = ctx->waves_per_cu;
     L.num_cus = ctx->num_cus;
     L.service = nullptr;          // (batched launches: a slot of the context's ring, see launch_batch)
+    L.cam_base = nullptr;         // (batched launches: launch_batch)
     L.tile_cost = nullptr;        // (batched launches: launch_batch)
     L.tile_perm = nullptr;
     L.top_packets = ctx->top_packets;
@@ -2073,6 +2088,33 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame *frames, i
             if (!ctx->debug_suppress_drain) { L.drain_flag = ctx->d_drain_flag; L.drain_seq = ctx->launch_seq; }
         } else {
             publish_after = ++ctx->launch_seq;
+        }
+    }
+    // The pixel-only part of the camera rays (RtLaunch::cam_base), formed once per camera / size / tile for this parity's stream:
+    // every frame of every later launch with the same camera loads it.  A host that moves the camera per frame pays one
+    // full-width pass over the pixels per launch instead of the same arithmetic at ~30 of 64 lanes inside the launch.
+    if (ctx->cam_base_enabled && ctx->last_route.kind == 1 && launches) {
+        uint8_t key[80];
+        std::memset(key, 0, sizeof key);
+        std::memcpy(key, first.u_rt, 12);                 // resolution, aspect
+        std::memcpy(key + 12, first.u_rt + 32, 36);       // camera position, direction, fov, focal distance (32 .. 68)
+        const int32_t tl[7] = { L.tile.tex_w, L.tile.tex_h, L.tile.local_rows, L.tile.rank, L.tile.nranks, L.tile.block_rows, L.tile.row0 };
+        std::memcpy(key + 48, tl, sizeof tl);
+        if (!ctx->d_cam_base[par]) {
+            if (hipMalloc((void **)&ctx->d_cam_base[par], L.slot_pixels * sizeof(float4)) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->d_cam_base[par] = nullptr;
+                ctx->cam_base_enabled = false;            // no memory for it: the kernel forms the rays itself, as before
+            }
+            ctx->cam_base_valid[par] = false;
+        }
+        if (ctx->d_cam_base[par]) {
+            if (!ctx->cam_base_valid[par] || std::memcmp(key, ctx->cam_base_key[par], sizeof key) != 0) {
+                pt::launch_camera_base(L, ctx->d_cam_base[par], rs);
+                std::memcpy(ctx->cam_base_key[par], key, sizeof key);
+                ctx->cam_base_valid[par] = true;
+            }
+            L.cam_base = ctx->d_cam_base[par];
         }
     }
     pt::launch_raytrace_setup(L, false, pick_variant(ctx), rs);
@@ -2329,7 +2371,7 @@ extern "C" int mi3pt_measure_tile_cost(mi3pt_ctx *ctx, uint32_t *cost, size_t nt
     if (int rc = prepare_layout(ctx)) return rc;
     if (int rc = prepare_cull(ctx)) return rc;
     const int variant = pick_variant(ctx);
-    if (variant < 9) return pt_set_error(MI3PT_ERR_STATE, "mi3pt_measure_tile_cost: the scene does not admit the culling walks (kernel variants 9 .. 12), whose diagnostic twin does the measuring");
+    if (variant < 9) return pt_set_error(MI3PT_ERR_STATE, "mi3pt_measure_tile_cost: the scene does not admit the culling walks (kernel variants 9 .. 13), whose diagnostic twin does the measuring");
     pt::RtLaunch L = build_launch(ctx, ctx->u_rt, acc_uniforms(ctx));
     const size_t n = (size_t)pt::raytrace_grid_blocks(L.tile);
     if (n != ntiles) return pt_set_error(MI3PT_ERR_INVALID, "mi3pt_measure_tile_cost: ntiles must be ceil(width / 8) * ceil(local rows / 8)");
@@ -2338,6 +2380,7 @@ extern "C" int mi3pt_measure_tile_cost(mi3pt_ctx *ctx, uint32_t *cost, size_t nt
     HIP_TRY(hipMalloc((void **)&d_cost, n * 4));
     hipError_t e = hipMemsetAsync(d_cost, 0, n * 4, ctx->stream);
     L.tile_cost = d_cost;
+    L.block_counters = nullptr;          // a measuring frame is no rendered frame: mi3pt_get_counters does not see it (round-4 advice: a bench's Mrays/s after a measurement was inflated)
     L.service = reinterpret_cast<pt::RtService *>(ctx->d_service + (size_t)SERVICE_SLOTS * service_slot_bytes());
     if (e == hipSuccess) {
         ctx->last_route = pt::raytrace_route(L, variant);
@@ -2345,6 +2388,7 @@ extern "C" int mi3pt_measure_tile_cost(mi3pt_ctx *ctx, uint32_t *cost, size_t nt
         pt::launch_raytrace(L, false, variant, ctx->stream);
         e = hipGetLastError();
     }
+    if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream, "read-back");      // (a copy to pageable memory blocks the host until the stream gets there: the bounded wait comes first)
     if (e == hipSuccess) e = hipMemcpyAsync(cost, d_cost, n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);
     (void)hipFree(d_cost);
@@ -2414,6 +2458,7 @@ extern "C" int mi3pt_read_texture(mi3pt_ctx *ctx, int which, float *dst, size_t 
     }
     if (nfloats != need) return pt_set_error(MI3PT_ERR_INVALID, "destination size does not match the texture");
     if (need == 0) return MI3PT_OK;
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream, "read-back"));      // (a copy to pageable memory blocks the host until the stream gets there: the bounded wait comes first)
     HIP_TRY(hipMemcpyAsync(dst, src, need * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     return MI3PT_OK;
@@ -2433,6 +2478,7 @@ extern "C" int mi3pt_write_texture(mi3pt_ctx *ctx, int which, const float *src, 
     const size_t need = (size_t)ctx->local_rows * ctx->width * 4;
     if (nfloats != need) return pt_set_error(MI3PT_ERR_INVALID, "source size does not match the texture");
     if (need) {
+        HIP_TRY(ctx_stream_sync(ctx, ctx->stream, "write-back"));
         HIP_TRY(hipMemcpyAsync(ctx->d_accum, src, need * 4, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx_stream_sync(ctx, ctx->stream));      // copy-on-call
     }
@@ -2451,6 +2497,7 @@ extern "C" int mi3pt_read_canvas_rgba8(mi3pt_ctx *ctx, uint8_t *dst, size_t nbyt
     const size_t need = (size_t)ctx->width * ctx->height * 4;
     if (nbytes != need) return pt_set_error(MI3PT_ERR_INVALID, "destination size does not match the canvas");
     if (int rc = settle_canvas(ctx)) return rc;
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream, "read-back"));      // (a copy to pageable memory blocks the host until the stream gets there: the bounded wait comes first)
     HIP_TRY(hipMemcpyAsync(dst, ctx->d_canvas8, need, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     return MI3PT_OK;
@@ -2562,6 +2609,7 @@ extern "C" int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT])
     for (int k = 0; k < MI3PT_CNT_COUNT; k++) out[k] = 0;
     if (ctx->nblocks == 0) return MI3PT_OK;
     std::vector<uint64_t> host(2 * (size_t)ctx->nblocks * pt::CNT_COUNT);
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream, "read-back"));      // (a copy to pageable memory blocks the host until the stream gets there: the bounded wait comes first)
     HIP_TRY(hipMemcpyAsync(host.data(), ctx->d_block_counters, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     for (int b = 0; b < 2 * ctx->nblocks; b++)
@@ -2602,6 +2650,7 @@ extern "C" int mi3pt_debug_wave_times(mi3pt_ctx *ctx, int enable, uint64_t *out,
     }
     if (!ctx->d_wave_times) return pt_set_error(MI3PT_ERR_STATE, "wave times are not enabled");
     if (capacity_slots < (size_t)ctx->wave_times_slots) return pt_set_error(MI3PT_ERR_INVALID, "buffer too small");
+    HIP_TRY(ctx_stream_sync(ctx, ctx->stream, "read-back"));      // (a copy to pageable memory blocks the host until the stream gets there: the bounded wait comes first)
     HIP_TRY(hipMemcpyAsync(out, ctx->d_wave_times, (size_t)ctx->wave_times_slots * 128, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     if (slots_out) *slots_out = (size_t)ctx->wave_times_slots;
@@ -2626,6 +2675,7 @@ extern "C" int mi3pt_debug_intersect(mi3pt_ctx *ctx, const float *rays, size_t n
         pt::launch_debug_intersect(scene_refs(ctx), d_rays, n, d_out, pick_walk(ctx), ctx->stream);
         e = hipGetLastError();
     }
+    if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream, "read-back");      // (a copy to pageable memory blocks the host until the stream gets there: the bounded wait comes first)
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * 48, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);
     (void)hipFree(d_rays);
@@ -2714,6 +2764,7 @@ extern "C" int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const fl
         pt::launch_debug_math(fn, d_a, d_b, d_o, n, ctx->stream);
         e = hipGetLastError();
     }
+    if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream, "read-back");      // (a copy to pageable memory blocks the host until the stream gets there: the bounded wait comes first)
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);
     if (d_a) (void)hipFree(d_a);

@@ -237,6 +237,9 @@ struct RtLaunch {
     const uint32_t *tile_perm;   // state-machine kernel, or null: position in the job order -> tile of the frame; the context sorts
                                  // the tiles by measured cost, costliest first, so that a launch's last tickets are its cheapest
                                  // tiles and the drain after the queue has run empty is short (any order renders the same bits)
+    const float4 *cam_base;      // state-machine kernel, or null: per texel of this rank's image, cam_pos + dir0 * focalDistance -- the part of
+                                 // cameraToRay (raytrace.wgsl:219-238, 446) that depends on the PIXEL only, formed once per camera by
+                                 // launch_camera_base instead of once per frame of a batch in the service step (same operations, same bits)
     RtService *service;          // device memory for one RtService block (service_block_bytes()), or null: the tuned twin of the
                                  // state-machine kernel reads its service step's scalars from it (launch_raytrace fills it first)
 };
@@ -250,6 +253,8 @@ RtRoute raytrace_route(const RtLaunch &L, int variant);
 bool raytrace_variant_fuses(int variant);      // can launch_raytrace fold the accumulate pass into this variant's kernel?  (the per-pixel kernels)
 void launch_raytrace_setup(const RtLaunch &L, bool fuse_accumulate, int variant, hipStream_t s);    // before launch_raytrace, same stream
 void launch_raytrace(const RtLaunch &L, bool fuse_accumulate, int variant, hipStream_t s);
+// fills `out` (tile.local_rows x tile.tex_w float4) for RtLaunch::cam_base from L.un / L.tile
+void launch_camera_base(const RtLaunch &L, float4 *out, hipStream_t s);
 void launch_accumulate_batch(const AccUniforms &acc0, const Tile &tile, const float4 *slots, size_t slot_pixels,
                              int nframes, float4 *accum, int store_f16, hipStream_t s);
 void launch_accumulate(const AccUniforms &acc, const Tile &tile, const float4 *input, float4 *accum,

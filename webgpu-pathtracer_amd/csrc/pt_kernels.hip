@@ -1187,6 +1187,35 @@ PT_DEV RtService compute_service(const RtLaunch &L, bool scene_has_nodes)
     return S;
 }
 
+// The pixel-only part of a camera ray (raytrace.wgsl:219-238 and the focal point's base, :446): uv = pixel / resolution,
+// dir0 = cameraToRay's direction, base = cam_pos + dir0 * focalDistance.  A batched launch forms it for every FRAME of a pixel
+// (256 times per launch, ~65 of a camera-path start's ~180 vector instructions, at ~30 of 64 lanes); this kernel forms it once
+// per camera and image size with the very same device functions, full waves, and the service step loads it (one 16-byte load,
+// coalesced along the 8-pixel rows of a tile, issued ahead of the disk sample that hides it).
+__global__ void __launch_bounds__(256) k_camera_base(const RtLaunch L, float4 *out)
+{
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ly = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= L.tile.tex_w || ly >= L.tile.local_rows) return;
+    const RtUniforms &un = L.un;
+    const CameraFrame cf = camera_frame(un);
+    const int pgy = local_to_global_row(ly, L.tile);
+    const bool ordinary = un.res_x >= 9.5367431640625e-07f && un.res_x <= 1.099511627776e12f &&
+                          un.res_y >= 9.5367431640625e-07f && un.res_y <= 1.099511627776e12f;      // (compute_service: res_ordinary)
+    float uvx, uvy;
+    if (ordinary) { uvx = div_pre((float)px, un.res_x, 1.0f / un.res_x); uvy = div_pre((float)pgy, un.res_y, 1.0f / un.res_y); }
+    else { uvx = (float)px / un.res_x; uvy = (float)pgy / un.res_y; }
+    const f3 dir0 = camera_direction(cf, un.aspect, uvx, uvy);
+    const f3 base = F3(un.cam_pos[0], un.cam_pos[1], un.cam_pos[2]) + dir0 * un.focal_distance;
+    out[(size_t)ly * L.tile.tex_w + px] = make_float4(base.x, base.y, base.z, 0.0f);
+}
+
+void launch_camera_base(const RtLaunch &L, float4 *out, hipStream_t s)
+{
+    if (L.tile.tex_w <= 0 || L.tile.local_rows <= 0) return;
+    hipLaunchKernelGGL(k_camera_base, dim3((L.tile.tex_w + 63) / 64, (L.tile.local_rows + 3) / 4), dim3(256), 0, s, L, out);
+}
+
 __global__ void __launch_bounds__(64) k_rt_service_setup(const RtLaunch L, RtService *out)
 {
     const RtService S = compute_service(L, L.scene.nnodes != 0);
@@ -2112,13 +2141,23 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     // afterwards and what it leaves in them is never read: a branch around the ray makes the compiler form o, d, the slot word,
                     // light and throughput in temporaries and copy them home where the two paths meet, 22 moves per step in EVERY launch)
                 }
-                if (ASSUME || res_ordinary_ != 0) { uvx = div_pre((float)pxx, un.res_x, inv_res_x); uvy = div_pre((float)pyy, un.res_y, inv_res_y); }
-                else { uvx = (float)pxx / un.res_x; uvy = (float)pyy / un.res_y; }
-                const f3 dir0 = camera_direction(cf, un.aspect, uvx, uvy);
+                // the pixel-only part -- uv, cameraToRay's direction, cam_pos + dir0 * focalDistance -- comes ready-made where the
+                // context has formed it for this camera (L.cam_base: k_camera_base, the same operations on the same values); the
+                // load is issued here, ahead of the disk sample below, whose ~70 instructions hide it
+                f3 fbase;
+                if (L.cam_base) {
+                    const float4 cb = L.cam_base[gx];
+                    fbase = xyz(cb);
+                } else {
+                    if (ASSUME || res_ordinary_ != 0) { uvx = div_pre((float)pxx, un.res_x, inv_res_x); uvy = div_pre((float)pyy, un.res_y, inv_res_y); }
+                    else { uvx = (float)pxx / un.res_x; uvy = (float)pyy / un.res_y; }
+                    const f3 dir0 = camera_direction(cf, un.aspect, uvx, uvy);
+                    fbase = cam_pos + dir0 * un.focal_distance;
+                }
                 float jx, jy, kx, ky;
                 rand_point_in_circle(seed, jx, jy);
                 const f3 jitter = F3(jx * inv_res_x, jy * inv_res_y, 0.0f);
-                const f3 focal = (cam_pos + dir0 * un.focal_distance) + jitter;
+                const f3 focal = fbase + jitter;
                 if (pinhole) {
                     // aperture == 0 (the reference's default, scene.ts:9): the lens offset is (+-0, +-0, 0) whatever the
                     // disk sample is (finite * 0), and cam_pos + (+-0) == cam_pos bit for bit unless a coordinate of

@@ -43,8 +43,11 @@ def balanced_bands(tile_cost, height, nranks, floor_per_pixel=0.0):
     acc, r = 0, 1
     for t in range(nrows_t):
         acc += int(row_cost[t])
-        # cut after tile row t once this rank has its share -- leaving at least one tile row for every rank still to come
-        while r < nranks and acc * nranks >= total * r and nrows_t - (t + 1) >= nranks - r:
+        # cut after tile row t once this rank has its share -- at most ONE cut per tile row (a row that holds several ranks' shares
+        # used to be cut several times at the same place: empty bands, idle ranks; round-4 advice) and leaving at least one tile row
+        # for every rank still to come (when exactly that many rows are left, every one of them is a cut)
+        left, waiting = nrows_t - (t + 1), nranks - r
+        if r < nranks and left >= waiting and (acc * nranks >= total * r or left == waiting):
             bounds.append(min((t + 1) * 8, height))
             r += 1
     while len(bounds) < nranks:
