@@ -341,6 +341,9 @@ typedef enum mi3pt_option {
     MI3PT_OPT_CAMERA_BASE = 25,     /* batched launches load the pixel-only part of a camera ray (uv, cameraToRay's direction, cam_pos + dir0 x
                                    * focalDistance) from an image formed once per camera, size and tile instead of forming it in every frame of
                                    * every pixel (1); costs 2 x 16 bytes per pixel of this context's share; 0 = formed in the kernel */
+    MI3PT_OPT_PACKET_ORDER = 26,    /* numbering of the 4-ary packets in device memory: 0 breadth-first (the reference's flattenBVH order carried
+                                   * over), 1 depth-first, 2 treelets of three levels; the walk follows references, any numbering renders the
+                                   * same bits.  Applied at the next scene analysis (0) */
     MI3PT_OPT_DEBUG_SUPPRESS_DRAIN = 24, /* tests: arm the gate but let no kernel publish its mark (forces the situation the time-out exists for) */
     MI3PT_OPT_SLOT_SETS = 15,  /* sets of per-frame radiance slots, 2 or 3; before mi3pt_resize (2) */
     MI3PT_OPT_PIPELINE = 16,   /* = mi3pt_set_pipelining */

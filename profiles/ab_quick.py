@@ -3,7 +3,8 @@
 MI3PT_LIBRARY, which the Python host reads).  The scenes are generated once and handed to the child processes as pickles; every
 (round, library) is a fresh process.  Per leg: the driver's job shape (80 warm-up frames, then 320 frames in 64-frame launches,
 1920x1080, 8 bounces), wall clock around submit .. sync, Mrays/s from the kernel's own ray count.
-usage: python profiles/ab_quick.py ROUNDS lib1.so lib2.so ... [--scenes dragon,demo,closeup,forest] [--tile R/N] [--frames 320] [--variants 0,13] [--walk-min N] [--batch FRAMES_PER_LAUNCH]"""
+usage: python profiles/ab_quick.py ROUNDS lib1.so lib2.so ... [--scenes dragon,demo,closeup,forest] [--tile R/N] [--frames 320] [--variants 0,13] [--walk-min N] [--batch FRAMES_PER_LAUNCH]
+       [--opt-legs "25=0;25=1"]   (legs of mi3pt_debug_set_option settings, "option=value[,option=value]" each, run for every library)"""
 import os, pickle, subprocess, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "webgpu-pathtracer_amd", "py")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -34,6 +35,8 @@ def child():
             ctx.set_option(capi.OPT_WALK_MIN, int(opt("--walk-min", "0")))
         if "--batch" in sys.argv:                  # frames per launch (MI3PT_OPT_BATCH; before resize)
             ctx.set_option(capi.OPT_BATCH, int(opt("--batch", "64")))
+        for kv in [x for x in opt("--opts", "").split(",") if x]:
+            ctx.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
         pc.upload_scene(ctx, sc, env)
         ctx.set_tile(tile[0], tile[1], 8)
         ctx.resize(W, H)
@@ -77,13 +80,16 @@ def main():
         pickle.dump(sc, open(path, "wb"), protocol=4)
     extra = [a for k in ("--tile", "--frames", "--walk-min", "--batch") if k in sys.argv for a in (k, opt(k, ""))]
     variants = opt("--variants", "0").split(",")          # several kernel variants of each library, e.g. --variants 0,13
+    legs = opt("--opt-legs", "").split(";")
     for r in range(rounds):
         for lib in libs:
             for v in variants:
-                env = dict(os.environ, MI3PT_LIBRARY=os.path.abspath(lib))
-                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", d, ",".join(names), *extra, "--variant", v], env=env, capture_output=True, text=True, timeout=600)
-                line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "FAILED: " + p.stderr[-300:]
-                print(f"{os.path.basename(lib):24s} variant {v:>2s}  {line}", flush=True)
+                for leg in legs:
+                    env = dict(os.environ, MI3PT_LIBRARY=os.path.abspath(lib))
+                    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", d, ",".join(names), *extra, "--variant", v, *(["--opts", leg] if leg else [])],
+                                       env=env, capture_output=True, text=True, timeout=600)
+                    line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "FAILED: " + p.stderr[-300:]
+                    print(f"{os.path.basename(lib):24s} variant {v:>2s} {leg:12s} {line}", flush=True)
 
 
 if __name__ == "__main__":

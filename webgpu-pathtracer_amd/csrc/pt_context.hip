@@ -131,6 +131,7 @@ struct mi3pt_ctx {
     uint8_t cam_base_key[2][80] = {};
     bool cam_base_valid[2] = { false, false };
     bool cam_base_enabled = true;        // MI3PT_OPT_CAMERA_BASE
+    int packet_order = 0;                // MI3PT_OPT_PACKET_ORDER: numbering of the wide packets in memory (prepare_cull): 0 breadth-first, 1 depth-first, 2 treelets
     uint32_t *d_canvas8 = nullptr;
     bool output_is_accum = false;
     uint64_t *d_block_counters = nullptr;
@@ -663,6 +664,10 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
     case MI3PT_OPT_WIDE: ctx->wide_enabled = value != 0; break;
     case MI3PT_OPT_GATE: ctx->gate_enabled = value != 0 && ctx->d_drain_flag != nullptr; if (ctx->gate_enabled) ctx->gate_releases = 0; break;
     case MI3PT_OPT_CAMERA_BASE: ctx->cam_base_enabled = value != 0; break;
+    case MI3PT_OPT_PACKET_ORDER:
+        if (value < 0 || value > 2) return pt_set_error(MI3PT_ERR_INVALID, "packet order: 0 breadth-first, 1 depth-first, 2 treelets");
+        if (ctx->packet_order != value) { ctx->packet_order = value; ctx->cull_dirty = true; }
+        break;
     case MI3PT_OPT_GATE_TIMEOUT_MS: if (value < 0) return pt_set_error(MI3PT_ERR_INVALID, "gate time-out must be >= 0 ms"); ctx->gate_timeout_ms = value; break;
     case MI3PT_OPT_GATE_RELEASES: return pt_set_error(MI3PT_ERR_INVALID, "MI3PT_OPT_GATE_RELEASES is read-only");
     case MI3PT_OPT_DEBUG_SUPPRESS_DRAIN: ctx->debug_suppress_drain = value != 0; break;
@@ -718,6 +723,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_WIDE: *value = ctx->wide_enabled ? 1 : 0; break;
     case MI3PT_OPT_GATE: *value = ctx->gate_enabled ? 1 : 0; break;
     case MI3PT_OPT_CAMERA_BASE: *value = ctx->cam_base_enabled ? 1 : 0; break;
+    case MI3PT_OPT_PACKET_ORDER: *value = ctx->packet_order; break;
     case MI3PT_OPT_GATE_TIMEOUT_MS: *value = ctx->gate_timeout_ms; break;
     case MI3PT_OPT_GATE_RELEASES: *value = ctx->gate_releases; break;
     case MI3PT_OPT_DEBUG_SUPPRESS_DRAIN: *value = ctx->debug_suppress_drain ? 1 : 0; break;
@@ -1606,6 +1612,54 @@ static int prepare_cull(mi3pt_ctx *ctx)
                 p.cull01 = (cw[0] << 16) | cw[1];
                 p.cull23 = (cw[2] << 16) | cw[3];
             }
+            // ---- numbering of the packets in memory (MI3PT_OPT_PACKET_ORDER; the walk follows references, so any numbering with
+            // the root at 0 renders the same bits).  Breadth-first (the reference's flattenBVH order carried over, raytrace.ts:667-694)
+            // keeps each LEVEL together; depth-first (pre-order) keeps each SUBTREE together: the deep part of a walk -- most of the
+            // distinct packets it touches in a tree of millions -- then stays within a few pages; treelets: the top three levels of a
+            // subtree breadth-first (up to 21 packets, 1.3 KB), then each of its frontier subtrees the same way.
+            if (ctx->packet_order != 0 && wp.size() > 1) {
+                const size_t nw = wp.size();
+                std::vector<uint32_t> order;
+                order.reserve(nw);
+                auto internal_kids = [&](uint32_t w, uint32_t *out) { int m = 0; for (int k = 0; k < 4; k++) { const uint32_t r = wp[w].ref[k]; if (r != pt::REF_NONE && !(r & pt::REF_LEAF)) out[m++] = r; } return m; };
+                std::vector<uint32_t> work;
+                work.push_back(0u);
+                while (!work.empty()) {
+                    const uint32_t top = work.back();
+                    work.pop_back();
+                    if (ctx->packet_order == 1) {
+                        order.push_back(top);
+                        uint32_t ks[4];
+                        const int m = internal_kids(top, ks);
+                        for (int k = m - 1; k >= 0; k--) work.push_back(ks[k]);          // (first child next)
+                    } else {
+                        std::vector<uint32_t> level(1, top), next, frontier;
+                        for (int depth = 0; depth < 3; depth++) {
+                            next.clear();
+                            for (uint32_t w : level) {
+                                order.push_back(w);
+                                uint32_t ks[4];
+                                const int m = internal_kids(w, ks);
+                                for (int k = 0; k < m; k++) next.push_back(ks[k]);
+                            }
+                            level.swap(next);
+                        }
+                        for (size_t k = level.size(); k-- > 0;) work.push_back(level[k]);
+                    }
+                }
+                if (order.size() == nw) {
+                    std::vector<uint32_t> newid(nw);
+                    for (size_t i = 0; i < nw; i++) newid[order[i]] = (uint32_t)i;
+                    std::vector<pt::WidePacket> moved(nw);
+                    for (size_t w = 0; w < nw; w++) {
+                        pt::WidePacket q = wp[w];
+                        for (int k = 0; k < 4; k++)
+                            if (q.ref[k] != pt::REF_NONE && !(q.ref[k] & pt::REF_LEAF)) q.ref[k] = newid[q.ref[k]];
+                        moved[newid[w]] = q;
+                    }
+                    wp.swap(moved);
+                }
+            }
             if (int rc = replace_buffer(ctx, &ctx->d_wide, wp.data(), wp.size() * sizeof(pt::WidePacket))) return rc;
             // ---- compressed wide packets + 64-byte triangle records (kernel variant 13): the same packets with the boxes on a
             // per-node 8-bit grid, rounded outward by at least one cell; the exact test moves to the leaf's own box, which travels
@@ -1869,6 +1923,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.tile_cost = nullptr;        // (batched launches: launch_batch)
     L.tile_perm = nullptr;
     L.top_packets = ctx->top_packets;
+    if (pick_variant(ctx) == 13 && (size_t)L.top_packets > ctx->nwide) L.top_packets = (int)ctx->nwide;      // (A/B builds that stage compressed packets in LDS)
     if (pick_variant(ctx) == 1) L.scene.tris = static_cast<const float4 *>(ctx->d_tris);    // uploaded records, uploaded indices
     return L;
 }

@@ -1256,6 +1256,11 @@ PT_DEV T uniform_block(const T &v)
 #define PT_CW_NO_PAIR_TEST 0
 #endif
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
+#ifdef PT_X_TOP_CW
+#define PT_X_TOP_CW_N PT_X_TOP_CW
+#else
+#define PT_X_TOP_CW_N 8
+#endif
 #define PT_SM_TOP_PACKETS 32       // node packets staged in LDS per wave (2 KB: 16 waves per CU still fit): the top 5 levels
 // TOPLDS = true additionally stages the first PT_SM_TOP_PACKETS node packets in LDS (kernel
 // variant 6).  Measured on MI355X (round 1): no gain -- the kernel is
@@ -1324,17 +1329,19 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     // PT_SM_TOP_PACKETS of them ARE the top levels of the tree (raytrace.ts:667-678), which
     // every ray walks.  One-wave workgroups (a multi-wave workgroup would hold its LDS and
     // wave slots until its slowest wave has drained) => a private 4 KB copy per wave.
-    __shared__ float4 top_lds[TOPLDS ? PT_SM_TOP_PACKETS * 4 : 1];
+    // (compressed-wide walk, build flag PT_X_TOP_CW = n <= 8: 20 waves x 7 680 B leave 512 B per wave of the CU's 160 KiB -- eight 64-byte packets)
+    constexpr int TOPN = (TOPLDS && CW) ? PT_X_TOP_CW_N : PT_SM_TOP_PACKETS;
+    __shared__ float4 top_lds[TOPLDS ? TOPN * 4 : 1];
     // A path's throughput and collected light are only touched by the service step; between service steps they rest here
     // (6 floats per lane, [k][lane]) instead of in six registers carried through every node and triangle step
     __shared__ float park_lds[6 * 64];
     const int lane = threadIdx.x;
     float *park = park_lds + lane;
     uint32_t *stack = stack_lds + lane;
-    const uint32_t top_cap = (uint32_t)L.top_packets < (uint32_t)PT_SM_TOP_PACKETS ? (uint32_t)L.top_packets : (uint32_t)PT_SM_TOP_PACKETS;
-    const uint32_t ntop = !TOPLDS ? 0u : (L.scene.npackets < top_cap ? L.scene.npackets : top_cap);
+    const uint32_t top_cap = (uint32_t)L.top_packets < (uint32_t)TOPN ? (uint32_t)L.top_packets : (uint32_t)TOPN;
+    const uint32_t ntop = !TOPLDS ? 0u : (CW ? top_cap : (L.scene.npackets < top_cap ? L.scene.npackets : top_cap));      // (CW: the host caps top_packets by the number of wide packets)
     if (TOPLDS) {
-        for (uint32_t i = (uint32_t)lane; i < ntop * 4u; i += 64u) top_lds[i] = L.scene.packets[i];
+        for (uint32_t i = (uint32_t)lane; i < ntop * 4u; i += 64u) top_lds[i] = CW ? L.scene.cwide[i] : L.scene.packets[i];
         __syncthreads();
     }
     uint32_t *ovf = L.stack_overflow + (size_t)blockIdx.x * ((PT_MAX_STACK - PT_SM_LDS_DEPTH) * 64) + lane;
@@ -1620,7 +1627,11 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                     if constexpr (CW) {
                         // compressed wide packet: 64 bytes, boxes on the node's 8-bit grid, rounded outward (CWidePacket; cwide_hit)
                         const float4 *P = sc.cwide + (size_t)ref * 4;
-                        const float4 c0 = P[0], c1 = P[1], c2 = P[2], c3 = P[3];
+                        float4 c0, c1, c2, c3;
+                        if (TOPLDS && ref < ntop) {       // top of the tree: this wave's LDS copy
+                            c0 = top_lds[ref * 4 + 0]; c1 = top_lds[ref * 4 + 1]; c2 = top_lds[ref * 4 + 2]; c3 = top_lds[ref * 4 + 3];
+                            asm volatile("" : "+v"(c0.x), "+v"(c1.x), "+v"(c2.x), "+v"(c3.x));   // keep these ds_read_b128
+                        } else { c0 = P[0]; c1 = P[1]; c2 = P[2]; c3 = P[3]; }
                         cr[0] = __float_as_uint(c3.x); cr[1] = __float_as_uint(c3.y); cr[2] = __float_as_uint(c3.z); cr[3] = __float_as_uint(c3.w);
                         const uint32_t meta = __float_as_uint(c0.w);
                         w01 = __float_as_uint(c2.z); w23 = __float_as_uint(c2.w); nchild = (meta >> 24) & 7u;
@@ -2444,13 +2455,18 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
             default: PT_SM(true,  true,  true,  false, false, false, false, true); break;
         } else
 #endif
+#ifndef PT_X_TOP_CW
+#define PT_TOP_CW false
+#else
+#define PT_TOP_CW true          // (A/B build: the first PT_X_TOP_CW compressed packets staged in LDS per wave)
+#endif
         if (r.lean && r.variant == 13) {        // compressed wide packets (SceneRefs::flags bit 2: the one-axis culling condition suits this scene)
             if (L.walk_min == PT_DEEP_WALK_MIN) {
-                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, false, false, true, PT_DEEP_WALK_MIN);
-                else PT_SM(true, true, true, true, false, false, false, false, true, PT_DEEP_WALK_MIN);
+                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN);
+                else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN);
             } else {
-                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, false, false, true);
-                else PT_SM(true, true, true, true, false, false, false, false, true);
+                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true);
+                else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true);
             }
         } else
         if (r.lean) switch (r.variant) {
