@@ -31,9 +31,10 @@ by the kernel), plus
                  lane-operations per second (SQ_INSTS_VALU x 64 x lane utilisation / kernel time),
                  `peak` = CUs x 4 SIMDs x 2.4 GHz / 2 x 64 lanes, `frac` = achieved / peak =
                  valu_issue_frac x lane_utilisation.  The memory side is reported beside it:
-                 `traffic` = HBM-side bytes per launch from rocprofv3 PMC passes of THIS command line
-                 (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md), `hbm` =
-                 traffic / kernel time against 8 TB/s, `l2` = (TCC_HIT + TCC_MISS) x 128 B / kernel
+                 `traffic` = fabric-side bytes (L2 misses) per launch from rocprofv3 PMC passes of THIS
+                 command line (FETCH_SIZE x 1 + WRITE_SIZE: the factor calibrated on this kernel's own
+                 access shapes, profiles/r05_fetch_calibration.log), `hbm` = traffic / kernel time
+                 against 8 TB/s and against what a pure random-64-byte-gather kernel reaches, `l2` = (TCC_HIT + TCC_MISS) x 128 B / kernel
                  time against the guide's 34.5 TB/s, `algorithmic_GBps` as SURVEY.md defines it.
                  Kernel time = the launches' exclusive share of the GPU clock (`kernel_ms_exclusive`:
                  consecutive launches overlap at their tails), from HIP event pairs on the streams
@@ -68,6 +69,9 @@ BLOCK_ROWS = int(os.environ.get("MI3PT_BENCH_BLOCK_ROWS", "8"))     # rows per b
 BOUNCES = 8
 FRAMES_PER_STEP = 16            # one step = one batch = one launch of the persistent kernel (single GPU)
 L2_PEAK_GBS = 34500.0           # same guide: L2 (8 x 4 MiB), aggregate
+FETCH_FACTOR = 1.0              # bytes per (FETCH_SIZE x 1024) for this kernel's divergent 64-byte gathers: measured, profiles/r05_fetch_calibration.log
+GATHER64_HBM_GBS = 1640.0       # same log: random 64-byte gathers (4 x 16 B per lane) out of a 4 GiB table, useful bytes
+GATHER64_MALL_GBS = 3500.0      # ... out of a 128 MiB table (resident in the Infinity Cache)
 KERNEL_NEEDLE = "k_raytrace_sm"
 # counter groups of the PMC passes: one rocprofv3 run each (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
@@ -369,7 +373,7 @@ def roofline_block(m, pmc, source, num_cus):
     alg_gbps = alg_per_launch / t_s / 1e9 if t_s > 0 else None
     traffic = None
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-        traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
+        traffic = int((FETCH_FACTOR * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
     hbm = traffic / t_s / 1e9 if traffic is not None and t_s > 0 else None
     lane_peak = num_cus * 4 * SHADER_CLOCK_HZ / 2.0 * 64.0          # VALU lane-operations per second, all SIMDs
     issue_frac = lane_util = lane_rate = None
@@ -385,12 +389,22 @@ def roofline_block(m, pmc, source, num_cus):
         "frac": round(lane_rate / lane_peak, 4) if lane_rate is not None else None,
         "frac_rule": "SQ_INSTS_VALU x 64 x lane_utilisation / kernel time / (CUs x 4 SIMDs x 2.4 GHz / 2 x 64 lanes) = valu_issue_frac x lane_utilisation",
         "traffic": traffic, "traffic_source": source,
-        "traffic_rule": "(2 x FETCH_SIZE + WRITE_SIZE) KB per launch, separate rocprofv3 --pmc passes, mean over the timed launches "
-                        "(MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B); L2-to-fabric bytes, Infinity-Cache hits included",
+        "traffic_rule": f"({FETCH_FACTOR:g} x FETCH_SIZE + WRITE_SIZE) KB per launch, separate rocprofv3 --pmc passes, mean over the timed launches.  "
+                        "FETCH_SIZE = 64 B x L2-to-fabric read requests; calibrated on known byte counts in this kernel's own access shapes "
+                        "(profiles/fetch_calibration.hip, r05_fetch_calibration.log): bytes / FETCH_SIZE = 1.000 for divergent gathers of 64-byte records "
+                        "(this kernel's packets and triangle records), 2.000 only for wide coalesced streaming reads (MI355X_MICROARCH.md's case), which "
+                        "this kernel does not make.  L2 MISSES, whoever serves them: the same gathers out of a table resident in the Infinity Cache "
+                        "count the same -- fabric-side traffic, an upper bound of the HBM traffic (no TCC counter separates the two)",
         "hbm": {"achieved": round(hbm, 1) if hbm is not None else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(hbm / HBM_PEAK_GBS, 4) if hbm is not None else None,
                 "peak_achievable": HBM_ACHIEVABLE_GBS,
-                "frac_of_achievable": round(hbm / HBM_ACHIEVABLE_GBS, 4) if hbm is not None else None},
+                "frac_of_achievable": round(hbm / HBM_ACHIEVABLE_GBS, 4) if hbm is not None else None,
+                # what a kernel that does nothing but this access shape reaches (profiles/r05_fetch_calibration.log): random 64-byte
+                # records, four 16-byte loads per lane, one-wave workgroups -- out of a 4 GiB table (HBM) and out of a 128 MiB one
+                # (Infinity Cache).  The roof of a gather-bound walk; the byte peak above is a streaming kernel's
+                "random_64B_gather_roof_GBps": {"from_hbm": GATHER64_HBM_GBS, "from_infinity_cache": GATHER64_MALL_GBS},
+                "frac_of_gather_roof": {"from_hbm": round(hbm / GATHER64_HBM_GBS, 4) if hbm is not None else None,
+                                        "from_infinity_cache": round(hbm / GATHER64_MALL_GBS, 4) if hbm is not None else None}},
         "kernel": m["kernel"], "kernel_ms": round(kernel_ms, 4), "kernel_ms_exclusive": round(m["kernel_ms_exclusive"], 4),
         "launches_timed": m["launches"], "frames_per_launch": m["frames_per_launch"],
         "kernel_ms_all_launches": round(m["kernel_ms_all"], 4), "launches_all": m["launches_all"],
@@ -766,6 +780,12 @@ def main():
                                          "(BASELINE.json config 5's scene; its own image, 3840x2160 on 8 GPUs, is a parity-test case)",
                              "scene_bytes": int(len(fj.sc.triangles) * 112 + len(fj.sc.nodes) * 48),
                              "roofline": roofline_block(forest, fpmc, fsource, capi_num_cus())}
+            fr = out["forest"]["roofline"]
+            if fr.get("hbm", {}).get("achieved") is not None:
+                fr["real_bound"] = ("the memory system's random-gather rate: this 2 GB scene does not fit the Infinity Cache; its L2 misses are divergent 64-byte sector "
+                                    f"requests at {fr['hbm']['achieved']:.0f} GB/s = {fr['hbm']['frac_of_gather_roof']['from_hbm']:.2f} of what a kernel that does nothing but such "
+                                    "gathers reaches out of HBM (profiles/r05_fetch_calibration.log), while its waves wait for memory more than they issue; the "
+                                    "vector-ALU fraction (frac) is reported for comparison with the other workloads")
             if flog:
                 out["forest"]["roofline"]["pmc_log"] = flog
         if args.tile:

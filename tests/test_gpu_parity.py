@@ -1252,3 +1252,26 @@ def test_camera_rays_from_the_precomputed_base_equal_the_in_kernel_ones(gpu_ctx,
     ctx.resize(64, 64)
     got = job(64, 64, 4)
     assert pc.same_bits(got, oracle(64, 64, 4))
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_packet_numbering_in_memory_does_not_change_a_bit(built, orc, demo, env, order):
+    """MI3PT_OPT_PACKET_ORDER: the 4-ary packets numbered depth-first (1) or in three-level treelets (2) instead of breadth-first.
+    The walk follows references: same image, same counters (its own context: the option re-runs the scene analysis)."""
+    w, h = 96, 80
+    u = pc.rt_uniforms(demo, w, h, frame=3, bounces=6)
+    want, ocnt = orc.raytrace(pc.oracle_scene(orc, demo, env), u.tobytes(), w, h)
+    with capi.Context(0) as ctx:
+        outs = []
+        for o in (0, order):
+            ctx.set_option(capi.OPT_PACKET_ORDER, o)
+            pc.upload_scene(ctx, demo, env)
+            ctx.resize(w, h)
+            ctx.reset_counters()
+            pc.gpu_frame(ctx, u)
+            outs.append((ctx.read_texture(capi.TEX_OUTPUT), ctx.counters()))
+            assert ctx.active_variant() == 13 and ctx.get_option(capi.OPT_PACKET_ORDER) == o
+        for img, cnt in outs:
+            assert pc.same_bits(img, want), pc.describe_diff(img, want)
+            pc.check_counters(cnt, ocnt, culled=True)
+        assert outs[0][1] == outs[1][1]
