@@ -1716,6 +1716,12 @@ static int prepare_cull(mi3pt_ctx *ctx)
                                 const double f0 = std::floor(x0) - 1.0, f1 = std::ceil(x1) + 1.0;
                                 if (!(f0 >= 0.0 && f1 <= 254.0 && f0 < f1)) { ok = false; break; }
                                 a = (uint32_t)f0; z = (uint32_t)f1;
+                                // ... and checked the way the kernel's plain-division path DECODES a plane, one fp32 fma: RN(o + cell q) is not
+                                // exact in general (o is an arbitrary fp32 value, not a multiple of the cell), but round-to-nearest is monotone and
+                                // the child's plane is itself an fp32 value, so a real plane a whole cell outside it cannot round to its inside.
+                                // Verified per plane rather than argued (round-4 advice): a packet that failed would send the tree to the exact packets.
+                                const float cf = (float)cell;
+                                if (!(std::fma((float)a, cf, o) <= b[ax] && std::fma((float)z, cf, o) >= b[3 + ax])) { ok = false; break; }
                             }
                             qlo |= a << (8 * k); qhi |= z << (8 * k);
                         }

@@ -1675,8 +1675,10 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
                                          "=v"(tn[2].x), "=v"(tn[2].y), "=v"(tn[2].z), "=v"(tn[3].x), "=v"(tn[3].y), "=v"(tn[3].z));
                             }
                             // a ray on the plain-division path (a parallel axis, an out-of-range component): the reference's test on the
-                            // decoded box -- exact fp32 coordinates (o + cell * q is representable: the builder keeps cells coarse
-                            // against the coordinates), a box that contains the child's: monotone, hence conservative too
+                            // decoded box.  The decoded planes RN(o + cell q) are NOT exact in general (o is not a multiple of the cell), but
+                            // round-to-nearest is monotone and the builder moved every plane outward by at least a whole cell, so the decoded
+                            // box still contains the child's (prepare_cull verifies exactly this fma for every plane of every packet) -- and
+                            // the reference's test is monotone under containment, hence conservative too
 #pragma unroll
                             for (int k = 0; k < 4; k++)
                                 hit[k] = ray_aabb(o, d, fmaf((float)((lx >> (8 * k)) & 0xffu), cx, c0.x), fmaf((float)((ly >> (8 * k)) & 0xffu), cy, c0.y), fmaf((float)((lz >> (8 * k)) & 0xffu), cz, c0.z),
