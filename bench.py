@@ -782,10 +782,13 @@ def main():
                              "roofline": roofline_block(forest, fpmc, fsource, capi_num_cus())}
             fr = out["forest"]["roofline"]
             if fr.get("hbm", {}).get("achieved") is not None:
-                fr["real_bound"] = ("the memory system's random-gather rate: this 2 GB scene does not fit the Infinity Cache; its L2 misses are divergent 64-byte sector "
+                fr["real_bound"] = ("per-wave latency of dependent gathers: this 2 GB scene does not fit the Infinity Cache; its L2 misses are divergent 64-byte sector "
                                     f"requests at {fr['hbm']['achieved']:.0f} GB/s = {fr['hbm']['frac_of_gather_roof']['from_hbm']:.2f} of what a kernel that does nothing but such "
-                                    "gathers reaches out of HBM (profiles/r05_fetch_calibration.log), while its waves wait for memory more than they issue; the "
-                                    "vector-ALU fraction (frac) is reported for comparison with the other workloads")
+                                    f"gathers reaches out of HBM and {fr['hbm']['frac_of_gather_roof']['from_infinity_cache']:.2f} of what it reaches out of the Infinity Cache "
+                                    "(profiles/r05_fetch_calibration.log); a fabric request is outstanding for ~650 L2 cycles on average (TCC_EA0_RDREQ_LEVEL / "
+                                    "TCC_EA0_RDREQ, profiles/r05_e_fabric_latency.log) -- the same as on the cache-resident 181 MB scene and half of what the "
+                                    "saturated gather probe shows -- so the memory system is not saturated: every node step waits for the slowest of its lanes' "
+                                    "round trips, and its waves wait for memory more than they issue; frac is the vector-ALU lane-op fraction, as for the other workloads")
             if flog:
                 out["forest"]["roofline"]["pmc_log"] = flog
         if args.tile:

@@ -14,10 +14,12 @@ cd $ROOT
 # Order matters on this pool: a box that has just run counter (--pmc) passes is slow for a while (clocks), so everything
 # that is timed without counters runs first, and the three bench lines -- each ends with its own counter passes -- are
 # spaced out.
+if [ -z "${SKIP_SCALING:-}" ]; then      # (every rank of every split since round 5: ~3 minutes each; SKIP_SCALING=1 when it ran in a call of its own)
 python profiles/scaling_model.py --steps 20 --warmup 5 > $OUT/${TAG}_scaling_model_steps20.log 2>&1
 python profiles/scaling_model.py --steps 16 --warmup 2 > $OUT/${TAG}_scaling_model_steps16.log 2>&1
 python profiles/scaling_model.py --steps 4 --warmup 1 > $OUT/${TAG}_scaling_model_steps4.log 2>&1
 echo "scaling model done"
+fi
 (python profiles/cull_probe.py demo; python profiles/cull_probe.py dragon; python profiles/cull_probe.py forest 3840x2160 8) > $OUT/${TAG}_cull_probe.log 2>&1
 echo "cull probe done"
 # wave timelines: the LEAN kernel with lane counts (experiment build: what ships + a dozen scalar counters, five waves) and the
