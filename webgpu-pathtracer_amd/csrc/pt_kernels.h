@@ -17,9 +17,15 @@ constexpr int PT_MAX_RESIDENT_WAVES = 256 * 24;
 #define PT_SM_LDS_DEPTH_VALUE 24
 #endif
 constexpr int SM_LDS_DEPTH = PT_SM_LDS_DEPTH_VALUE;
+// ... and of the SIX-waves-per-SIMD builds (round 5: the compressed-wide walk of ordinary trees): 24 one-wave workgroups per CU leave
+// 6 826 B each, LDS is handed out in 1 280-byte granules, five of them = 6 400 B = 19 entries + the 1.5 KB of parked path state.
+#ifndef PT_SM_LDS_DEPTH_SIX_VALUE
+#define PT_SM_LDS_DEPTH_SIX_VALUE 19
+#endif
+constexpr int SM_LDS_DEPTH_SIX = PT_SM_LDS_DEPTH_SIX_VALUE;
 // Stack entries per lane beyond the LDS part: a wave's slice of the global overflow area (the reference aborts a walk at 64
-// stacked entries, raytrace.wgsl:167-171: PT_MAX_STACK in pt_kernels.hip)
-constexpr int SM_OVERFLOW_ENTRIES = 64 - SM_LDS_DEPTH;
+// stacked entries, raytrace.wgsl:167-171: PT_MAX_STACK in pt_kernels.hip), sized for the build with the shallowest LDS part
+constexpr int SM_OVERFLOW_ENTRIES = 64 - (SM_LDS_DEPTH_SIX < SM_LDS_DEPTH ? SM_LDS_DEPTH_SIX : SM_LDS_DEPTH);
 // The culling walks (CULL, WIDE) visit children near first, so their stack occupancy is not the reference order's.
 // They keep a fixed leaf list of SM_CULL_LEAF_CAP entries at the top of the LDS column, node entries in the
 // SM_LDS_DEPTH - SM_CULL_LEAF_CAP slots below it, and deeper node entries (rare) in the wave's global overflow slice;
@@ -29,11 +35,11 @@ constexpr int SM_OVERFLOW_ENTRIES = 64 - SM_LDS_DEPTH;
 #define PT_CULL_LEAF_CAP_VALUE 8
 #endif
 constexpr int SM_CULL_LEAF_CAP = PT_CULL_LEAF_CAP_VALUE;
-constexpr int SM_CULL_STACK_MAX = SM_LDS_DEPTH - SM_CULL_LEAF_CAP + SM_OVERFLOW_ENTRIES;
+constexpr int SM_CULL_STACK_MAX = 64 - SM_CULL_LEAF_CAP;       // (LDS node slots + overflow entries of any build: depth - leaf cap + 64 - depth)
 // The WIDE walk parks up to four leaves per node step (its `full` rule needs LCAP - 4 >= 0 free slots to ever run one), and
 // the culling walks pop one entry and push up to three more than they popped below the leaf list.
-static_assert(SM_CULL_LEAF_CAP >= 4 && SM_LDS_DEPTH - SM_CULL_LEAF_CAP >= 3, "leaf list / node slots of the culling walks");
-static_assert(SM_LDS_DEPTH >= 8 && SM_LDS_DEPTH <= 32, "LDS stack depth");
+static_assert(SM_CULL_LEAF_CAP >= 4 && SM_LDS_DEPTH - SM_CULL_LEAF_CAP >= 3 && SM_LDS_DEPTH_SIX - SM_CULL_LEAF_CAP >= 3, "leaf list / node slots of the culling walks");
+static_assert(SM_LDS_DEPTH >= 8 && SM_LDS_DEPTH <= 32 && SM_LDS_DEPTH_SIX >= 8 && SM_LDS_DEPTH_SIX <= 32, "LDS stack depth");
 
 // Resident waves per SIMD the state-machine kernels are compiled for (__launch_bounds__: 5 -> at most 96 vector registers,
 // 4 -> 128) and, times four SIMDs, the one-wave workgroups per compute unit of their persistent grid: the tuned twins of
@@ -43,7 +49,16 @@ static_assert(SM_LDS_DEPTH >= 8 && SM_LDS_DEPTH <= 32, "LDS stack depth");
 #define PT_SM_TUNED_WAVES 5
 #endif
 constexpr int SM_TUNED_WAVES_PER_SIMD = PT_SM_TUNED_WAVES, SM_OTHER_WAVES_PER_SIMD = 4;
+// Round 5: the compressed-wide walk's builds for ordinary trees (walk_min 32) fit 80 registers -- 8 of them spilled around the walk
+// loop, service-step state that the walk does not touch -- and run SIX waves per SIMD on a 19-entry LDS stack: dragon +2.8 %, demo
+// +3.9 %, close-up +5.2 % (profiles/r05_f_ab_six_waves.log); the deep walks of very large trees (walk_min 44) lose 2.5 % to the shorter
+// stack and keep five.
+#ifndef PT_SM_SIX_WAVES
+#define PT_SM_SIX_WAVES 6
+#endif
+constexpr int SM_SIX_WAVES_PER_SIMD = PT_SM_SIX_WAVES;
 static_assert(4 * SM_TUNED_WAVES_PER_SIMD * (SM_LDS_DEPTH * 256 + 6 * 256) < 160 * 1024, "LDS: stack + parked path state of every resident wave");
+static_assert(4 * SM_SIX_WAVES_PER_SIMD * (SM_LDS_DEPTH_SIX * 256 + 6 * 256) < 160 * 1024, "LDS: stack + parked path state of every resident wave (six-wave builds)");
 
 // The environment texture's size: fixed by the API (renderer.ts:76-85; MI3PT_ENV_WIDTH / _HEIGHT in include/mi3pt.h, tied to these
 // by a static_assert in pt_context.hip).  The tuned kernel instantiations have it as a constant; launch_raytrace sends any other size
@@ -272,7 +287,7 @@ int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, ui
                       int lcap, int leaf_min, int num_cus, hipStream_t s);
 #endif
 int raytrace_grid_blocks(const Tile &tile);
-int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned = false);
+int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned = false, int waves_per_simd = 0);
 // packs the three position vectors of `ntris` 112-byte triangle records into 48-byte rows (the context's cull analysis)
 void launch_pack_vertices(const float4 *tris, float4 *out, uint32_t ntris, hipStream_t s);
 // writes NodePacket::cull of `npackets` packets from a dense array (the context's cull analysis)

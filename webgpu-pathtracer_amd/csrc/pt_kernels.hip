@@ -1256,6 +1256,9 @@ PT_DEV T uniform_block(const T &v)
 #define PT_CW_NO_PAIR_TEST 0
 #endif
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
+#ifndef PT_CW_WAVES
+#define PT_CW_WAVES SM_SIX_WAVES_PER_SIMD          // the compressed-wide walk with walk_min 32: six waves per SIMD (pt_kernels.h)
+#endif
 #ifdef PT_X_TOP_CW
 #define PT_X_TOP_CW_N PT_X_TOP_CW
 #else
@@ -1298,9 +1301,10 @@ PT_DEV T uniform_block(const T &v)
 // CW (with WIDE): the walk on compressed wide packets and 64-byte triangle records (variant 13; cwide_hit above).
 // WMIN: the lean build's walk_min (a constant there: as a launch parameter in a scalar register it cost the 870 k-triangle scene 0.8 %
 // and the demo scene 1.5 %, profiles/r04_o_walkmin2.log): 32, or 44 for the deep walks of very large trees (compressed packets only).
+// WAVES: resident waves per SIMD of a lean build (5: 96 registers, SM_LDS_DEPTH stack entries in LDS; 6: 80 registers, SM_LDS_DEPTH_SIX).
 template <bool DEFER, bool CULL, bool WIDE, bool FILT, bool YMAX, bool DIAG, bool TOPLDS = false, bool LITE = false, bool CW = false,
-          int WMIN = PT_DEFAULT_WALK_MIN>
-__global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_WAVES_PER_SIMD) k_raytrace_sm(const RtLaunch L)
+          int WMIN = PT_DEFAULT_WALK_MIN, int WAVES = SM_TUNED_WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_raytrace_sm(const RtLaunch L)
 {
     static_assert(!CULL || DEFER, "the culling walks park their leaves");
     static_assert((!WIDE || CULL) && (!FILT || WIDE) && (!YMAX || FILT) && (!CW || FILT), "WIDE needs CULL, FILT needs WIDE, YMAX and CW need FILT");
@@ -1318,7 +1322,8 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     // ordinary resolution: a scene with nodes whose root is an internal node with a guard-range box, a resolution of ordinary
     // magnitude (launch_assumptions_hold; a launch that fails them runs the lean build of variant 7 or 4, which assumes nothing)
     constexpr bool ASSUME = TUNED && CULL;
-    constexpr int DEPTH = PT_SM_LDS_DEPTH;                  // LDS stack entries per lane
+    static_assert(WAVES == SM_TUNED_WAVES_PER_SIMD || (WAVES == SM_SIX_WAVES_PER_SIMD && !DIAG), "five waves per SIMD, or six for a lean build");
+    constexpr int DEPTH = WAVES == SM_SIX_WAVES_PER_SIMD && WAVES != SM_TUNED_WAVES_PER_SIMD ? SM_LDS_DEPTH_SIX : PT_SM_LDS_DEPTH;      // LDS stack entries per lane
     constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
     // deeper entries (rare: the stack holds about one entry per tree level) go to this
@@ -1344,19 +1349,19 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
         for (uint32_t i = (uint32_t)lane; i < ntop * 4u; i += 64u) top_lds[i] = CW ? L.scene.cwide[i] : L.scene.packets[i];
         __syncthreads();
     }
-    uint32_t *ovf = L.stack_overflow + (size_t)blockIdx.x * ((PT_MAX_STACK - PT_SM_LDS_DEPTH) * 64) + lane;
+    uint32_t *ovf = L.stack_overflow + (size_t)blockIdx.x * (SM_OVERFLOW_ENTRIES * 64) + lane;      // (a slice of SM_OVERFLOW_ENTRIES >= PT_MAX_STACK - DEPTH entries per lane)
     // LDS and the overflow slice are accessed by separate instructions (a pointer select
     // between the two address spaces would compile to flat_* accesses, which wait for every
     // outstanding memory operation): the LDS access is unconditional, the overflow access a
     // rare branch kept apart by the opaque asm.
     auto st_load = [&](int i) -> uint32_t {
-        uint32_t v = stack[(i < PT_SM_LDS_DEPTH ? i : 0) * 64];
+        uint32_t v = stack[(i < DEPTH ? i : 0) * 64];
         asm volatile("" : "+v"(v));          // keep this a ds_read of its own
-        if (i >= PT_SM_LDS_DEPTH) v = ovf[(i - PT_SM_LDS_DEPTH) * 64];
+        if (i >= DEPTH) v = ovf[(i - DEPTH) * 64];
         return v;
     };
     auto st_store = [&](int i, uint32_t v) {
-        if (i >= PT_SM_LDS_DEPTH) ovf[(i - PT_SM_LDS_DEPTH) * 64] = v;
+        if (i >= DEPTH) ovf[(i - DEPTH) * 64] = v;
         else stack[i * 64] = v;
     };
     const SceneRefs &sc = L.scene;
@@ -1845,7 +1850,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
             // (stack accesses are plain LDS, both child boxes are tested and pushed without
             // divergence); packets with a guard bit take the generic child handling.
             const bool trav = mode == M_TRAV;
-            if (__ballot(trav && ((pre.flags & 8u) != 0u || sp >= PT_SM_LDS_DEPTH)) == 0ull) {
+            if (__ballot(trav && ((pre.flags & 8u) != 0u || sp >= DEPTH)) == 0ull) {
                 if (trav) {
                     sp--;
                     const uint32_t ref = stack[sp * 64];
@@ -2315,12 +2320,14 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : SM_TUNED_
     }
 }
 
-int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned)
+int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned, int waves_per_simd)
 {
     const int ntiles = raytrace_grid_blocks(tile);
     if (num_cus <= 0) num_cus = 256;
+    if (waves_per_simd <= 0) waves_per_simd = tuned ? SM_TUNED_WAVES_PER_SIMD : SM_OTHER_WAVES_PER_SIMD;
+    if (waves_per_cu > 4 * waves_per_simd) waves_per_cu = 0;          // (more than the build can keep resident: its own width)
     if (waves_per_cu <= 0 || waves_per_cu > 24) {
-        waves_per_cu = 4 * (tuned ? SM_TUNED_WAVES_PER_SIMD : SM_OTHER_WAVES_PER_SIMD);
+        waves_per_cu = 4 * waves_per_simd;
         // A small launch (an interactive host: one or two frames, or a small image) gets fewer waves: at least 8 jobs each,
         // at least 4 per CU.  With a handful of jobs per wave a launch is all ramp and drain, and a launch that fills every
         // wave slot keeps its successor out until its own waves exit; narrower launches overlap.  One 1080p frame per
@@ -2415,9 +2422,22 @@ bool raytrace_variant_fuses(int variant)
     return variant <= 2;
 #endif
 }
+// Waves per SIMD the build a route runs is compiled for: the compressed-wide walk's lean builds with the ordinary walk threshold run six
+// (launch_raytrace: PT_CW_WAVES), the other lean builds five, the diagnostic twins four.
+static int route_waves_per_simd(const RtLaunch &L, const RtRoute &r)
+{
+    if (!(r.kind == 1 && r.lean)) return SM_OTHER_WAVES_PER_SIMD;
+    if (r.variant == 13 && L.walk_min != PT_DEEP_WALK_MIN) {
+#ifdef MI3PT_EXPERIMENTS
+        if (L.wave_times && L.diag_lite) return SM_TUNED_WAVES_PER_SIMD;      // (the lean build + lane counts: five)
+#endif
+        return PT_CW_WAVES;
+    }
+    return SM_TUNED_WAVES_PER_SIMD;
+}
 static int persistent_blocks_for(const RtLaunch &L, const RtRoute &r)
 {
-    return raytrace_persistent_blocks(L.tile, L.nframes, L.waves_per_cu, L.num_cus, r.kind == 1 && r.lean);
+    return raytrace_persistent_blocks(L.tile, L.nframes, L.waves_per_cu, L.num_cus, r.kind == 1 && r.lean, route_waves_per_simd(L, r));
 }
 RtRoute raytrace_route(const RtLaunch &L, int variant)
 {
@@ -2467,8 +2487,8 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
                 if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN);
                 else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN);
             } else {
-                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true);
-                else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true);
+                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEFAULT_WALK_MIN, PT_CW_WAVES);
+                else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEFAULT_WALK_MIN, PT_CW_WAVES);
             }
         } else
         if (r.lean) switch (r.variant) {
