@@ -1257,7 +1257,7 @@ def test_camera_rays_from_the_precomputed_base_equal_the_in_kernel_ones(gpu_ctx,
 @pytest.mark.parametrize("order", [1, 2])
 def test_packet_numbering_in_memory_does_not_change_a_bit(built, orc, demo, env, order):
     """MI3PT_OPT_PACKET_ORDER: the 4-ary packets numbered depth-first (1) or in three-level treelets (2) instead of breadth-first.
-    The walk follows references: same image, same counters (its own context: the option re-runs the scene analysis)."""
+    The walk follows references: same image, same path counters (its own context: the option re-runs the scene analysis)."""
     w, h = 96, 80
     u = pc.rt_uniforms(demo, w, h, frame=3, bounces=6)
     want, ocnt = orc.raytrace(pc.oracle_scene(orc, demo, env), u.tobytes(), w, h)
@@ -1274,4 +1274,5 @@ def test_packet_numbering_in_memory_does_not_change_a_bit(built, orc, demo, env,
         for img, cnt in outs:
             assert pc.same_bits(img, want), pc.describe_diff(img, want)
             pc.check_counters(cnt, ocnt, culled=True)
-        assert outs[0][1] == outs[1][1]
+        for k in pc.PATH_COUNTERS:          # (the box / triangle test counts of a culling walk depend on which rays share a wave: not compared)
+            assert outs[0][1][k] == outs[1][1][k]

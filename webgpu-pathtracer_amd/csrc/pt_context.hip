@@ -148,6 +148,7 @@ struct mi3pt_ctx {
     bool debug_suppress_drain = false;    // MI3PT_OPT_DEBUG_SUPPRESS_DRAIN (tests): the gate is armed but no kernel publishes its drain mark
     hipStream_t gate_release_stream = nullptr;
     volatile uint32_t *h_drain_flag = nullptr;   // the drain word as the host sees it, where signal memory is host memory (hipPointerGetAttributes at create); else null
+    float *d_park = nullptr;              // [2 parities][PT_MAX_RESIDENT_WAVES][6][64] parked path state of the builds that keep it in memory (RtLaunch::park)
     uint32_t *d_stack_overflow = nullptr; // [2 parities][PT_MAX_RESIDENT_WAVES][SM_OVERFLOW_ENTRIES][64] overflow stack entries
     void *d_fs_taps = nullptr;            // the de-noise pass's tap table (pt::launch_fullscreen), built for fs_taps_res
     float fs_taps_res[2] = { 0.0f, 0.0f };
@@ -455,6 +456,7 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     CREATE_TRY(hipMalloc(&ctx->d_cdf, env_bytes));
     CREATE_TRY(hipMalloc((void **)&ctx->d_tile_counter, 256));
     CREATE_TRY(hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * pt::SM_OVERFLOW_ENTRIES * 64 * 4));
+    CREATE_TRY(hipMalloc((void **)&ctx->d_park, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * 6 * 64 * sizeof(float)));
     CREATE_TRY(hipMalloc((void **)&ctx->d_service, (size_t)(SERVICE_SLOTS + 1) * service_slot_bytes()));      // (+ 1: the launches mi3pt_submit runs at once on the main stream)
     CREATE_TRY(hipMalloc(&ctx->d_fs_taps, pt::fullscreen_taps_bytes()));
     CREATE_TRY(hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream));     // self-cleaning afterwards
@@ -544,7 +546,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
     if (ctx->gate_release_stream) (void)hipStreamDestroy(ctx->gate_release_stream);
     free_textures(ctx);
     for (void *p : { ctx->d_cwide, ctx->d_tripk64, ctx->d_wide, ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
-                     (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow, (void *)ctx->d_service, ctx->d_fs_taps })
+                     (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow, (void *)ctx->d_park, (void *)ctx->d_service, ctx->d_fs_taps })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
         for (int k = 0; k < 2; k++)
@@ -1926,6 +1928,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.num_cus = ctx->num_cus;
     L.service = nullptr;          // (batched launches: a slot of the context's ring, see launch_batch)
     L.cam_base = nullptr;         // (batched launches: launch_batch)
+    L.park = ctx->d_park;
     L.tile_cost = nullptr;        // (batched launches: launch_batch)
     L.tile_perm = nullptr;
     L.top_packets = ctx->top_packets;
@@ -2122,6 +2125,7 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame *frames, i
     L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
     L.tile_counter = ctx->d_tile_counter + par * 32;
     L.stack_overflow = ctx->d_stack_overflow + (size_t)par * pt::PT_MAX_RESIDENT_WAVES * pt::SM_OVERFLOW_ENTRIES * 64;
+    L.park = ctx->d_park + (size_t)par * pt::PT_MAX_RESIDENT_WAVES * 6 * 64;
     L.service = reinterpret_cast<pt::RtService *>(ctx->d_service + (size_t)((ctx->seq - 1) % SERVICE_SLOTS) * service_slot_bytes());
     bool cost_measuring = false, cost_ordered = false;
     if (int rc = cost_order_prepare(ctx, L, first.u_rt, pick_variant(ctx), rs, &cost_measuring, &cost_ordered)) return rc;

@@ -7,7 +7,10 @@ namespace pt {
 
 // Upper bound on the persistent kernels' grid (CUs x waves per CU, clamped to this); sizes the
 // per-wave overflow-stack slices and diagnostic slots.  MI355X: 256 CUs x at most 24 waves.
-constexpr int PT_MAX_RESIDENT_WAVES = 256 * 24;
+#ifndef PT_MAX_WAVES_PER_CU
+#define PT_MAX_WAVES_PER_CU 24
+#endif
+constexpr int PT_MAX_RESIDENT_WAVES = 256 * PT_MAX_WAVES_PER_CU;
 
 // Stack entries per lane that the state-machine kernels keep in LDS ([depth][lane], 256 B per entry and wave).  With the
 // 1.5 KB of parked path state, 20 one-wave workgroups per CU x (SM_LDS_DEPTH x 256 B + 1536 B) must fit the 160 KB of LDS --
@@ -23,9 +26,11 @@ constexpr int SM_LDS_DEPTH = PT_SM_LDS_DEPTH_VALUE;
 #define PT_SM_LDS_DEPTH_SIX_VALUE 19
 #endif
 constexpr int SM_LDS_DEPTH_SIX = PT_SM_LDS_DEPTH_SIX_VALUE;
+constexpr int SM_LDS_DEPTH_SIX_DEEP = 25;       // ... of the six-wave build for very large trees: all 6 400 B are stack, the parked path state lives in memory (RtLaunch::park)
 // Stack entries per lane beyond the LDS part: a wave's slice of the global overflow area (the reference aborts a walk at 64
 // stacked entries, raytrace.wgsl:167-171: PT_MAX_STACK in pt_kernels.hip), sized for the build with the shallowest LDS part
 constexpr int SM_OVERFLOW_ENTRIES = 64 - (SM_LDS_DEPTH_SIX < SM_LDS_DEPTH ? SM_LDS_DEPTH_SIX : SM_LDS_DEPTH);
+static_assert(SM_LDS_DEPTH_SIX_DEEP >= SM_LDS_DEPTH_SIX && 4 * 6 * SM_LDS_DEPTH_SIX_DEEP * 256 < 160 * 1024, "six-wave deep build: LDS");
 // The culling walks (CULL, WIDE) visit children near first, so their stack occupancy is not the reference order's.
 // They keep a fixed leaf list of SM_CULL_LEAF_CAP entries at the top of the LDS column, node entries in the
 // SM_LDS_DEPTH - SM_CULL_LEAF_CAP slots below it, and deeper node entries (rare) in the wave's global overflow slice;
@@ -52,7 +57,7 @@ constexpr int SM_TUNED_WAVES_PER_SIMD = PT_SM_TUNED_WAVES, SM_OTHER_WAVES_PER_SI
 // Round 5: the compressed-wide walk's builds for ordinary trees (walk_min 32) fit 80 registers -- 8 of them spilled around the walk
 // loop, service-step state that the walk does not touch -- and run SIX waves per SIMD on a 19-entry LDS stack: dragon +2.8 %, demo
 // +3.9 %, close-up +5.2 % (profiles/r05_f_ab_six_waves.log); the deep walks of very large trees (walk_min 44) lose 2.5 % to the shorter
-// stack and keep five.
+// stack -- their six-wave build therefore keeps the parked path state in memory and gives all 6 400 B to the stack: 25 entries, +4.0 %.
 #ifndef PT_SM_SIX_WAVES
 #define PT_SM_SIX_WAVES 6
 #endif
@@ -255,6 +260,8 @@ struct RtLaunch {
     const float4 *cam_base;      // state-machine kernel, or null: per texel of this rank's image, cam_pos + dir0 * focalDistance -- the part of
                                  // cameraToRay (raytrace.wgsl:219-238, 446) that depends on the PIXEL only, formed once per camera by
                                  // launch_camera_base instead of once per frame of a batch in the service step (same operations, same bits)
+    float *park;                 // state-machine kernel builds that park a path's throughput and collected light in MEMORY instead of LDS (the
+                                 // six-wave build for very large trees: its whole LDS share is stack): [grid][6][64] floats, or null
     RtService *service;          // device memory for one RtService block (service_block_bytes()), or null: the tuned twin of the
                                  // state-machine kernel reads its service step's scalars from it (launch_raytrace fills it first)
 };

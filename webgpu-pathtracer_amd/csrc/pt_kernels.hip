@@ -1259,6 +1259,9 @@ PT_DEV T uniform_block(const T &v)
 #ifndef PT_CW_WAVES
 #define PT_CW_WAVES SM_SIX_WAVES_PER_SIMD          // the compressed-wide walk with walk_min 32: six waves per SIMD (pt_kernels.h)
 #endif
+#ifndef PT_CW_DEEP_WAVES
+#define PT_CW_DEEP_WAVES SM_SIX_WAVES_PER_SIMD     // ... with walk_min 44 (trees of >= 2^20 packets): six as well, on a 25-entry stack -- its parked path state lives in memory (PARKG)
+#endif
 #ifdef PT_X_TOP_CW
 #define PT_X_TOP_CW_N PT_X_TOP_CW
 #else
@@ -1323,7 +1326,16 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
     // magnitude (launch_assumptions_hold; a launch that fails them runs the lean build of variant 7 or 4, which assumes nothing)
     constexpr bool ASSUME = TUNED && CULL;
     static_assert(WAVES == SM_TUNED_WAVES_PER_SIMD || (WAVES == SM_SIX_WAVES_PER_SIMD && !DIAG), "five waves per SIMD, or six for a lean build");
-    constexpr int DEPTH = WAVES == SM_SIX_WAVES_PER_SIMD && WAVES != SM_TUNED_WAVES_PER_SIMD ? SM_LDS_DEPTH_SIX : PT_SM_LDS_DEPTH;      // LDS stack entries per lane
+    // PARKG: the six-wave build for very large trees (walk_min 44): its whole 6 400-byte LDS share is stack (25 entries: deep walks pay
+    // for every entry that leaves LDS), and a path's throughput and collected light, touched by the service step only, rest in the
+    // wave's slice of L.park in memory -- read where shading starts, ahead of the loads it waits for anyway, written where a segment starts
+    constexpr bool SIX = WAVES == SM_SIX_WAVES_PER_SIMD && WAVES != SM_TUNED_WAVES_PER_SIMD;
+#ifdef PT_X_PARKG_ALL
+    constexpr bool PARKG = SIX;
+#else
+    constexpr bool PARKG = SIX && WMIN == PT_DEEP_WALK_MIN;
+#endif
+    constexpr int DEPTH = PARKG ? SM_LDS_DEPTH_SIX_DEEP : (SIX ? SM_LDS_DEPTH_SIX : PT_SM_LDS_DEPTH);      // LDS stack entries per lane
     constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
     // deeper entries (rare: the stack holds about one entry per tree level) go to this
@@ -1339,9 +1351,10 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
     __shared__ float4 top_lds[TOPLDS ? TOPN * 4 : 1];
     // A path's throughput and collected light are only touched by the service step; between service steps they rest here
     // (6 floats per lane, [k][lane]) instead of in six registers carried through every node and triangle step
-    __shared__ float park_lds[6 * 64];
+    __shared__ float park_lds[PARKG ? 1 : 6 * 64];
     const int lane = threadIdx.x;
-    float *park = park_lds + lane;
+    float *park = park_lds + (PARKG ? 0 : lane);
+    float *const parkg = PARKG ? L.park + (size_t)blockIdx.x * (6 * 64) + lane : nullptr;
     uint32_t *stack = stack_lds + lane;
     const uint32_t top_cap = (uint32_t)L.top_packets < (uint32_t)TOPN ? (uint32_t)L.top_packets : (uint32_t)TOPN;
     const uint32_t ntop = !TOPLDS ? 0u : (CW ? top_cap : (L.scene.npackets < top_cap ? L.scene.npackets : top_cap));      // (CW: the host caps top_packets by the number of wide packets)
@@ -1987,8 +2000,13 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
             u_miss += (uint32_t)__popcll(__ballot(shade_miss));
             bool ended = true;
             if (shade_hit || shade_miss) {
-                ray_color = F3(park[0], park[64], park[128]);
-                light = F3(park[192], park[256], park[320]);
+                if constexpr (PARKG) {
+                    ray_color = F3(parkg[0], parkg[64], parkg[128]);
+                    light = F3(parkg[192], parkg[256], parkg[320]);
+                } else {
+                    ray_color = F3(park[0], park[64], park[128]);
+                    light = F3(park[192], park[256], park[320]);
+                }
             }
 #ifdef PT_DIAG_SERVICE
             if (wave_times) st_switch(3);
@@ -2213,8 +2231,13 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
         }
         bool slow_segment = false;
         if (need_segment) {
-            park[0] = ray_color.x; park[64] = ray_color.y; park[128] = ray_color.z;
-            park[192] = light.x; park[256] = light.y; park[320] = light.z;
+            if constexpr (PARKG) {
+                parkg[0] = ray_color.x; parkg[64] = ray_color.y; parkg[128] = ray_color.z;
+                parkg[192] = light.x; parkg[256] = light.y; parkg[320] = light.z;
+            } else {
+                park[0] = ray_color.x; park[64] = ray_color.y; park[128] = ray_color.z;
+                park[192] = light.x; park[256] = light.y; park[320] = light.z;
+            }
         }
         ray_color = F3(0.0f, 0.0f, 0.0f);       // (dead until the lane's next shading: nothing to keep in registers -- zeros, which cost
         light = F3(0.0f, 0.0f, 0.0f);           // six moves per service step where they meet the values read back from the park, can be made
@@ -2326,7 +2349,7 @@ int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, 
     if (num_cus <= 0) num_cus = 256;
     if (waves_per_simd <= 0) waves_per_simd = tuned ? SM_TUNED_WAVES_PER_SIMD : SM_OTHER_WAVES_PER_SIMD;
     if (waves_per_cu > 4 * waves_per_simd) waves_per_cu = 0;          // (more than the build can keep resident: its own width)
-    if (waves_per_cu <= 0 || waves_per_cu > 24) {
+    if (waves_per_cu <= 0 || waves_per_cu > PT_MAX_WAVES_PER_CU) {
         waves_per_cu = 4 * waves_per_simd;
         // A small launch (an interactive host: one or two frames, or a small image) gets fewer waves: at least 8 jobs each,
         // at least 4 per CU.  With a handful of jobs per wave a launch is all ramp and drain, and a launch that fills every
@@ -2427,11 +2450,11 @@ bool raytrace_variant_fuses(int variant)
 static int route_waves_per_simd(const RtLaunch &L, const RtRoute &r)
 {
     if (!(r.kind == 1 && r.lean)) return SM_OTHER_WAVES_PER_SIMD;
-    if (r.variant == 13 && L.walk_min != PT_DEEP_WALK_MIN) {
+    if (r.variant == 13) {
 #ifdef MI3PT_EXPERIMENTS
         if (L.wave_times && L.diag_lite) return SM_TUNED_WAVES_PER_SIMD;      // (the lean build + lane counts: five)
 #endif
-        return PT_CW_WAVES;
+        return L.walk_min == PT_DEEP_WALK_MIN ? PT_CW_DEEP_WAVES : PT_CW_WAVES;
     }
     return SM_TUNED_WAVES_PER_SIMD;
 }
@@ -2484,8 +2507,8 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
 #endif
         if (r.lean && r.variant == 13) {        // compressed wide packets (SceneRefs::flags bit 2: the one-axis culling condition suits this scene)
             if (L.walk_min == PT_DEEP_WALK_MIN) {
-                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN);
-                else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN);
+                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN, PT_CW_DEEP_WAVES);
+                else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN, PT_CW_DEEP_WAVES);
             } else {
                 if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEFAULT_WALK_MIN, PT_CW_WAVES);
                 else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEFAULT_WALK_MIN, PT_CW_WAVES);
