@@ -344,6 +344,10 @@ typedef enum mi3pt_option {
     MI3PT_OPT_PACKET_ORDER = 26,    /* numbering of the 4-ary packets in device memory: 0 breadth-first (the reference's flattenBVH order carried
                                    * over), 1 depth-first, 2 treelets of three levels; the walk follows references, any numbering renders the
                                    * same bits.  Applied at the next scene analysis (0) */
+    MI3PT_OPT_SIX_WAVES = 27,       /* the shipped walk's build: 1 = six waves per SIMD (80 registers, a 19-entry LDS stack -- 25 for very large trees,
+                                   * whose parked path state then lives in memory), 0 = five (96 registers, 24 entries), -1 = by the size of
+                                   * the launch: six from 2.5 M jobs (tiles x frames) on -- long launches gain 2 .. 5 % from the extra wave, a
+                                   * rank of an 8-way split's 10 ms launches lose 2 .. 3 % to the longer drain (-1) */
     MI3PT_OPT_DEBUG_SUPPRESS_DRAIN = 24, /* tests: arm the gate but let no kernel publish its mark (forces the situation the time-out exists for) */
     MI3PT_OPT_SLOT_SETS = 15,  /* sets of per-frame radiance slots, 2 or 3; before mi3pt_resize (2) */
     MI3PT_OPT_PIPELINE = 16,   /* = mi3pt_set_pipelining */

@@ -131,6 +131,7 @@ struct mi3pt_ctx {
     uint8_t cam_base_key[2][80] = {};
     bool cam_base_valid[2] = { false, false };
     bool cam_base_enabled = true;        // MI3PT_OPT_CAMERA_BASE
+    int six_waves = -1;                  // MI3PT_OPT_SIX_WAVES: the compressed-wide walk's build, -1 = by the size of the launch (pt::RtLaunch::six_waves)
     int packet_order = 0;                // MI3PT_OPT_PACKET_ORDER: numbering of the wide packets in memory (prepare_cull): 0 breadth-first, 1 depth-first, 2 treelets
     uint32_t *d_canvas8 = nullptr;
     bool output_is_accum = false;
@@ -666,6 +667,7 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
     case MI3PT_OPT_WIDE: ctx->wide_enabled = value != 0; break;
     case MI3PT_OPT_GATE: ctx->gate_enabled = value != 0 && ctx->d_drain_flag != nullptr; if (ctx->gate_enabled) ctx->gate_releases = 0; break;
     case MI3PT_OPT_CAMERA_BASE: ctx->cam_base_enabled = value != 0; break;
+    case MI3PT_OPT_SIX_WAVES: ctx->six_waves = value < 0 ? -1 : (value != 0 ? 1 : 0); break;
     case MI3PT_OPT_PACKET_ORDER:
         if (value < 0 || value > 2) return pt_set_error(MI3PT_ERR_INVALID, "packet order: 0 breadth-first, 1 depth-first, 2 treelets");
         if (ctx->packet_order != value) { ctx->packet_order = value; ctx->cull_dirty = true; }
@@ -725,6 +727,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_WIDE: *value = ctx->wide_enabled ? 1 : 0; break;
     case MI3PT_OPT_GATE: *value = ctx->gate_enabled ? 1 : 0; break;
     case MI3PT_OPT_CAMERA_BASE: *value = ctx->cam_base_enabled ? 1 : 0; break;
+    case MI3PT_OPT_SIX_WAVES: *value = ctx->six_waves; break;
     case MI3PT_OPT_PACKET_ORDER: *value = ctx->packet_order; break;
     case MI3PT_OPT_GATE_TIMEOUT_MS: *value = ctx->gate_timeout_ms; break;
     case MI3PT_OPT_GATE_RELEASES: *value = ctx->gate_releases; break;
@@ -1929,6 +1932,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     L.service = nullptr;          // (batched launches: a slot of the context's ring, see launch_batch)
     L.cam_base = nullptr;         // (batched launches: launch_batch)
     L.park = ctx->d_park;
+    L.six_waves = ctx->six_waves;
     L.tile_cost = nullptr;        // (batched launches: launch_batch)
     L.tile_perm = nullptr;
     L.top_packets = ctx->top_packets;

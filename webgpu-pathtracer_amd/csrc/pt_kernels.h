@@ -260,6 +260,7 @@ struct RtLaunch {
     const float4 *cam_base;      // state-machine kernel, or null: per texel of this rank's image, cam_pos + dir0 * focalDistance -- the part of
                                  // cameraToRay (raytrace.wgsl:219-238, 446) that depends on the PIXEL only, formed once per camera by
                                  // launch_camera_base instead of once per frame of a batch in the service step (same operations, same bits)
+    int32_t six_waves;           // the compressed-wide walk's build: 1 = six waves per SIMD, 0 = five, -1 = by the size of the launch (route_waves_per_simd)
     float *park;                 // state-machine kernel builds that park a path's throughput and collected light in MEMORY instead of LDS (the
                                  // six-wave build for very large trees: its whole LDS share is stack): [grid][6][64] floats, or null
     RtService *service;          // device memory for one RtService block (service_block_bytes()), or null: the tuned twin of the

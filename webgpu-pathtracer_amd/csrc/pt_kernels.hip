@@ -1256,12 +1256,6 @@ PT_DEV T uniform_block(const T &v)
 #define PT_CW_NO_PAIR_TEST 0
 #endif
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
-#ifndef PT_CW_WAVES
-#define PT_CW_WAVES SM_SIX_WAVES_PER_SIMD          // the compressed-wide walk with walk_min 32: six waves per SIMD (pt_kernels.h)
-#endif
-#ifndef PT_CW_DEEP_WAVES
-#define PT_CW_DEEP_WAVES SM_SIX_WAVES_PER_SIMD     // ... with walk_min 44 (trees of >= 2^20 packets): six as well, on a 25-entry stack -- its parked path state lives in memory (PARKG)
-#endif
 #ifdef PT_X_TOP_CW
 #define PT_X_TOP_CW_N PT_X_TOP_CW
 #else
@@ -2445,8 +2439,15 @@ bool raytrace_variant_fuses(int variant)
     return variant <= 2;
 #endif
 }
-// Waves per SIMD the build a route runs is compiled for: the compressed-wide walk's lean builds with the ordinary walk threshold run six
-// (launch_raytrace: PT_CW_WAVES), the other lean builds five, the diagnostic twins four.
+// Waves per SIMD of the build a route runs.  The compressed-wide walk has two lean builds per instantiation: FIVE waves (96 registers, a
+// 24-entry LDS stack) and SIX (80 registers with a handful spilled around the walk loop; 19 entries -- or 25 with the parked path state in
+// memory, for very large trees).  Six waves overlap more of the per-step round trips: +2 .. +5 % on launches that run for tens of
+// milliseconds.  But a sixth more paths are in flight when the job queue runs empty, and that drain is paid once per launch: a rank of an
+// 8-way split (a 10 ms launch) is 2 .. 3 % SLOWER with six (profiles/r05_i_six_waves_by_launch_size.log).  So the choice goes by the size of
+// the launch: jobs (tiles x frames) per resident wave.  L.six_waves forces it (MI3PT_OPT_SIX_WAVES).  Other lean builds: five; twins: four.
+#ifndef PT_SIX_WAVES_MIN_JOBS
+#define PT_SIX_WAVES_MIN_JOBS 2500000
+#endif
 static int route_waves_per_simd(const RtLaunch &L, const RtRoute &r)
 {
     if (!(r.kind == 1 && r.lean)) return SM_OTHER_WAVES_PER_SIMD;
@@ -2454,7 +2455,10 @@ static int route_waves_per_simd(const RtLaunch &L, const RtRoute &r)
 #ifdef MI3PT_EXPERIMENTS
         if (L.wave_times && L.diag_lite) return SM_TUNED_WAVES_PER_SIMD;      // (the lean build + lane counts: five)
 #endif
-        return L.walk_min == PT_DEEP_WALK_MIN ? PT_CW_DEEP_WAVES : PT_CW_WAVES;
+        if (L.six_waves >= 0) return L.six_waves ? SM_SIX_WAVES_PER_SIMD : SM_TUNED_WAVES_PER_SIMD;
+        const long long jobs = (long long)raytrace_grid_blocks(L.tile) * (L.nframes > 0 ? L.nframes : 1);
+        // (a job of a very large tree -- the walk_min-44 builds -- is an order of magnitude longer)
+        return jobs >= (L.walk_min == PT_DEEP_WALK_MIN ? PT_SIX_WAVES_MIN_JOBS / 10 : PT_SIX_WAVES_MIN_JOBS) ? SM_SIX_WAVES_PER_SIMD : SM_TUNED_WAVES_PER_SIMD;
     }
     return SM_TUNED_WAVES_PER_SIMD;
 }
@@ -2506,12 +2510,13 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
 #define PT_TOP_CW true          // (A/B build: the first PT_X_TOP_CW compressed packets staged in LDS per wave)
 #endif
         if (r.lean && r.variant == 13) {        // compressed wide packets (SceneRefs::flags bit 2: the one-axis culling condition suits this scene)
+            const bool six = route_waves_per_simd(L, r) == SM_SIX_WAVES_PER_SIMD, ymax = (L.scene.flags & 4u) != 0u;
             if (L.walk_min == PT_DEEP_WALK_MIN) {
-                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN, PT_CW_DEEP_WAVES);
-                else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN, PT_CW_DEEP_WAVES);
+                if (six) { if (ymax) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN, SM_SIX_WAVES_PER_SIMD); else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN, SM_SIX_WAVES_PER_SIMD); }
+                else { if (ymax) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN); else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEEP_WALK_MIN); }
             } else {
-                if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEFAULT_WALK_MIN, PT_CW_WAVES);
-                else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEFAULT_WALK_MIN, PT_CW_WAVES);
+                if (six) { if (ymax) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true, PT_DEFAULT_WALK_MIN, SM_SIX_WAVES_PER_SIMD); else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true, PT_DEFAULT_WALK_MIN, SM_SIX_WAVES_PER_SIMD); }
+                else { if (ymax) PT_SM(true, true, true, true, true, false, PT_TOP_CW, false, true); else PT_SM(true, true, true, true, false, false, PT_TOP_CW, false, true); }
             }
         } else
         if (r.lean) switch (r.variant) {
