@@ -620,15 +620,18 @@ def main():
              "kernel_ms_all": (launch_ms_total + warm_ms) / max(launches + warm_launches, 1), "launches_all": int(launches + warm_launches),
              "frames_per_launch": round(launch_frames / max(launches, 1), 2),
              "variant": ctx.active_variant(),
-             # (template arguments: DEFER, CULL, WIDE, FILT, YMAX, DIAG, TOPLDS, LITE, CW -- csrc/pt_kernels.hip; what the last launch ran: mi3pt_debug_last_launch)
-             "kernel": (lambda v: {13: "k_raytrace_sm<true,true,true,true,YMAX,false,false,false,true>", 12: "k_raytrace_sm<true,true,true,true,true,false>", 11: "k_raytrace_sm<true,true,true,true,false,false>",
+             # (template arguments: DEFER, CULL, WIDE, FILT, YMAX, DIAG, TOPLDS, LITE, CW, WMIN, WAVES -- csrc/pt_kernels.hip; what the last launch ran:
+             # mi3pt_debug_last_launch.  WAVES: launches of >= 2.5 M jobs (tiles x frames) run the six-waves-per-SIMD build, shorter ones the
+             # five-wave build -- the driver's 320 timed frames are a 256-frame launch of <..., 32, 6> and a 64-frame launch of <..., 32, 5>,
+             # and `rocprofv3 --stats` lists the two instantiations separately)
+             "kernel": (lambda v: {13: "k_raytrace_sm<true,true,true,true,YMAX,false,false,false,true,WMIN,WAVES>", 12: "k_raytrace_sm<true,true,true,true,true,false>", 11: "k_raytrace_sm<true,true,true,true,false,false>",
                                    10: "k_raytrace_sm<true,true,true,false,false,false>", 9: "k_raytrace_sm<true,true,false,false,false,false>",
                                    7: "k_raytrace_sm<true,false,false,false,false,false>", 4: "k_raytrace_sm<false,false,false,false,false,false>"}
                         .get(v, f"raytrace kernel variant {v}") + " (persistent raytrace kernel: per-lane state machine, deferred-leaf walk"
                         + (" with exact-image distance culling" if v >= 9 else "") + (" on 4-ary wide packets" if v >= 10 else "")
                         + (", filtered slab test" if v in (11, 12) else "") + (", one-axis culling condition" if v == 12 else "")
                         + (": COMPRESSED packets (64 B, boxes on an 8-bit grid rounded outward, conservative test; the exact test on the leaf's own box in the triangle step)" if v == 13 else "")
-                        + "; lean build, five waves per SIMD; batched frames)")(ctx.last_launch()["variant"] if not use_group else ctx.active_variant()),
+                        + "; lean build, six waves per SIMD for launches of >= 2.5 M jobs (80 registers), five below (96); batched frames)")(ctx.last_launch()["variant"] if not use_group else ctx.active_variant()),
              "lean": (ctx.last_launch()["lean"] if not use_group else None)}
         # ---- is the gathered image the right image?  (outside the timed region; round-4 verdict: the N > 1 line gathered and
         # discarded.)  Rank 0 renders the shares of two OTHER ranks again, alone, on its own GPU -- every row, every frame of the
