@@ -300,8 +300,9 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
  * the leaf's own box as uploaded.  Above the leaves a box test only has to never reject what the reference's exact test passes
  * (boxes nest: a leaf that passes has every ancestor pass), so the node step runs a conservative test on the decoded planes
  * (one v_cvt_f32_ubyte + one fma per quotient); the leaf's own box is tested EXACTLY in the triangle step, and only leaves that
- * pass it count as triangle tests.  Half the bytes and half the loads of 10 per node step.  Two instantiations per culling
- * condition (one axis / three axes, chosen per scene like 12 / 11) x two walk thresholds (32 lanes; 44 for very large trees).
+ * pass it count as triangle tests.  Half the bytes and half the loads of 10 per node step.  Instantiations: culling condition
+ * (one axis / three axes, chosen per scene like 12 / 11) x walk threshold (32 lanes; 44 for very large trees) x waves per SIMD (six:
+ * 80 registers, for launches of >= 2.5 M jobs; five: 96 registers; MI3PT_OPT_SIX_WAVES).
  * Needs every box of the tree nested in its parent's and finite (any tree of the reference's builder); otherwise 10 runs.
  * Every reference-legal setting (samplesPerFrame 1 .. 2^24, maxBounces 0 .. 65535, F16 storage, pipelining off) runs this
  * kernel; launches beyond those packing limits run the per-pixel kernel (2), frame by frame.
@@ -328,7 +329,7 @@ typedef enum mi3pt_option {
     MI3PT_OPT_JOB_CHUNK = 8,   /* job tickets per draw while the queue is long (4) */
     MI3PT_OPT_BATCH_LIMIT = 9, /* upper bound of frames per launch, of this context -- or of every member of this group (512) */
     MI3PT_OPT_BATCH = 10,      /* frames per launch on one GPU; x nranks for a rank of a tile split (256; the product is capped by MI3PT_OPT_BATCH_LIMIT); 1 = no batching */
-    MI3PT_OPT_WAVES_PER_CU = 11, /* resident one-wave workgroups per compute unit (0 = what the kernel is compiled for: 20 for the shipped batched launch, 16 otherwise) */
+    MI3PT_OPT_WAVES_PER_CU = 11, /* resident one-wave workgroups per compute unit (0 = what the kernel build is compiled for: 24 / 20 for the shipped walk's six- / five-wave builds, 16 otherwise) */
     MI3PT_OPT_CULL = 12,       /* 0: `auto` stops at variant 7 */
     MI3PT_OPT_WIDE = 13,       /* 0: `auto` stops at variant 9 */
     MI3PT_OPT_GATE = 14,       /* launches wait for their predecessor's drain mark (1; 0 when a profiler is attached) */

@@ -14,6 +14,20 @@ from mi3pt_host import capi, layout, scenes
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[(-1, 0), (0, 0), (1, 0), (1, 44), (0, 44)],
+                ids=["waves-auto", "five-waves", "six-waves", "six-waves-deep-build", "five-waves-deep-build"])
+def waves_per_simd(request, gpu_ctx):
+    """Every test of this file with the shipped walk's five- and six-wave builds forced (MI3PT_OPT_SIX_WAVES): the six-wave build has a
+    19-entry LDS stack, so the stack tests below cross its LDS part at other depths; and with the walk threshold of very large trees
+    (44: their own instantiations -- the six-wave one keeps a 25-entry stack and the parked path state in memory)."""
+    six, walk_min = request.param
+    gpu_ctx.set_option(capi.OPT_SIX_WAVES, six)
+    gpu_ctx.set_option(capi.OPT_WALK_MIN, walk_min)
+    yield request.param
+    gpu_ctx.set_option(capi.OPT_SIX_WAVES, -1)
+    gpu_ctx.set_option(capi.OPT_WALK_MIN, 0)
+
+
 def _render(ctx, sc, w, h, frames, variant, bounces=8, **kw):
     ctx.set_kernel_variant(variant)
     ctx.reset()

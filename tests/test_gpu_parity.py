@@ -1276,3 +1276,49 @@ def test_packet_numbering_in_memory_does_not_change_a_bit(built, orc, demo, env,
             pc.check_counters(cnt, ocnt, culled=True)
         for k in pc.PATH_COUNTERS:          # (the box / triangle test counts of a culling walk depend on which rays share a wave: not compared)
             assert outs[0][1][k] == outs[1][1][k]
+
+
+
+@pytest.mark.parametrize("six", [0, 1])
+def test_five_and_six_wave_builds_render_the_oracles_bits(gpu_ctx, orc, demo, env, six):
+    """MI3PT_OPT_SIX_WAVES forced: the small images of this file would only ever run the five-wave build (the six-wave one is taken
+    from 2.5 M jobs per launch on) -- here every frame case, multi-sample frames, the lens, F16 storage and a tile split on both."""
+    ctx = gpu_ctx
+    pc.upload_scene(ctx, demo, env)
+    osc = pc.oracle_scene(orc, demo, env)
+    ctx.set_option(capi.OPT_SIX_WAVES, six)
+    try:
+        ctx.set_tile(0, 1, 8)
+        for (w, h, bounces, spf, aperture, focal, frame, rotation) in FRAME_CASES:
+            ctx.resize(w, h)
+            ctx.reset_counters()
+            u = pc.rt_uniforms(demo, w, h, frame=frame, bounces=bounces, spf=spf, aperture=aperture, focal=focal, rotation=rotation)
+            pc.gpu_frame(ctx, u)
+            got, cnt = ctx.read_texture(capi.TEX_OUTPUT), ctx.counters()
+            want, ocnt = orc.raytrace(osc, u.tobytes(), w, h)
+            assert pc.same_bits(got, want), ((w, h, bounces, spf), pc.describe_diff(got, want))
+            pc.check_counters(cnt, ocnt, culled=True)
+            assert ctx.last_launch()["variant"] == 13 and ctx.last_launch()["lean"]
+        # batched frames with the running mean, F16 storage, a rank of a split
+        w, h = 100, 52
+        mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+        for storage, rank, nranks in ((capi.STORAGE_F32, 0, 1), (capi.STORAGE_F16, 0, 1), (capi.STORAGE_F32, 1, 3)):
+            ctx.set_storage(storage)
+            ctx.set_tile(rank, nranks, 8)
+            ctx.resize(w, h)
+            ctx.reset()
+            ctx.set_uniforms(capi.PASS_RAYTRACE, pc.rt_uniforms(demo, w, h, frame=2, bounces=6, spf=2, aperture=0.03, focal=3.5).tobytes())
+            ctx.set_uniforms(capi.PASS_ACCUMULATE, pc.acc_uniforms(w, h, 2).tobytes())
+            ctx.submit_frames(mask, 5)
+            got = ctx.read_texture(capi.TEX_ACCUMULATION)
+            f16 = storage == capi.STORAGE_F16
+            want = np.zeros((orc.tile_local_rows(h, rank, nranks, 8), w, 4), np.float32)
+            for f in range(2, 7):
+                img, _ = orc.raytrace(osc, pc.rt_uniforms(demo, w, h, frame=f, bounces=6, spf=2, aperture=0.03, focal=3.5).tobytes(), w, h, rank, nranks, 8, store_f16=f16)
+                want = orc.accumulate(pc.acc_uniforms(w, h, f).tobytes(), w, h, img, want, rank, nranks, 8, store_f16=f16)
+            assert pc.same_bits(got, want), ((storage, rank, nranks), pc.describe_diff(got, want))
+    finally:
+        ctx.set_option(capi.OPT_SIX_WAVES, -1)
+        ctx.set_storage(capi.STORAGE_F32)
+        ctx.set_tile(0, 1, 8)
+        ctx.resize(64, 64)
