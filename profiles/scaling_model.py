@@ -8,6 +8,9 @@ effective per link + ~60 us of launch / rendezvous, profiles/r01_g_gather_bench.
 usage: python profiles/scaling_model.py [--steps 20 --warmup 5 --workload dragon]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+only = None
+if "--only" in sys.argv:          # --only 8: that split alone (with MI3PT_BENCH_BLOCK_ROWS=16 / 32: the block size of the deal)
+    i = sys.argv.index("--only"); only = int(sys.argv[i + 1]); del sys.argv[i:i + 2]
 extra = sys.argv[1:] or ["--steps", "20", "--warmup", "5"]
 
 
@@ -21,7 +24,7 @@ def run(tile):
 
 base = run(None)
 print(f"N=1: {base['value']:.0f} Mrays/s, {base['ms_per_step'] * base['steps']:.3f} ms for {base['steps']} steps", flush=True)
-for n in (2, 4, 8):
+for n in ((only,) if only else (2, 4, 8)):
     ranks = [run(f"{r}/{n}") for r in range(n)]          # every rank (round 4 rendered three of the eight)
     t = [j["ms_per_step"] * j["steps"] for j in ranks]
     rays = sum(j["config"]["rays_per_step"] for j in ranks) * (n / len(ranks)) * base["steps"]
