@@ -2409,6 +2409,11 @@ extern "C" int mi3pt_submit_frames(mi3pt_ctx *ctx, unsigned pass_mask, uint32_t 
         // the frame counters alone and join the queue as copies -- what mi3pt_submit would do for each of them after checking the
         // scene, the variant and the batch compatibility again (0.3 ms of a rank's 9.6 ms job for 256 frames, before anything was
         // launched: profiles/r04_e_rank_job_host.log).  The queue is launched at the same depth as there.
+        // INVARIANT this fast path rests on (round-4 advice): between two frames INSIDE this call nothing can change -- no upload, no
+        // uniform other than the two frame counters, no option, no resize: single-threaded entry, and every such change is an entry
+        // point of its own -- so batch_compatible, check_scene and the prepare_* steps, which that first mi3pt_submit just ran, would
+        // give the same answers for every copy.  tests/test_gpu_gate.py holds it to `count` separate submits across a capacity
+        // boundary and with the cost-ordered job lists (whose per-launch state flush_pending advances, as for separate submits).
         if (queues_only && ctx->pending.size() == queued_before + 1) {
             while (i + 1 < count && (int)ctx->pending.size() < ctx->batch_cap) {
                 mi3pt_ctx::PendingFrame nf = ctx->pending.back();
