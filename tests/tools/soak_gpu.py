@@ -142,7 +142,7 @@ def soak_options():
         sc = scene(name)
         with capi.Context(0) as base:
             pc.upload_scene(base, sc, ENV)
-            for _ in range(40):
+            for _ in range(int(os.environ.get("SOAK_OPTIONS", "40"))):
                 w, h, frames = int(rng.choice([64, 200, 333, 640])), int(rng.choice([40, 113, 360])), int(rng.choice([1, 3, 16, 40]))
                 want, cw = render(base, sc, w, h, frames, bounces=6)
                 opts = {capi.OPT_WALK_MIN: int(rng.choice([1, 8, 24, 32, 48, 64])), capi.OPT_LEAF_MIN: int(rng.choice([1, 8, 24, 32, 64])),
@@ -151,7 +151,13 @@ def soak_options():
                         capi.OPT_JOB_GROUP: int(rng.choice([-1, 0, 1, 7, 100, 5000])), capi.OPT_JOB_CHUNK: int(rng.choice([1, 2, 4, 7, 64])),
                         capi.OPT_BATCH: int(rng.choice([1, 2, 5, 16, 64])), capi.OPT_WAVES_PER_CU: int(rng.choice([0, 1, 3, 8, 12, 16, 20, 24])),
                         capi.OPT_GATE: int(rng.integers(0, 2)), capi.OPT_COST_ORDER: int(rng.integers(0, 2)),
-                        capi.OPT_WIDE: int(rng.integers(0, 2)), capi.OPT_CULL: int(rng.integers(0, 2))}
+                        capi.OPT_WIDE: int(rng.integers(0, 2)), capi.OPT_CULL: int(rng.integers(0, 2)),
+                        # round 5: five / six waves per SIMD (walk_min 44 picks the deep builds: six waves = a 25-entry stack and the parked
+                        # path state in memory), the camera base image, the packet numbering
+                        capi.OPT_SIX_WAVES: int(rng.integers(-1, 2)), capi.OPT_CAMERA_BASE: int(rng.integers(0, 2)),
+                        capi.OPT_PACKET_ORDER: int(rng.integers(0, 3))}
+                if rng.random() < 0.3:
+                    opts[capi.OPT_WALK_MIN] = 44
                 with capi.Context(0) as c:
                     for k, v in opts.items():
                         c.set_option(k, v)
