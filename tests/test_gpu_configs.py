@@ -1,8 +1,7 @@
 """BASELINE.json configs 2-5 as parity-test cases at the sizes BASELINE.json states (config 1 is in
 test_gpu_parity.py / test_golden.py).  The shipped kernel is held to the ORACLE on whole images:
-config 2 for its whole 64-spp job, config 3 for three whole 1080p frames (and a sixteenth of the
-image for all 256 spp), config 4 for two whole 4K frames with the thin lens (and one row block
-for all 1024 spp), config 5 for a quarter of the 4K image (two ranks of the 8-way split; a whole
+config 2 for its whole 64-spp job, config 3 -- the headline's -- for its whole 256-spp job, config 4
+for two whole 4K frames with the thin lens (and four row blocks for all 1024 spp), config 5 for a quarter of the 4K image (two ranks of the 8-way split; a whole
 frame of the 10 M-triangle forest is most of a minute of oracle).  The oracle's passes run on
 the box's CPU share (pt_oracle.default_threads: the cgroup quota, not the 256 processors OpenMP
 sees).  Beside that: bit-identity with the per-pixel kernel (variant 2, the WGSL control flow),
@@ -227,8 +226,9 @@ def test_config2_demo_1080p_64spp(gpu_ctx, orc, demo, env):
 
 
 def test_config3_dragon_class_1080p_256spp(gpu_ctx, orc, dragon, env):
-    """Config 3 at its stated 256 spp: one 256-frame launch of the shipped kernel (the default batch depth); a
-    sixteenth of the image (8-row blocks from top to bottom) against the oracle's 256 frames."""
+    """Config 3 -- the configuration the headline metric is quoted on -- at its stated 256 spp: one 256-frame launch of the shipped
+    kernel (the default batch depth, the six-wave build) against the ORACLE's 256 whole frames and their running mean (about 75 s of
+    oracle on the box's 16-core share), and against the per-pixel kernel."""
     w, h, spp = 1920, 1080, 256
     ctx = gpu_ctx
     pc.upload_scene(ctx, dragon, env)
@@ -239,9 +239,9 @@ def test_config3_dragon_class_1080p_256spp(gpu_ctx, orc, dragon, env):
     assert ctx.active_variant() == 13          # the shipped choice: compressed wide packets, one-axis culling condition (this scene's hint)
     _same_job(got, cgot, ref, cref, spp * w * h)
     assert cgot["tri_tests"] <= cref["tri_tests"]
-    want, _ = _oracle_image(orc, dragon, env, w, h, range(2, 2 + spp), 5, 16, 8)
-    share = got[tiles.local_rows_of(h, 5, 16, 8)]
-    assert pc.same_bits(share, want), "config 3, 256 spp, 1/16 of the image vs oracle: " + pc.describe_diff(share, want)
+    assert ctx.last_launch()["workgroups"] == 24 * 256          # six waves per SIMD: 8.3 M jobs in the launch
+    want, cwant = _oracle_image(orc, dragon, env, w, h, range(2, 2 + spp))
+    _same_as_oracle(got, cgot, want, cwant, "config 3, 256 spp, the WHOLE image vs oracle")
     for v in pc.variants_available(ctx, (10, 11, 12)):                     # ... and the exact-packet wide walks, on a shorter job
         a, ca = _render_spp(ctx, dragon, w, h, 16, variant=v)
         b, cb = _render_spp(ctx, dragon, w, h, 16)
@@ -265,10 +265,11 @@ def test_config4_dragon_dof_4k_1024spp_one_rank_of_4(gpu_ctx, orc, dragon, env):
     got, cgot = _render_spp(ctx, dragon, w, h, spp, **kw)
     _same_job(got, cgot, ref, cref, spp * w * ctx.local_rows)
     mine = tiles.local_rows_of(h, 1, 4, 8)
-    first = next(y for y in mine if y >= 1100 and y % 8 == 0)          # a block of this rank's through the model
-    want = _oracle_block(orc, dragon, env, w, h, range(2, 2 + spp), first, **kw)
-    at = mine.index(first)
-    assert pc.same_bits(got[at:at + 8], want), "config 4, 1024 spp, one block vs oracle: " + pc.describe_diff(got[at:at + 8], want)
+    for lo in (400, 1100, 1400, 1900):                                 # four blocks of this rank's: sky, through the model (twice), floor
+        first = next(y for y in mine if y >= lo and y % 8 == 0)
+        want = _oracle_block(orc, dragon, env, w, h, range(2, 2 + spp), first, **kw)
+        at = mine.index(first)
+        assert pc.same_bits(got[at:at + 8], want), f"config 4, 1024 spp, the block at row {first} vs oracle: " + pc.describe_diff(got[at:at + 8], want)
     ctx.set_tile(0, 1, 8)
     ctx.resize(64, 64)
 
@@ -287,11 +288,11 @@ def test_config5_forest_4k_4096spp_one_rank_of_8(gpu_ctx, orc, forest, env):
     got, cgot = _render_spp(ctx, forest, w, h, spp)
     assert ctx.active_variant() == 13          # the shipped choice: compressed wide packets, three-axis culling condition (this scene's margins are not negligible)
     _same_job(got, cgot, ref, cref, spp * w * ctx.local_rows)
-    short, _ = _render_spp(ctx, forest, w, h, 8)
+    short, _ = _render_spp(ctx, forest, w, h, 32)
     mine = tiles.local_rows_of(h, 3, 8, 8)
     first = next(y for y in mine if y >= 1200 and y % 8 == 0)          # a block of this rank's among the trees
-    want = _oracle_block(orc, forest, env, w, h, range(2, 10), first)
+    want = _oracle_block(orc, forest, env, w, h, range(2, 34), first)
     at = mine.index(first)
-    assert pc.same_bits(short[at:at + 8], want), "config 5, 8 spp, one block vs oracle: " + pc.describe_diff(short[at:at + 8], want)
+    assert pc.same_bits(short[at:at + 8], want), "config 5, 32 spp, one block vs oracle: " + pc.describe_diff(short[at:at + 8], want)
     ctx.set_tile(0, 1, 8)
     ctx.resize(64, 64)
