@@ -43,7 +43,8 @@ extern "C" {
 /* 3 (round 5): mi3pt_set_tile deals the row blocks back and forth (ABI 2 as first released dealt them one way: a host that
  * de-interleaves gathered rows must use mi3pt_tile_global_row / mi3pt_tile_owner, not its own copy of the old formula);
  * MI3PT_OPT_BATCH defaults to 256 frames per launch (was 64), MI3PT_OPT_WALK_MIN reads 0 = "by the size of the tree" (was 32);
- * new exports mi3pt_tile_global_row, mi3pt_tile_owner; new options MI3PT_OPT_GATE_TIMEOUT_MS, MI3PT_OPT_GATE_RELEASES. */
+ * new exports mi3pt_tile_global_row, mi3pt_tile_owner; new options MI3PT_OPT_GATE_TIMEOUT_MS, MI3PT_OPT_GATE_RELEASES, MI3PT_OPT_CAMERA_BASE,
+ * MI3PT_OPT_PACKET_ORDER, MI3PT_OPT_SIX_WAVES (22 .. 27); MI3PT_OPT_WAVES_PER_CU reads up to 24 (six waves per SIMD). */
 #define MI3PT_ABI_VERSION 3
 
 typedef enum mi3pt_status {
