@@ -55,6 +55,14 @@ for waves in (4, 5, 6, 8):
     ms, _ = ctx.walk_probe(mix, waves, repeats=3, passes=16)
     base = base or ms
     print(f"  {waves} waves per SIMD: {ms:.3f} ms for 16 passes  {16 * len(mix) / ms / 1e3:.0f} Mrays/s walk-only  ({base / ms:.2f}x the 4-wave rate)")
+# the SHIPPED walk alone (round 5: compressed wide packets, distance culling, paired triangle steps -- k_walk_probe_cw), every idle lane
+# refilled at once: what a wave that does nothing but walk sustains, and whether its hits are the reference walk's
+_, ref_hits = ctx.walk_probe(mix, 4, repeats=1, want_hits=True)
+for waves in (5, 6, 7, 8):
+    ms, hits = ctx.walk_probe(mix, 100 + waves, repeats=3, passes=16, want_hits=True)
+    same = np.array_equal(hits.view(np.uint32), ref_hits.view(np.uint32))
+    print(f"  compressed-wide walk, {waves} waves per SIMD: {ms:.3f} ms for 16 passes  {16 * len(mix) / ms / 1e3:.0f} Mrays/s walk-only   hits identical to the reference walk's: {same}"
+          + ("" if same else f" ({int((hits.view(np.uint32) != ref_hits.view(np.uint32)).any(axis=1).sum())} rays differ)"))
 # reference point: the coherent primary rays alone
 for waves in (4, 8):
     ms, _ = ctx.walk_probe(generations[0], waves, repeats=3, passes=16)

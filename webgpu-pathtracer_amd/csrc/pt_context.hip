@@ -2783,25 +2783,30 @@ extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t 
     if (passes < 1) passes = 1;
     if (!rays || !ms_out || n == 0 || n * (size_t)passes > 0x7fffffffu) return pt_set_error(MI3PT_ERR_INVALID, "bad argument");
     if (int rc = check_scene(ctx)) return rc;
+    if (waves_per_simd >= 100) {          // the shipped compressed-wide walk: its packets come from the scene analysis
+        if (int rc = prepare_layout(ctx)) return rc;
+        if (int rc = prepare_cull(ctx)) return rc;
+        if (!(ctx->wide_ok && ctx->cwide_ok)) return pt_set_error(MI3PT_ERR_STATE, "the scene does not admit the compressed-wide walk");
+    }
     const int lcap = ctx->leaf_cap - (pt::SM_LDS_DEPTH - 16);        // the probe keeps 16 stack entries per lane in LDS
-    if (ctx->nnodes == 0 || lcap < 4) return pt_set_error(MI3PT_ERR_STATE, "the scene's tree is too deep for the walk probe");
+    if (ctx->nnodes == 0 || (lcap < 4 && waves_per_simd < 100)) return pt_set_error(MI3PT_ERR_STATE, "the scene's tree is too deep for the walk probe");
     float *d_rays = nullptr;
     float4 *d_out = nullptr;
     uint32_t *d_counter = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipMalloc((void **)&d_rays, n * 24);
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * 16);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_counter, 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_counter, 8);
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * 24, hipMemcpyHostToDevice, ctx->stream);
     float best_ms = 0.0f;
     for (int r = 0; e == hipSuccess && r < (repeats > 0 ? repeats : 1); r++) {
-        e = hipMemsetAsync(d_counter, 0, 4, ctx->stream);
+        e = hipMemsetAsync(d_counter, 0, 8, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
         if (e == hipSuccess && !pt::launch_walk_probe(scene_refs(ctx), d_rays, (uint32_t)n, (uint32_t)(n * (size_t)passes), d_counter, d_out, waves_per_simd, lcap,
                                                       ctx->leaf_min, ctx->num_cus, ctx->stream)) {
-            pt_set_error(MI3PT_ERR_INVALID, "waves_per_simd must be 4, 5, 6 or 8");
+            pt_set_error(MI3PT_ERR_INVALID, "waves_per_simd must be 4, 5, 6 or 8 (100 + 5 .. 8: the compressed-wide walk)");
             e = hipErrorInvalidValue;
         }
         if (e == hipSuccess) e = hipGetLastError();

@@ -3169,11 +3169,205 @@ __global__ void __launch_bounds__(64, MINW) k_walk_probe(const SceneRefs sc, con
     }
 }
 
+// The same experiment with the SHIPPED walk (round 5): compressed wide packets, distance culling, deferred leaves with the paired
+// triangle step -- k_raytrace_sm's node and triangle steps transcribed -- over a list of rays with every idle lane refilled at once.
+// What a wave that does NOTHING but walk sustains, at 5 .. 8 waves per SIMD: the walking half of a design whose waves specialise
+// (DESIGN.md 7).  Rays whose node entries would leave the LDS part of the stack lose them (counted in counter[1]): the probe is for
+// timing on trees whose walks fit, and its hits are compared with the reference walk's by the caller.
+template <int MINW, int DEPTH, bool YMAX>
+__global__ void __launch_bounds__(64, MINW) k_walk_probe_cw(const SceneRefs sc, const float *__restrict__ rays, uint32_t nrays, uint32_t total,
+                                                            uint32_t *__restrict__ counter, float4 *__restrict__ out, int leaf_min)
+{
+    constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;
+    __shared__ uint32_t stack_lds[DEPTH * 64];
+    const int lane = threadIdx.x;
+    uint32_t *stack = stack_lds + lane;
+    f3 o = F3(0.0f, 0.0f, 0.0f), d = o;
+    RayPre pre;
+    pre.ix = pre.iy = pre.iz = 0.0f; pre.flags = 8u;
+    Best best;
+    best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
+    float cull_ka = __builtin_inff(), cull_kb = __builtin_inff();
+    int sp = 0, nl = 0;
+    uint32_t ray = 0xffffffffu, dropped = 0u;
+    bool exhausted = false;
+    uint32_t chunk_next = 0u, chunk_left = 0u;
+    auto push = [&](uint32_t ref) {
+        const bool lf = (ref & PT_REF_LEAF) != 0u;
+        if (lf || sp < NCAP) stack[(lf ? DEPTH - 1 - nl : sp) * 64] = ref;
+        else dropped++;
+        nl += (lf && ref != PT_REF_NONE) ? 1 : 0;
+        sp += (lf || sp >= NCAP) ? 0 : 1;
+    };
+    for (;;) {
+        const unsigned long long idle = __ballot(ray == 0xffffffffu);
+        if (idle != 0ull && !exhausted) {
+            if (chunk_left == 0u) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(counter, 2048u);
+                chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                chunk_left = chunk_next < total ? min(2048u, total - chunk_next) : 0u;
+                if (chunk_left == 0u) exhausted = true;
+            }
+            const uint32_t take = min((uint32_t)__popcll(idle), chunk_left);
+            const uint32_t rank = (uint32_t)lane_rank(idle);
+            if (ray == 0xffffffffu && rank < take) {
+                uint32_t mine = (chunk_next + rank) % nrays;
+                ray = mine;
+                o = F3(rays[(size_t)mine * 6 + 0], rays[(size_t)mine * 6 + 1], rays[(size_t)mine * 6 + 2]);
+                d = F3(rays[(size_t)mine * 6 + 3], rays[(size_t)mine * 6 + 4], rays[(size_t)mine * 6 + 5]);
+                best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
+                sp = nl = 0;
+                const bool nan_ray = !(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z) || !(o.x == o.x) || !(o.y == o.y) || !(o.z == o.z);
+                if (!nan_ray) {
+                    pre = ray_prepare(o, d, sc.flags);
+                    cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
+                    const float4 root0 = sc.nodes[0], root1 = sc.nodes[1];
+                    if ((sc.flags & 2u) != 0u || ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
+                        stack[0] = sc.wide_root;
+                        sp = 1;
+                    }
+                }
+            }
+            chunk_next += take;
+            chunk_left -= take;
+        }
+        if (ray != 0xffffffffu && sp == 0 && nl == 0) {
+            out[ray] = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
+            ray = 0xffffffffu;
+        }
+        if (__ballot(ray != 0xffffffffu) == 0ull) { if (exhausted) break; else continue; }
+        for (int it = 0; it < 4; it++) {
+            const bool has_node = sp > 0, has_leaf = nl > 0;
+            const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
+            if (n_node == 0 && n_leaf == 0) break;
+            const bool full = __ballot(nl > LCAP - 4) != 0ull;
+            if (full || n_node == 0 || n_leaf >= leaf_min) {
+                const bool two = nl > 1;
+                if (has_leaf) {
+                    nl--;
+                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu;
+                    uint32_t tj = ti;
+                    if (two) { nl--; tj = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu; }
+                    float4 pa = sc.tripk64[(size_t)ti * 4 + 0], pb = sc.tripk64[(size_t)ti * 4 + 1], pc = sc.tripk64[(size_t)ti * 4 + 2], pd = sc.tripk64[(size_t)ti * 4 + 3];
+                    float4 qa, qb, qc, qd;
+                    if constexpr (!YMAX) { qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f); qb = qa; qc = qa; qd = qa; }
+                    if (two) { qa = sc.tripk64[(size_t)tj * 4 + 0]; qb = sc.tripk64[(size_t)tj * 4 + 1]; qc = sc.tripk64[(size_t)tj * 4 + 2]; qd = sc.tripk64[(size_t)tj * 4 + 3]; }
+                    keep16<YMAX>(pa); keep16<YMAX>(pb); keep16<YMAX>(pc); keep16<YMAX>(pd);
+                    {
+                        float t, u, v;
+                        const bool inbox = leaf_box_hit(o, d, pre, __float_as_uint(pd.w) != 0u, F3(pc.y, pc.z, pc.w), F3(pd.x, pd.y, pd.z));
+                        const bool hit = ray_triangle_flat_e(o, d, F3(pa.x, pa.y, pa.z), F3(pa.w, pb.x, pb.y), F3(pb.z, pb.w, pc.x), t, u, v) && inbox;
+                        bool take = hit && t < best.t;
+                        if (hit && t == best.t && best.tri >= 0) take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
+                        best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                        best.tri = take ? (int32_t)ti : best.tri;
+                    }
+                    if (two) {
+                        keep16<YMAX>(qa); keep16<YMAX>(qb); keep16<YMAX>(qc); keep16<YMAX>(qd);
+                        float t, u, v;
+                        const bool inbox = leaf_box_hit(o, d, pre, __float_as_uint(qd.w) != 0u, F3(qc.y, qc.z, qc.w), F3(qd.x, qd.y, qd.z));
+                        const bool hit = ray_triangle_flat_e(o, d, F3(qa.x, qa.y, qa.z), F3(qa.w, qb.x, qb.y), F3(qb.z, qb.w, qc.x), t, u, v) && inbox;
+                        bool take = hit && t < best.t;
+                        if (hit && t == best.t && best.tri >= 0) take = sc.leaf_rank[tj] < sc.leaf_rank[best.tri];
+                        best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                        best.tri = take ? (int32_t)tj : best.tri;
+                    }
+                }
+            } else if (has_node) {
+                sp--;
+                const uint32_t ref = stack[sp * 64];
+                uint32_t cr[4];
+                bool hit[4];
+                float key[4];
+                f3 tn[4];
+                if constexpr (YMAX) { key[0] = key[1] = key[2] = key[3] = -PT_INF; }
+                const float4 *P = sc.cwide + (size_t)ref * 4;
+                const float4 c0 = P[0], c1 = P[1], c2 = P[2], c3 = P[3];
+                cr[0] = __float_as_uint(c3.x); cr[1] = __float_as_uint(c3.y); cr[2] = __float_as_uint(c3.z); cr[3] = __float_as_uint(c3.w);
+                const uint32_t meta = __float_as_uint(c0.w);
+                const uint32_t w01 = __float_as_uint(c2.z), w23 = __float_as_uint(c2.w);
+                const uint32_t lx = __float_as_uint(c1.x), ly = __float_as_uint(c1.y), lz = __float_as_uint(c1.z);
+                const uint32_t hx = __float_as_uint(c1.w), hy = __float_as_uint(c2.x), hz = __float_as_uint(c2.y);
+                const float cx = __uint_as_float((meta & 0xffu) << 23), cy = __uint_as_float(((meta >> 8) & 0xffu) << 23), cz = __uint_as_float(((meta >> 16) & 0xffu) << 23);
+                if ((pre.flags & 8u) == 0u) {
+                    const float Ax = (c0.x - o.x) * pre.ix, Ay = (c0.y - o.y) * pre.iy, Az = (c0.z - o.z) * pre.iz;
+                    const float Bx = cx * pre.ix, By = cy * pre.iy, Bz = cz * pre.iz;
+                    const bool nx_ = pre.ix < 0.0f, ny_ = pre.iy < 0.0f, nz_ = pre.iz < 0.0f;
+                    const uint32_t ex = nx_ ? hx : lx, fx = nx_ ? lx : hx, ey = ny_ ? hy : ly, fy = ny_ ? ly : hy, ez = nz_ ? hz : lz, fz = nz_ ? lz : hz;
+#define PT_CBOX(K)                                                                                                          \
+                    {                                                                                                      \
+                        const float ax_ = fmaf((float)((ex >> (8 * K)) & 0xffu), Bx, Ax), bx_ = fmaf((float)((fx >> (8 * K)) & 0xffu), Bx, Ax); \
+                        const float ay_ = fmaf((float)((ey >> (8 * K)) & 0xffu), By, Ay), by_ = fmaf((float)((fy >> (8 * K)) & 0xffu), By, Ay); \
+                        const float az_ = fmaf((float)((ez >> (8 * K)) & 0xffu), Bz, Az), bz_ = fmaf((float)((fz >> (8 * K)) & 0xffu), Bz, Az); \
+                        const f3 a_ = F3(ax_, ay_, az_);                                                                   \
+                        const float f_ = fminf(fminf(bx_, by_), bz_);                                                      \
+                        key[K] = fmaxf(fmaxf(a_.x, a_.y), a_.z);                                                           \
+                        if constexpr (!YMAX) tn[K] = a_;                                                                   \
+                        hit[K] = cwide_hit(key[K], f_);                                                                    \
+                    }
+                    PT_CBOX(0) PT_CBOX(1) PT_CBOX(2) PT_CBOX(3)
+#undef PT_CBOX
+                } else {
+                    if constexpr (!YMAX) {
+                        key[0] = key[1] = key[2] = key[3] = -PT_INF;
+                        tn[0] = tn[1] = tn[2] = tn[3] = F3(-PT_INF, -PT_INF, -PT_INF);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        hit[k] = ray_aabb(o, d, fmaf((float)((lx >> (8 * k)) & 0xffu), cx, c0.x), fmaf((float)((ly >> (8 * k)) & 0xffu), cy, c0.y), fmaf((float)((lz >> (8 * k)) & 0xffu), cz, c0.z),
+                                          fmaf((float)((hx >> (8 * k)) & 0xffu), cx, c0.x), fmaf((float)((hy >> (8 * k)) & 0xffu), cy, c0.y), fmaf((float)((hz >> (8 * k)) & 0xffu), cz, c0.z));
+                }
+                const float rc = fmaf(cull_ka, best.t, cull_kb);
+                const float bt = best.t * 1.00000095367431640625f;
+                const float wgt[4] = { __uint_as_float(w01 & 0xffff0000u), __uint_as_float(w01 << 16), __uint_as_float(w23 & 0xffff0000u), __uint_as_float(w23 << 16) };
+                const float ymax = fmaxf(fmaxf(fabsf(pre.ix), fabsf(pre.iy)), fabsf(pre.iz));
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float dk = wgt[k] * rc;
+                    float tc;
+                    if constexpr (YMAX) tc = fmaf(-dk, ymax, key[k]);
+                    else tc = fmaxf(fmaxf(fmaf(-dk, fabsf(pre.ix), tn[k].x), fmaf(-dk, fabsf(pre.iy), tn[k].y)), fmaf(-dk, fabsf(pre.iz), tn[k].z));
+                    cr[k] = (hit[k] && !(tc > bt)) ? cr[k] : PT_REF_NONE;
+                }
+#define PT_CSWAP(A, B)                                                                         \
+                {                                                                              \
+                    const bool sw = key[A] < key[B];                                           \
+                    const float ka_ = sw ? key[B] : key[A], kb_ = sw ? key[A] : key[B];        \
+                    const uint32_t ra_ = sw ? cr[B] : cr[A], rb_ = sw ? cr[A] : cr[B];         \
+                    key[A] = ka_; key[B] = kb_; cr[A] = ra_; cr[B] = rb_;                      \
+                }
+                PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+#pragma unroll
+                for (int k = 0; k < 4; k++) push(cr[k]);
+            }
+        }
+    }
+    if (dropped) atomicAdd(counter + 1, dropped);
+}
+
 // returns 0 when the occupancy is not instantiated
 int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, uint32_t total, uint32_t *counter, float4 *out, int waves_per_simd,
                       int lcap, int leaf_min, int num_cus, hipStream_t s)
 {
     const dim3 block(64);
+    if (waves_per_simd >= 100) {          // 100 + w: the shipped compressed-wide walk at w waves per SIMD (k_walk_probe_cw)
+        const int w = waves_per_simd - 100;
+        if (!sc.cwide || !sc.tripk64) return 0;
+        const dim3 g((num_cus > 0 ? num_cus : 256) * 4 * w);
+        const bool ymax = (sc.flags & 4u) != 0u;
+#define PT_WP(W, D) do { if (ymax) hipLaunchKernelGGL((k_walk_probe_cw<W, D, true>), g, block, 0, s, sc, rays, nrays, total, counter, out, leaf_min); \
+                         else hipLaunchKernelGGL((k_walk_probe_cw<W, D, false>), g, block, 0, s, sc, rays, nrays, total, counter, out, leaf_min); return 1; } while (0)
+        switch (w) {      // LDS per wave = DEPTH x 256 B, in 1 280-byte granules: 20 / 24 / 28 / 32 waves per CU
+        case 5: PT_WP(5, 30);
+        case 6: PT_WP(6, 25);
+        case 7: PT_WP(7, 20);
+        case 8: PT_WP(8, 20);
+        default: return 0;
+        }
+#undef PT_WP
+    }
     const dim3 grid((num_cus > 0 ? num_cus : 256) * 4 * waves_per_simd);
     switch (waves_per_simd) {
     case 4: hipLaunchKernelGGL((k_walk_probe<4, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
