@@ -39,7 +39,7 @@ d /= np.linalg.norm(d, axis=1, keepdims=True)
 rays = np.concatenate([np.broadcast_to(cam, d.shape), d], axis=1).astype(np.float32)
 generations = [rays]
 for g in range(3):
-    ms, hits = ctx.walk_probe(generations[-1], 4, repeats=1, want_hits=True)
+    ms, hits = ctx.walk_probe(generations[-1], 4 if workload == "demo" else 105, repeats=1, want_hits=True)      # (the legacy probe's 16-entry stack does not hold the large tree)
     hit = hits[:, 3].view(np.int32) >= 0
     src = generations[-1][hit]
     pos = src[:, :3] + src[:, 3:] * hits[hit, 0:1]
@@ -51,20 +51,27 @@ for g in range(3):
 mix = np.concatenate(generations)
 print(f"{workload} {w}x{h}: ray mix {len(mix)} rays ({', '.join(str(len(g)) for g in generations)} per generation)")
 base = None
-for waves in (4, 5, 6, 8):
+for waves in ((4, 5, 6, 8) if workload == "demo" else ()):
     ms, _ = ctx.walk_probe(mix, waves, repeats=3, passes=16)
     base = base or ms
     print(f"  {waves} waves per SIMD: {ms:.3f} ms for 16 passes  {16 * len(mix) / ms / 1e3:.0f} Mrays/s walk-only  ({base / ms:.2f}x the 4-wave rate)")
 # the SHIPPED walk alone (round 5: compressed wide packets, distance culling, paired triangle steps -- k_walk_probe_cw), every idle lane
 # refilled at once: what a wave that does nothing but walk sustains, and whether its hits are the reference walk's
-_, ref_hits = ctx.walk_probe(mix, 4, repeats=1, want_hits=True)
-for waves in (5, 6, 7, 8):
-    ms, hits = ctx.walk_probe(mix, 100 + waves, repeats=3, passes=16, want_hits=True)
-    same = np.array_equal(hits.view(np.uint32), ref_hits.view(np.uint32))
-    print(f"  compressed-wide walk, {waves} waves per SIMD: {ms:.3f} ms for 16 passes  {16 * len(mix) / ms / 1e3:.0f} Mrays/s walk-only   hits identical to the reference walk's: {same}"
-          + ("" if same else f" ({int((hits.view(np.uint32) != ref_hits.view(np.uint32)).any(axis=1).sum())} rays differ)"))
+if workload == "demo":
+    _, ref_hits = ctx.walk_probe(mix, 4, repeats=1, want_hits=True)
+else:                                   # the per-ray reference walk (t, u, v of the closest hit: columns 1 .. of mi3pt_debug_intersect are position-based; compare t only)
+    ref_hits = None
+for refill_min in (1, 8, 16, 24, 32):          # idle lanes that trigger a refill (each refill is a memory round trip for the wave, like a service step)
+    ctx.set_option(capi.OPT_TOP_PACKETS, refill_min)
+    for waves in (5, 6, 7):
+        ms, hits = ctx.walk_probe(mix, 100 + waves, repeats=3, passes=16, want_hits=True)
+        note = capi.last_error()
+        same = np.array_equal(hits.view(np.uint32), ref_hits.view(np.uint32)) if ref_hits is not None else "n/a"
+        print(f"  compressed-wide walk, refill at {refill_min:2d} idle lanes, {waves} waves per SIMD: {ms:.3f} ms for 16 passes  {16 * len(mix) / ms / 1e3:.0f} Mrays/s walk-only   "
+              f"[{note}]   hits identical to the reference walk's: {same}"
+              + ("" if same in (True, "n/a") else f" ({int((hits.view(np.uint32) != ref_hits.view(np.uint32)).any(axis=1).sum())} rays differ)"), flush=True)
 # reference point: the coherent primary rays alone
-for waves in (4, 8):
+for waves in ((4, 8) if workload == "demo" else ()):
     ms, _ = ctx.walk_probe(generations[0], waves, repeats=3, passes=16)
     print(f"  primary rays only, {waves} waves per SIMD: {ms:.3f} ms for 16 passes  {16 * len(generations[0]) / ms / 1e3:.0f} Mrays/s")
 # cost of the mix in the reference's own unit: box tests per ray (the full kernel's frames average 10.4 on this scene)

@@ -2796,15 +2796,17 @@ extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipMalloc((void **)&d_rays, n * 24);
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * 16);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_counter, 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_counter, 16);
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * 24, hipMemcpyHostToDevice, ctx->stream);
     float best_ms = 0.0f;
     for (int r = 0; e == hipSuccess && r < (repeats > 0 ? repeats : 1); r++) {
-        e = hipMemsetAsync(d_counter, 0, 8, ctx->stream);
+        e = hipMemsetAsync(d_counter, 0, 16, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
-        if (e == hipSuccess && !pt::launch_walk_probe(scene_refs(ctx), d_rays, (uint32_t)n, (uint32_t)(n * (size_t)passes), d_counter, d_out, waves_per_simd, lcap,
+        // (the compressed-wide probe takes its refill threshold -- idle lanes that trigger a refill -- where the other one takes lcap: MI3PT_OPT_TOP_PACKETS)
+        if (e == hipSuccess && !pt::launch_walk_probe(scene_refs(ctx), d_rays, (uint32_t)n, (uint32_t)(n * (size_t)passes), d_counter, d_out, waves_per_simd,
+                                                      waves_per_simd >= 100 ? std::max(1, std::min(ctx->top_packets, 64)) : lcap,
                                                       ctx->leaf_min, ctx->num_cus, ctx->stream)) {
             pt_set_error(MI3PT_ERR_INVALID, "waves_per_simd must be 4, 5, 6 or 8 (100 + 5 .. 8: the compressed-wide walk)");
             e = hipErrorInvalidValue;
@@ -2817,6 +2819,11 @@ extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t 
         if (e == hipSuccess && (r == 0 || ms < best_ms)) best_ms = ms;
     }
     if (e == hipSuccess && out_tuvi) e = hipMemcpy(out_tuvi, d_out, n * 16, hipMemcpyDeviceToHost);
+    uint32_t stats[4] = { 0, 0, 0, 0 };
+    if (e == hipSuccess) e = hipMemcpy(stats, d_counter, 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && waves_per_simd >= 100)       // (a note, not an error: the probe's statistics of its last repeat)
+        pt_set_error(MI3PT_OK, "walk probe: lanes per step " + std::to_string(stats[3] ? (double)stats[2] / stats[3] : 0.0) +
+                               " dropped " + std::to_string(stats[1]));
     for (void *p : { (void *)d_rays, (void *)d_out, (void *)d_counter })
         if (p) (void)hipFree(p);
     if (e0) (void)hipEventDestroy(e0);

@@ -3176,7 +3176,7 @@ __global__ void __launch_bounds__(64, MINW) k_walk_probe(const SceneRefs sc, con
 // timing on trees whose walks fit, and its hits are compared with the reference walk's by the caller.
 template <int MINW, int DEPTH, bool YMAX>
 __global__ void __launch_bounds__(64, MINW) k_walk_probe_cw(const SceneRefs sc, const float *__restrict__ rays, uint32_t nrays, uint32_t total,
-                                                            uint32_t *__restrict__ counter, float4 *__restrict__ out, int leaf_min)
+                                                            uint32_t *__restrict__ counter, float4 *__restrict__ out, int leaf_min, int refill_min)
 {
     constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;
     __shared__ uint32_t stack_lds[DEPTH * 64];
@@ -3189,7 +3189,9 @@ __global__ void __launch_bounds__(64, MINW) k_walk_probe_cw(const SceneRefs sc, 
     best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
     float cull_ka = __builtin_inff(), cull_kb = __builtin_inff();
     int sp = 0, nl = 0;
-    uint32_t ray = 0xffffffffu, dropped = 0u;
+    uint32_t ray = 0xffffffffu, dropped = 0u, lanes_sum = 0u, steps_sum = 0u;
+    uint32_t nray = 0xfffffffeu;          // the ray fetched ahead (0xfffffffe: none yet -- a dummy that is retired without a result)
+    f3 no = F3(0.0f, 0.0f, 0.0f), nd = F3(0.0f, 1.0f, 0.0f);
     bool exhausted = false;
     uint32_t chunk_next = 0u, chunk_left = 0u;
     auto push = [&](uint32_t ref) {
@@ -3199,8 +3201,29 @@ __global__ void __launch_bounds__(64, MINW) k_walk_probe_cw(const SceneRefs sc, 
         nl += (lf && ref != PT_REF_NONE) ? 1 : 0;
         sp += (lf || sp >= NCAP) ? 0 : 1;
     };
+    auto start_segment = [&]() {
+        best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
+        sp = nl = 0;
+        const bool nan_ray = !(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z) || !(o.x == o.x) || !(o.y == o.y) || !(o.z == o.z);
+        if (!nan_ray && ray != 0xfffffffeu) {
+            pre = ray_prepare(o, d, sc.flags);
+            cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
+            const float4 root0 = sc.nodes[0], root1 = sc.nodes[1];
+            if ((sc.flags & 2u) != 0u || ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
+                stack[0] = sc.wide_root;
+                sp = 1;
+            }
+        }
+    };
     for (;;) {
+        // retire finished rays, then refill -- once at least refill_min lanes are idle (or nothing is left to walk): every refill is a
+        // memory round trip for the wave (the rays come from a list), as a service step is in the real kernel
+        if (ray != 0xffffffffu && sp == 0 && nl == 0) {
+            if (ray != 0xfffffffeu) out[ray] = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
+            ray = 0xffffffffu;
+        }
         const unsigned long long idle = __ballot(ray == 0xffffffffu);
+        if ((int)__popcll(idle) >= refill_min || (idle != 0ull && __ballot(ray != 0xffffffffu) == 0ull))
         if (idle != 0ull && !exhausted) {
             if (chunk_left == 0u) {
                 uint32_t base = 0;
@@ -3212,35 +3235,31 @@ __global__ void __launch_bounds__(64, MINW) k_walk_probe_cw(const SceneRefs sc, 
             const uint32_t take = min((uint32_t)__popcll(idle), chunk_left);
             const uint32_t rank = (uint32_t)lane_rank(idle);
             if (ray == 0xffffffffu && rank < take) {
-                uint32_t mine = (chunk_next + rank) % nrays;
-                ray = mine;
-                o = F3(rays[(size_t)mine * 6 + 0], rays[(size_t)mine * 6 + 1], rays[(size_t)mine * 6 + 2]);
-                d = F3(rays[(size_t)mine * 6 + 3], rays[(size_t)mine * 6 + 4], rays[(size_t)mine * 6 + 5]);
-                best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
-                sp = nl = 0;
-                const bool nan_ray = !(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z) || !(o.x == o.x) || !(o.y == o.y) || !(o.z == o.z);
-                if (!nan_ray) {
-                    pre = ray_prepare(o, d, sc.flags);
-                    cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
-                    const float4 root0 = sc.nodes[0], root1 = sc.nodes[1];
-                    if ((sc.flags & 2u) != 0u || ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
-                        stack[0] = sc.wide_root;
-                        sp = 1;
-                    }
-                }
+                // the ray this lane fetched while it walked its last one (nray: one ray ahead; the first refill of a lane walks a
+                // dummy that misses everything): no memory round trip in the refill -- what a refill from an LDS queue filled by a
+                // serving wave would cost -- and the fetch of the ray after it goes out now
+                ray = nray;
+                o = no; d = nd;
+                const uint32_t mine = (chunk_next + rank) % nrays;
+                nray = mine;
+                no = F3(rays[(size_t)mine * 6 + 0], rays[(size_t)mine * 6 + 1], rays[(size_t)mine * 6 + 2]);
+                nd = F3(rays[(size_t)mine * 6 + 3], rays[(size_t)mine * 6 + 4], rays[(size_t)mine * 6 + 5]);
+                start_segment();
             }
             chunk_next += take;
             chunk_left -= take;
         }
-        if (ray != 0xffffffffu && sp == 0 && nl == 0) {
-            out[ray] = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
-            ray = 0xffffffffu;
+        if (exhausted && ray == 0xffffffffu && nray != 0xfffffffeu) {      // the list is handed out: the ray fetched ahead is this lane's last
+            ray = nray; nray = 0xfffffffeu;
+            o = no; d = nd;
+            start_segment();
         }
-        if (__ballot(ray != 0xffffffffu) == 0ull) { if (exhausted) break; else continue; }
-        for (int it = 0; it < 4; it++) {
+        if (__ballot(ray != 0xffffffffu && (sp > 0 || nl > 0)) == 0ull) { if (exhausted && __ballot(ray != 0xffffffffu || nray != 0xfffffffeu) == 0ull) break; else continue; }
+        lanes_sum += (uint32_t)__popcll(__ballot(ray != 0xffffffffu && (sp > 0 || nl > 0)));
+        steps_sum++;
+        {
             const bool has_node = sp > 0, has_leaf = nl > 0;
             const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
-            if (n_node == 0 && n_leaf == 0) break;
             const bool full = __ballot(nl > LCAP - 4) != 0ull;
             if (full || n_node == 0 || n_leaf >= leaf_min) {
                 const bool two = nl > 1;
@@ -3345,6 +3364,7 @@ __global__ void __launch_bounds__(64, MINW) k_walk_probe_cw(const SceneRefs sc, 
         }
     }
     if (dropped) atomicAdd(counter + 1, dropped);
+    if (lane == 0) { atomicAdd(counter + 2, lanes_sum >> 6); atomicAdd(counter + 3, steps_sum >> 6); }      // (in units of 64: mean walking lanes per step = 64 x c[2] / c[3]... both scaled alike)
 }
 
 // returns 0 when the occupancy is not instantiated
@@ -3357,8 +3377,8 @@ int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, ui
         if (!sc.cwide || !sc.tripk64) return 0;
         const dim3 g((num_cus > 0 ? num_cus : 256) * 4 * w);
         const bool ymax = (sc.flags & 4u) != 0u;
-#define PT_WP(W, D) do { if (ymax) hipLaunchKernelGGL((k_walk_probe_cw<W, D, true>), g, block, 0, s, sc, rays, nrays, total, counter, out, leaf_min); \
-                         else hipLaunchKernelGGL((k_walk_probe_cw<W, D, false>), g, block, 0, s, sc, rays, nrays, total, counter, out, leaf_min); return 1; } while (0)
+#define PT_WP(W, D) do { if (ymax) hipLaunchKernelGGL((k_walk_probe_cw<W, D, true>), g, block, 0, s, sc, rays, nrays, total, counter, out, leaf_min, lcap); \
+                         else hipLaunchKernelGGL((k_walk_probe_cw<W, D, false>), g, block, 0, s, sc, rays, nrays, total, counter, out, leaf_min, lcap); return 1; } while (0)
         switch (w) {      // LDS per wave = DEPTH x 256 B, in 1 280-byte granules: 20 / 24 / 28 / 32 waves per CU
         case 5: PT_WP(5, 30);
         case 6: PT_WP(6, 25);
