@@ -15,7 +15,8 @@ Headline workload (default) = the scene BASELINE.json's target is quoted on: the
 configs[1] (default demo mesh, 1,998 triangles) and is also measured, shorter, as `also.demo` -- and
 as `also.demo_presenting_every_frame` with the reference's whole render(): a de-noised, tone-mapped canvas per frame.
 
-N > 1 (launched by torch.distributed.run, one process per GPU): image tiles are dealt to the
+N > 1 (one process per GPU: launched by torch.distributed.run -- or by bench.py itself when `python bench.py --gpus N`
+is run plain, self_launch() -- ): image tiles are dealt to the
 ranks in 8-row blocks, the scene is replicated, there is NO per-frame communication, and the job
 ends with one RCCL gather of the HDR accumulation buffers to rank 0 (inside the timed region).
 Default `--scaling strong`: the metric is Mrays/s AT 1920x1080, so the one 1080p image is split
@@ -442,6 +443,56 @@ def roofline_block(m, pmc, source, num_cus):
     return block
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it (round-5 verdict: that command died here).  This process
+    becomes the launcher and never touches the GPU: it builds (compilers only), picks a free rendezvous port on 127.0.0.1 and
+    starts N fresh children of this same command line, one rank per GPU, with the variables torch.distributed.run would
+    set; rank 0's stdout (the one JSON line) is this process's stdout, the other ranks' stdout goes to stderr.  Returns
+    the first non-zero exit code of a child (the other children are then ended by PID), 0 when all succeed.  No exec,
+    no re-launch of a process that has initialised HIP."""
+    import signal
+    import socket
+    import __graft_entry__ as ge
+    ge.build(load=False)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MI3PT_BENCH_SELF_LAUNCHED="1")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                         stdout=None if r == 0 else sys.stderr))
+    rc, grace = 0, None
+    try:
+        while any(c.poll() is None for c in children):
+            failed = [c.returncode for c in children if c.poll() is not None and c.returncode != 0]
+            if failed and rc == 0:
+                rc, grace = failed[0], time.monotonic() + 20.0      # the others usually fail at their next collective by themselves
+            if grace is not None and time.monotonic() > grace:
+                for c in children:
+                    if c.poll() is None:
+                        c.send_signal(signal.SIGTERM)
+                grace = time.monotonic() + 10.0
+                for c in children:
+                    try:
+                        c.wait(timeout=max(grace - time.monotonic(), 0.1))
+                    except subprocess.TimeoutExpired:
+                        c.kill()
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for c in children:
+            if c.poll() is None:
+                c.kill()
+        rc = 130
+    for c in children:
+        c.wait()
+        if rc == 0 and c.returncode != 0:
+            rc = c.returncode
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -475,11 +526,15 @@ def main():
         if world != 1:
             raise SystemExit("--group is one process for all GPUs: do not launch it through torch.distributed.run")
         group_devices = [0] * args.gpus if os.environ.get("MI3PT_BENCH_REHEARSAL") == "1" else list(range(args.gpus))
+    elif "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches the GPU)
+        raise SystemExit(self_launch(args.gpus))
     elif world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N   (or: --gpus N --group)")
         args.gpus = world
 
+    if os.environ.get("MI3PT_BENCH_ECHO_RANK") == "1":      # (tests/test_bench_launcher.py)
+        print(f"bench.py rank {rank}/{world} local {local_rank} rendezvous {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+              file=sys.stderr, flush=True)
     # Build (make / g++ children) BEFORE anything touches the GPU; the other ranks meet rank 0 at
     # the process-group rendezvous below, i.e. after the build.  The library itself is loaded
     # after torch (two HIP runtimes in one process: the first one loaded has to be torch's).
