@@ -70,7 +70,9 @@ BLOCK_ROWS = int(os.environ.get("MI3PT_BENCH_BLOCK_ROWS", "8"))     # rows per b
 BOUNCES = 8
 FRAMES_PER_STEP = 16            # one step = one batch = one launch of the persistent kernel (single GPU)
 L2_PEAK_GBS = 34500.0           # same guide: L2 (8 x 4 MiB), aggregate
-FETCH_FACTOR = 1.0              # bytes per (FETCH_SIZE x 1024) for this kernel's divergent 64-byte gathers: measured, profiles/r05_fetch_calibration.log
+FETCH_FACTOR = 1.0              # REQUESTED bytes per (FETCH_SIZE x 1024) for this kernel's divergent 64-byte gathers: measured, profiles/r05_fetch_calibration.log
+FETCH_FACTOR_UPPER = 2.0        # ... if every such request moved a whole 128-byte line over the fabric (the size class the requests are tallied in): the
+                                # upper bound of the bytes MOVED, and the guide's factor for streaming reads (MI355X_MICROARCH.md, HBM section)
 GATHER64_HBM_GBS = 1640.0       # same log: random 64-byte gathers (4 x 16 B per lane) out of a 4 GiB table, useful bytes
 GATHER64_MALL_GBS = 3500.0      # ... out of a 128 MiB table (resident in the Infinity Cache)
 KERNEL_NEEDLE = "k_raytrace_sm"
@@ -78,7 +80,10 @@ KERNEL_NEEDLE = "k_raytrace_sm"
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
               ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
                "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"),
-              ("TCC_HIT_sum", "TCC_MISS_sum"))
+              ("TCC_HIT_sum", "TCC_MISS_sum"),
+              # the L2's fabric-side read requests by the size class they are tallied in (round-5 advice: FETCH_SIZE x 1 is the REQUESTED
+              # bytes of this kernel's 64-byte gathers; every one of those requests is tallied as a 128-byte one)
+              ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_sum"))
 # a second camera on the headline scene: the model fills the frame (the reference's camera, main.ts:83-92, sees mostly
 # floor and sky around the unit-height model: 1.86 rays per pixel, half of them single sky / floor segments)
 CLOSEUP_CAMERA = {"position": (0.55, 0.62, 1.15), "target": (0.0, 0.5, 0.0)}
@@ -208,8 +213,14 @@ class Job:
         """The uniform blocks of n consecutive frames cut into launches of per_launch: [(raytrace bytes, accumulate bytes, frames)].
         Inputs of the job (the timed region starts with them in hand, like the scene in HBM); advances the frame counter."""
         out, done = [], 0
+        # EQUAL launches (round-5 verdict: the driver's 320 frames used to be a 256- and a 64-frame launch, which run two different
+        # builds of the kernel -- six and five waves per SIMD -- and every per-launch figure averaged the two): the fewest launches
+        # the batch capacity allows, all of the same whole number of steps where the frame count divides that way
+        launches = max(-(-n // max(per_launch, 1)), 1)
+        steps_total = n // FRAMES_PER_STEP
+        even = n % FRAMES_PER_STEP == 0 and steps_total % launches == 0
         while done < n:
-            k = min(per_launch, n - done)
+            k = (n // launches) if even else min(per_launch, n - done)
             out.append((self.rt_uniforms(self.frame), self.acc_uniforms(self.frame), k))
             self.frame += k
             done += k
@@ -366,16 +377,33 @@ def roofline_block(m, pmc, source, num_cus):
     """m: measurements of the timed run (see measure()); pmc: counter means per timed launch.
     Rates are per launch over the launches' exclusive share of the GPU clock (kernel_ms_exclusive = span from the
     first launch's start to the last one's end / launches: consecutive launches overlap at their tails, so the
-    sum of their own durations, kernel_ms, counts the overlap twice)."""
+    sum of their own durations, kernel_ms, counts the overlap twice).  The timed launches are EQUAL (Job.plan) and run one
+    instantiation of the kernel (`launches`), so a per-launch mean is a mean over like things.
+    Three fractions, by three rules, at top level (`frac_by_rule`): the vector-ALU lane-operation fraction (the roof that binds:
+    `frac`), the counter-based HBM-side fraction north_star names (`hbm_counter`: requested bytes; `hbm_counter_upper`: if every
+    request moved a 128-byte line), and SURVEY.md 8(d)'s algorithmic bytes over the HBM peak (above 1 on a scene the caches
+    serve: reported because the rule asks for it, not a roof)."""
     kernel_ms = m["kernel_ms"]
     t_ms = m["kernel_ms_exclusive"] if m["kernel_ms_exclusive"] > 0 else kernel_ms
     t_s = t_ms * 1e-3
     alg_per_launch = algorithmic_bytes(m["counters"]) / max(m["launches"], 1)
     alg_gbps = alg_per_launch / t_s / 1e9 if t_s > 0 else None
-    traffic = None
+    traffic = traffic_upper = None
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         traffic = int((FETCH_FACTOR * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
+        traffic_upper = int((FETCH_FACTOR_UPPER * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
+    # the fabric-side read requests by the size class they are TALLIED in (a separate pass); bytes if each moved its class's size
+    rdreq = None
+    if "TCC_EA0_RDREQ_128B_sum" in pmc:
+        n32, n64, n128 = pmc.get("TCC_EA0_RDREQ_32B_sum", 0.0), pmc.get("TCC_EA0_RDREQ_64B_sum", 0.0), pmc["TCC_EA0_RDREQ_128B_sum"]
+        by_class = 32.0 * n32 + 64.0 * n64 + 128.0 * n128
+        rdreq = {"requests_32B": int(n32), "requests_64B": int(n64), "requests_128B": int(n128), "requests": int(pmc.get("TCC_EA0_RDREQ_sum", n32 + n64 + n128)),
+                 "read_bytes_by_size_class": int(by_class),
+                 "read_GBps_by_size_class": round(by_class / t_s / 1e9, 1) if t_s > 0 else None}
+        if "WRITE_SIZE" in pmc:
+            traffic_upper = int(by_class + pmc["WRITE_SIZE"] * 1024.0)
     hbm = traffic / t_s / 1e9 if traffic is not None and t_s > 0 else None
+    hbm_upper = traffic_upper / t_s / 1e9 if traffic_upper is not None and t_s > 0 else None
     lane_peak = num_cus * 4 * SHADER_CLOCK_HZ / 2.0 * 64.0          # VALU lane-operations per second, all SIMDs
     issue_frac = lane_util = lane_rate = None
     if "SQ_INSTS_VALU" in pmc and t_s > 0:
@@ -383,31 +411,54 @@ def roofline_block(m, pmc, source, num_cus):
         if pmc.get("SQ_ACTIVE_INST_VALU"):
             lane_util = pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
             lane_rate = pmc["SQ_INSTS_VALU"] * 64.0 * lane_util / t_s
+    waves = m.get("waves_per_simd")
     block = {
         # the roof that binds (see real_bound): vector-ALU lane-operations
         "bound": "valu", "achieved": round(lane_rate / 1e12, 3) if lane_rate is not None else None,
         "peak": round(lane_peak / 1e12, 3), "unit": "Tlane-op/s",
         "frac": round(lane_rate / lane_peak, 4) if lane_rate is not None else None,
         "frac_rule": "SQ_INSTS_VALU x 64 x lane_utilisation / kernel time / (CUs x 4 SIMDs x 2.4 GHz / 2 x 64 lanes) = valu_issue_frac x lane_utilisation",
+        "frac_by_rule": {
+            "valu": round(lane_rate / lane_peak, 4) if lane_rate is not None else None,
+            "hbm_counter": round(hbm / HBM_PEAK_GBS, 4) if hbm is not None else None,
+            "hbm_counter_upper": round(hbm_upper / HBM_PEAK_GBS, 4) if hbm_upper is not None else None,
+            "survey_8d_algorithmic": round(alg_gbps / HBM_PEAK_GBS, 3) if alg_gbps is not None else None,
+            "rules": {"valu": "what binds: VALU issue x lane utilisation (frac_rule)",
+                      "hbm_counter": "north_star's: (1 x FETCH_SIZE + WRITE_SIZE) KB per launch / kernel time / 8 TB/s -- REQUESTED bytes of the kernel's "
+                                     "64-byte gathers (calibrated), a lower bound of the bytes moved over the fabric",
+                      "hbm_counter_upper": "the same requests priced at the size class they are tallied in (128 B each): an upper bound of the bytes moved",
+                      "survey_8d_algorithmic": "SURVEY.md 8(d): bytes the walk touches in the reference's layouts / kernel time / 8 TB/s; > 1 where L1 / L2 / "
+                                               "Infinity Cache serve them (a 181 MB scene): not a roof, reported because the rule defines it"}},
         "traffic": traffic, "traffic_source": source,
-        "traffic_rule": f"({FETCH_FACTOR:g} x FETCH_SIZE + WRITE_SIZE) KB per launch, separate rocprofv3 --pmc passes, mean over the timed launches.  "
-                        "FETCH_SIZE = 64 B x L2-to-fabric read requests; calibrated on known byte counts in this kernel's own access shapes "
-                        "(profiles/fetch_calibration.hip, r05_fetch_calibration.log): bytes / FETCH_SIZE = 1.000 for divergent gathers of 64-byte records "
-                        "(this kernel's packets and triangle records), 2.000 only for wide coalesced streaming reads (MI355X_MICROARCH.md's case), which "
-                        "this kernel does not make.  L2 MISSES, whoever serves them: the same gathers out of a table resident in the Infinity Cache "
-                        "count the same -- fabric-side traffic, an upper bound of the HBM traffic (no TCC counter separates the two)",
+        "traffic_if_every_request_moves_its_size_class": traffic_upper,
+        "traffic_rule": f"traffic = ({FETCH_FACTOR:g} x FETCH_SIZE + WRITE_SIZE) KB per launch, separate rocprofv3 --pmc passes, mean over the (equal) timed launches: the "
+                        "bytes this kernel REQUESTS from the fabric.  FETCH_SIZE = 64 B x L2-to-fabric read requests; calibrated on known byte counts in "
+                        "this kernel's own access shapes (profiles/fetch_calibration.hip, r05_fetch_calibration.log): requested bytes / FETCH_SIZE = 1.000 "
+                        "for divergent gathers of 64-byte records (one request per record), 2.000 for wide coalesced streaming reads (MI355X_MICROARCH.md's "
+                        "case), which this kernel does not make.  That is a LOWER bound of the bytes moved: the same log shows every one of those requests "
+                        "tallied as a 128-byte request (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ, 64B ~ 0, 32B = 0: collected live here, `fabric_read_requests`), "
+                        f"and no counter says whether a 128-byte-class request for a 64-byte record moves 64 or 128 bytes -- priced at its class the "
+                        f"traffic is `traffic_if_every_request_moves_its_size_class` (= {FETCH_FACTOR_UPPER:g} x FETCH_SIZE + WRITE_SIZE), the UPPER bound; "
+                        "`hbm.achieved` / `hbm.frac` use the lower, `hbm.upper_*` the upper.  Either way these are L2 MISSES, whoever serves them: the same "
+                        "gathers out of a table resident in the Infinity Cache count the same (no TCC counter separates the two)",
+        "fabric_read_requests": rdreq,
         "hbm": {"achieved": round(hbm, 1) if hbm is not None else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(hbm / HBM_PEAK_GBS, 4) if hbm is not None else None,
+                "upper_achieved": round(hbm_upper, 1) if hbm_upper is not None else None,
+                "upper_frac": round(hbm_upper / HBM_PEAK_GBS, 4) if hbm_upper is not None else None,
                 "peak_achievable": HBM_ACHIEVABLE_GBS,
                 "frac_of_achievable": round(hbm / HBM_ACHIEVABLE_GBS, 4) if hbm is not None else None,
                 # what a kernel that does nothing but this access shape reaches (profiles/r05_fetch_calibration.log): random 64-byte
                 # records, four 16-byte loads per lane, one-wave workgroups -- out of a 4 GiB table (HBM) and out of a 128 MiB one
-                # (Infinity Cache).  The roof of a gather-bound walk; the byte peak above is a streaming kernel's
+                # (Infinity Cache), in REQUESTED bytes like `achieved`.  The roof of a gather-bound walk; the byte peak above is a streaming kernel's
                 "random_64B_gather_roof_GBps": {"from_hbm": GATHER64_HBM_GBS, "from_infinity_cache": GATHER64_MALL_GBS},
                 "frac_of_gather_roof": {"from_hbm": round(hbm / GATHER64_HBM_GBS, 4) if hbm is not None else None,
                                         "from_infinity_cache": round(hbm / GATHER64_MALL_GBS, 4) if hbm is not None else None}},
         "kernel": m["kernel"], "kernel_ms": round(kernel_ms, 4), "kernel_ms_exclusive": round(m["kernel_ms_exclusive"], 4),
         "launches_timed": m["launches"], "frames_per_launch": m["frames_per_launch"],
+        # one block per timed launch: which instantiation it ran (the launches of a job are equal, so: the same one)
+        "launches": [{"frames": m["frames_per_launch"], "instantiation": m["kernel"].split(" (")[0], "waves_per_simd": waves,
+                      "workgroups": m.get("workgroups"), "kernel_ms": round(kernel_ms, 4)} for _ in range(int(m["launches"]))],
         "kernel_ms_all_launches": round(m["kernel_ms_all"], 4), "launches_all": m["launches_all"],
         # what SURVEY.md 8(d) calls the achieved figure: bytes the algorithm touches (in the reference's layouts, from the
         # kernel's own counters) per second.  Served by L1 / L2 / Infinity Cache: not comparable with an HBM peak.
@@ -436,8 +487,9 @@ def roofline_block(m, pmc, source, num_cus):
                                     "issue_stalled": round(pmc.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3)}
         block["pmc_counters"] = {k: round(v, 1) for k, v in sorted(pmc.items())}
         block["real_bound"] = ("vector-ALU lane-operations, reached through per-wave latency: each step is a dependent chain of one LDS and "
-                               "one L2 / fabric round trip (a divergent 128-B packet gather) and a few hundred instructions that a single "
-                               "wave issues at one per 4 cycles, with 5 waves per SIMD (96 VGPRs) to overlap them; frac = VALU issue x lane "
+                               "one L2 / fabric round trip (a divergent 64-B packet gather) and a few hundred instructions that a single "
+                               f"wave issues at one per 4 cycles, with {waves if waves else 'five or six'} waves per SIMD "
+                               f"({ {5: 96, 6: 80}.get(waves, '80 - 96') } VGPRs) to overlap them; frac = VALU issue x lane "
                                "utilisation is the fraction of the machine's lane-op rate in use; HBM-side traffic and L2 requests are "
                                "reported beside it (hbm, l2) and are not what the kernel runs out of on a scene that fits the Infinity Cache")
     return block
@@ -674,20 +726,28 @@ def main():
              # (the warm-up's launches can be shorter: W steps need not be a whole number of launches)
              "kernel_ms_all": (launch_ms_total + warm_ms) / max(launches + warm_launches, 1), "launches_all": int(launches + warm_launches),
              "frames_per_launch": round(launch_frames / max(launches, 1), 2),
-             "variant": ctx.active_variant(),
-             # (template arguments: DEFER, CULL, WIDE, FILT, YMAX, DIAG, TOPLDS, LITE, CW, WMIN, WAVES -- csrc/pt_kernels.hip; what the last launch ran:
-             # mi3pt_debug_last_launch.  WAVES: launches of >= 2.5 M jobs (tiles x frames) run the six-waves-per-SIMD build, shorter ones the
-             # five-wave build -- the driver's 320 timed frames are a 256-frame launch of <..., 32, 6> and a 64-frame launch of <..., 32, 5>,
-             # and `rocprofv3 --stats` lists the two instantiations separately)
-             "kernel": (lambda v: {13: "k_raytrace_sm<true,true,true,true,YMAX,false,false,false,true,WMIN,WAVES>", 12: "k_raytrace_sm<true,true,true,true,true,false>", 11: "k_raytrace_sm<true,true,true,true,false,false>",
-                                   10: "k_raytrace_sm<true,true,true,false,false,false>", 9: "k_raytrace_sm<true,true,false,false,false,false>",
-                                   7: "k_raytrace_sm<true,false,false,false,false,false>", 4: "k_raytrace_sm<false,false,false,false,false,false>"}
-                        .get(v, f"raytrace kernel variant {v}") + " (persistent raytrace kernel: per-lane state machine, deferred-leaf walk"
-                        + (" with exact-image distance culling" if v >= 9 else "") + (" on 4-ary wide packets" if v >= 10 else "")
-                        + (", filtered slab test" if v in (11, 12) else "") + (", one-axis culling condition" if v == 12 else "")
-                        + (": COMPRESSED packets (64 B, boxes on an 8-bit grid rounded outward, conservative test; the exact test on the leaf's own box in the triangle step)" if v == 13 else "")
-                        + "; lean build, six waves per SIMD for launches of >= 2.5 M jobs (80 registers), five below (96); batched frames)")(ctx.last_launch()["variant"] if not use_group else ctx.active_variant()),
-             "lean": (ctx.last_launch()["lean"] if not use_group else None)}
+             "variant": ctx.active_variant()}
+        # which instantiation the timed launches ran (mi3pt_debug_last_launch: the launches of a job are equal -- Job.plan -- so the last
+        # one stands for all): template arguments DEFER, CULL, WIDE, FILT, YMAX, DIAG, TOPLDS, LITE, CW, WMIN, WAVES[, W8] -- csrc/pt_kernels.hip.
+        # WAVES from the grid: a launch that fills the machine runs CUs x 4 SIMDs x WAVES one-wave workgroups
+        last = ctx.last_launch() if not use_group else {"variant": ctx.active_variant(), "lean": None, "workgroups": None}
+        v, wg = last["variant"], last["workgroups"]
+        waves = (wg // (capi_num_cus() * 4)) if wg and wg % (capi_num_cus() * 4) == 0 and wg // (capi_num_cus() * 4) in (4, 5, 6) else None
+        ymax = "YMAX"
+        wmin = 44 if workload == "forest" else 32
+        names = {14: f"k_raytrace_sm<true,true,true,true,{ymax},false,false,false,true,{wmin},{waves or 'WAVES'},true>",
+                 13: f"k_raytrace_sm<true,true,true,true,{ymax},false,false,false,true,{wmin},{waves or 'WAVES'}>",
+                 12: "k_raytrace_sm<true,true,true,true,true,false>", 11: "k_raytrace_sm<true,true,true,true,false,false>",
+                 10: "k_raytrace_sm<true,true,true,false,false,false>", 9: "k_raytrace_sm<true,true,false,false,false,false>",
+                 7: "k_raytrace_sm<true,false,false,false,false,false>", 4: "k_raytrace_sm<false,false,false,false,false,false>"}
+        m["kernel"] = (names.get(v, f"raytrace kernel variant {v}") + " (persistent raytrace kernel: per-lane state machine, deferred-leaf walk"
+                       + (" with exact-image distance culling" if v >= 9 else "") + (" on 4-ary wide packets" if 10 <= v <= 13 else "")
+                       + (", filtered slab test" if v in (11, 12) else "") + (", one-axis culling condition" if v == 12 else "")
+                       + (": COMPRESSED packets (64 B, boxes on an 8-bit grid rounded outward, conservative test; the exact test on the leaf's own box in the triangle step)" if v == 13 else "")
+                       + (" on EIGHT-wide compressed packets (80 B; hit masks in octant order, one 64-bit node entry and one 32-bit leaf entry per step: the experiment of round 6, not the default)" if v == 14 else "")
+                       + f"; lean build, {waves if waves else 'five or six'} waves per SIMD" + (" (80 registers: launches of >= 2.5 M jobs)" if waves == 6 else " (96 registers)" if waves == 5 else "")
+                       + "; YMAX = the one-axis culling condition where the scene's margins allow it; batched frames)")
+        m["lean"], m["waves_per_simd"], m["workgroups"] = last["lean"], waves, wg
         # ---- is the gathered image the right image?  (outside the timed region; round-4 verdict: the N > 1 line gathered and
         # discarded.)  Rank 0 renders the shares of two OTHER ranks again, alone, on its own GPU -- every row, every frame of the
         # job (warm-up included: the accumulation image is the mean since frame 2) -- and compares them bit for bit with what

@@ -277,7 +277,7 @@ int mi3pt_raytrace_launch_span(mi3pt_ctx *ctx, double *span_ms);
 int mi3pt_get_counters(mi3pt_ctx *ctx, uint64_t out[MI3PT_CNT_COUNT]);
 int mi3pt_reset_counters(mi3pt_ctx *ctx);
 
-/* Kernel variant: 0 = auto, 1 = per-pixel kernel walking the uploaded records,
+/* Kernel variant (0 .. 14): 0 = auto, 1 = per-pixel kernel walking the uploaded records,
  * 2 = per-pixel kernel walking node packets, 3 = persistent waves with lane refill,
  * 4 = persistent per-lane state machine (the default), 5 = 4 with a walk threshold of 48,
  * 6 = 4 with the top 32 node packets staged in LDS (measured: no gain),
@@ -305,6 +305,14 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
  * (one axis / three axes, chosen per scene like 12 / 11) x walk threshold (32 lanes; 44 for very large trees) x waves per SIMD (six:
  * 80 registers, for launches of >= 2.5 M jobs; five: 96 registers; MI3PT_OPT_SIX_WAVES).
  * Needs every box of the tree nested in its parent's and finite (any tree of the reference's builder); otherwise 10 runs.
+ * 14 = the EIGHT-wide walk (round 6; measured, NOT the default -- profiles/r06_a_ab_eight_wide.log): 13's conservative test on 80-byte packets
+ * of up to eight children whose slots are chosen by position, so that `slot ^ octant of the ray's direction signs` is a front-to-back
+ * order: a node step leaves two 8-bit hit masks, pushes at most ONE 64-bit node entry (first child packet, hits in visiting order,
+ * internal-slot mask) and ONE 32-bit leaf entry (record base, hit slots) and pops the nearest child by a find-first-bit -- no sort,
+ * no per-child references, a stack of one entry per tree level.  26 % fewer dependent node steps per ray, 47 % more box tests,
+ * 1.4 x the instructions per step: -2 .. -5 % on the 870 k-triangle scene, -25 % on the 10 M-triangle forest.  Same bits (the
+ * grouping of the reference tree's nodes into packets is free: only the leaves' own boxes decide what is tested).  Falls back to 13
+ * where its packets could not be built (a tree more than 30 packet levels deep, more than 2^24 packets or records).
  * Every reference-legal setting (samplesPerFrame 1 .. 2^24, maxBounces 0 .. 65535, F16 storage, pipelining off) runs this
  * kernel; launches beyond those packing limits run the per-pixel kernel (2), frame by frame.
  * auto = 13 when the scene allows the wide walk and its compressed packets could be built -- else 10 (an experiment build: 10,
@@ -418,15 +426,6 @@ int mi3pt_device_build_bvh(mi3pt_ctx *ctx, void *nodes_out, size_t nodes_capacit
  * triangles restores the shipped numbering. */
 int mi3pt_debug_set_packet_layout(mi3pt_ctx *ctx, int layout);
 
-#ifdef MI3PT_EXPERIMENTS       /* the experiment build only (make -C webgpu-pathtracer_amd/csrc experiments): not in libmi3pt.so */
-/* Design experiment, not part of the rendering path: walks `n` given rays (6 floats each) with the
- * deferred-leaf walk ALONE (no shading) as a persistent kernel with 4, 5, 6 or 8 resident waves
- * per SIMD, `passes` times over the list inside one launch (amortises the drain), and reports the
- * best of `repeats` kernel times; out_tuvi (optional) receives (t, u, v, triangle as int bits) per
- * ray = the hit raySceneIntersect would report. */
-int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t n, int waves_per_simd, int repeats, int passes,
-                           float *out_tuvi, float *ms_out);
-#endif
 /* fn: 0 sin, 1 cos, 2 tan, 3 log, 4 exp, 5 atan2(a,b), 6 asin, 7 pow(a,b),
  * 8 fp16 round trip, 9 sqrt, 10 a/b; the kernels' reduced-instruction forms: 11 sqrt, 12 1/a,
  * 13..15 x/y/z of normalize(a, b, a - b), 16 log for a = 0 or a in [2^-32, 1] (rand()'s values: what randNormal

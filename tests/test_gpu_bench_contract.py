@@ -36,8 +36,21 @@ def test_single_gpu_line():
     roof = j["roofline"]
     # the roof that binds: vector-ALU lane-operations (round-2 verdict: not "hbm" for a scene that fits the Infinity Cache)
     assert roof["bound"] == "valu" and roof["unit"] == "Tlane-op/s" and abs(roof["peak"] - 78.643) < 0.01
-    # the 320 timed frames are a 256- and a 64-frame launch
+    # the 320 timed frames are two EQUAL launches of 160 (round-5 verdict: 256 + 64 ran two different builds of the kernel and every
+    # per-launch figure averaged the two): one instantiation, named with its waves per SIMD, one block per launch
     assert roof["kernel_ms"] > 0 and roof["launches_timed"] == 2 and roof["frames_per_launch"] == 160.0
+    assert len(roof["launches"]) == 2 and all(b["frames"] == 160.0 and b["waves_per_simd"] == 6 for b in roof["launches"])
+    assert roof["launches"][0]["instantiation"] == roof["launches"][1]["instantiation"] and ",32,6>" in roof["launches"][0]["instantiation"]
+    assert "6 waves per SIMD" in roof["real_bound"] and "5 waves" not in roof["real_bound"]
+    # three fractions by three rules, at top level: what binds (VALU), north_star's counter-based HBM side (requested bytes, and the
+    # upper bound if every request moved its 128-byte class), SURVEY 8(d)'s algorithmic bytes over the HBM peak (cache-served: > 1)
+    by = roof["frac_by_rule"]
+    assert by["valu"] == roof["frac"] and by["hbm_counter"] == roof["hbm"]["frac"] and set(by["rules"]) == {"valu", "hbm_counter", "hbm_counter_upper", "survey_8d_algorithmic"}
+    assert 0 < by["hbm_counter"] <= by["hbm_counter_upper"] <= 1 and by["survey_8d_algorithmic"] > 1
+    assert abs(by["hbm_counter_upper"] - roof["hbm"]["upper_frac"]) < 1e-9
+    req = roof["fabric_read_requests"]
+    assert req and req["requests_128B"] > 0 and req["requests_32B"] + req["requests_64B"] + req["requests_128B"] <= 1.01 * req["requests"]
+    assert roof["traffic"] < roof["traffic_if_every_request_moves_its_size_class"] <= 2.05 * roof["traffic"]
     # the non-overlapped kernel time per frame cannot exceed the wall clock per frame
     assert roof["kernel_ms_exclusive"] / 10 <= j["ms_per_step"] * 1.02         # (a launch per ten steps, on average)
     assert roof["kernel_ms_exclusive"] <= roof["kernel_ms"] * 1.02

@@ -78,12 +78,12 @@ def test_soups_culled_walk_is_bit_identical(gpu_ctx, env, name):
     for cam in ((0.0, 0.3, 2.5), (0.05, 0.02, 0.1), (3.0, 0.0, 0.0)):         # outside, inside the cloud, from the side
         kw = dict(position=cam, direction=tuple(-np.array(cam) / np.linalg.norm(cam)))
         ref, cref = _render(ctx, sc, w, h, (2, 3), variant=2, **kw)
-        for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
+        for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13, 14)):
             ctx.set_kernel_variant(variant)
             assert ctx.active_variant() == variant
             got, cgot = _render(ctx, sc, w, h, (2, 3), variant=variant, **kw)
-            if variant == 13:
-                assert ctx.last_launch() == dict(ctx.last_launch(), kind=1, variant=13, lean=True)      # the compressed-wide kernel did run
+            if variant in (13, 14):
+                assert ctx.last_launch() == dict(ctx.last_launch(), kind=1, variant=variant, lean=True)      # the compressed-wide / 8-wide kernel did run
             assert pc.same_bits(got, ref), f"{name} camera {cam} variant {variant}: " + pc.describe_diff(got, ref)
             pc.check_counters(cgot, cref, culled=True, what=name)
     ctx.resize(64, 64)
@@ -108,7 +108,7 @@ def test_grazing_views_over_a_tessellated_floor(gpu_ctx, env):
         cam = (0.0, height, 3.9)
         kw = dict(position=cam, direction=(0.0, 0.0, -1.0), fov=60.0)
         ref, cref = _render(ctx, sc, w, h, (2, 3, 4), variant=7, **kw)
-        for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
+        for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13, 14)):
             got, cgot = _render(ctx, sc, w, h, (2, 3, 4), variant=variant, **kw)
             assert pc.same_bits(got, ref), f"camera height {height} variant {variant}: " + pc.describe_diff(got, ref)
             pc.check_counters(cgot, cref, culled=True, what=f"height {height}")
@@ -137,7 +137,7 @@ def test_boxes_that_do_not_bound_their_triangles_are_never_skipped(gpu_ctx, orc,
     ctx.resize(w, h)
     u = pc.rt_uniforms(demo, w, h, frame=2, bounces=6)
     want, ocnt = orc.raytrace(orc.OracleScene(demo.triangles, demo.material_bytes, broken, env), u.tobytes(), w, h)
-    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):              # (10: a node whose box does not hold its children is not absorbed into a wide packet)
+    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13, 14)):              # (10: a node whose box does not hold its children is not absorbed into a wide packet)
         ctx.set_kernel_variant(variant)
         ctx.reset_counters()
         pc.gpu_frame(ctx, u)
@@ -210,7 +210,7 @@ def test_node_stack_beyond_its_lds_part(gpu_ctx, orc, env):
     want, ocnt = orc.raytrace(orc.OracleScene(tris, mats, nodes, env), u.tobytes(), w, h)
     assert ocnt["stack_overflows"] == 0 and 0 < ocnt["hits"] < ocnt["rays"]
     assert ocnt["box_tests"] > 100 * ocnt["rays"]             # every ray enters (almost) every box
-    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
+    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13, 14)):
         ctx.set_kernel_variant(variant)
         assert ctx.active_variant() == variant            # no silent fall-back: this tree admits both walks
         ctx.reset_counters()
@@ -222,6 +222,96 @@ def test_node_stack_beyond_its_lds_part(gpu_ctx, orc, env):
     ctx.resize(64, 64)
 
 
+def _deep_eight_wide_scene(depth):
+    """A hand-made tree whose 8-ary collapse (kernel variant 14) is `depth` + 2 packet levels deep AND whose walk piles up one node
+    entry per level: a spine of `depth` internal nodes; spine node k has a side subtree of eight triangles whose internal boxes are
+    as large as the spine node's own (so the collapse -- largest area first -- opens THEM and leaves the next spine node a child
+    packet) and lie, by their centres, behind the rest of the spine as seen from the camera (so the walk descends the spine first
+    and one internal child of every level stays in its entry).  Every box spans the whole x / y range: every ray enters every box."""
+    z_of = lambda k: -40.0 + k
+    pos = []
+    for k in range(depth + 1):
+        for j in range(8 if k < depth else 2):
+            x0 = -0.9 + 0.22 * j
+            pos.append([[x0, -0.4, z_of(k) + 0.01 * j], [x0 + 0.2, -0.4, z_of(k) + 0.01 * j], [x0 + 0.1, 0.5, z_of(k) + 0.01 * j]])
+    pos = np.array(pos, np.float64)
+    ntri = len(pos)
+    tris = layout.pack_triangles(pos, np.tile(np.array([0.0, 0.0, 1.0]), (ntri, 3, 1)), np.zeros(ntri, int))
+    p32 = pos.astype(np.float32)
+    nodes = np.zeros(2 * ntri - 1, layout.BVH_NODE)
+
+    def put(i, mn, mx, leaf=-1, left=-1, right=-1):
+        nodes[i]["min"], nodes[i]["max"] = mn, mx
+        nodes[i]["isLeaf"], nodes[i]["left"], nodes[i]["right"], nodes[i]["triangleIndex"] = (1 if leaf >= 0 else 0), left, right, leaf
+
+    def put_leaf(i, t):
+        put(i, tuple(p32[t].min(0)), tuple(p32[t].max(0)), leaf=t)
+
+    zhi = z_of(depth) + 0.2
+    idx, t = 0, 0
+    for k in range(depth):
+        spine_box = ((-1.0, -1.0, z_of(k) - 0.1), (1.0, 1.0, zhi))
+        fat = ((-1.0, -1.0, z_of(k) - 0.1), (1.0, 1.0, zhi - 0.01))          # the side subtree's internal boxes: centre a little farther from the camera
+        put(idx, *spine_box, left=idx + 1, right=idx + 16)
+        # side subtree: root idx+1; halves idx+2, idx+9; quarters idx+3, idx+6, idx+10, idx+13; leaves behind each quarter
+        put(idx + 1, *fat, left=idx + 2, right=idx + 9)
+        for h, base in enumerate((idx + 2, idx + 9)):
+            put(base, *fat, left=base + 1, right=base + 4)
+            for q, qb in enumerate((base + 1, base + 4)):
+                put(qb, *fat, left=qb + 1, right=qb + 2)
+                put_leaf(qb + 1, t); put_leaf(qb + 2, t + 1)
+                t += 2
+        idx += 16
+    put(idx, (-1.0, -1.0, z_of(depth) - 0.1), (1.0, 1.0, zhi), left=idx + 1, right=idx + 2)
+    put_leaf(idx + 1, t); put_leaf(idx + 2, t + 1)
+    assert idx + 3 == len(nodes) and t + 2 == ntri
+    mats = layout.pack_materials([dict(color=(0.9, 0.8, 0.7), roughness=1.0, metalness=0.5, specularColor=(1, 1, 1))])
+    return tris, mats, nodes
+
+
+@pytest.mark.parametrize("depth,want_variant", [(6, 14), (24, 14), (40, 13)])
+def test_eight_wide_node_stack_beyond_its_lds_part(gpu_ctx, orc, env, depth, want_variant):
+    """The 8-wide walk (variant 14) keeps 8 .. 11 64-bit node entries per lane in LDS and up to 22 more in the wave's overflow slice;
+    its stack holds one entry per packet level.  On this tree the walk really stacks `depth` entries: 6 stays in LDS, 24 uses the
+    overflow slice in every build, 40 is more levels than the two hold together -- the context must then hand the scene to variant 13.
+    Images and paths equal the oracle's either way."""
+    tris, mats, nodes = _deep_eight_wide_scene(depth)
+    ctx = gpu_ctx
+    ctx.upload_bvh(nodes)
+    ctx.upload_triangles(tris)
+    ctx.upload_materials(mats)
+    ctx.upload_environment(env)
+    ctx.set_tile(0, 1, 8)
+    w, h = 96, 64
+    ctx.resize(w, h)
+
+    class Cam:
+        camera = dict(position=(0.0, 0.0, 5.0), fov=3.0, focalDistance=1.0, aperture=0.0)
+
+        @staticmethod
+        def camera_direction():
+            return (0.0, 0.0, -1.0)
+
+    u = pc.rt_uniforms(Cam, w, h, frame=2, bounces=4)
+    want, ocnt = orc.raytrace(orc.OracleScene(tris, mats, nodes, env), u.tobytes(), w, h)
+    assert ocnt["stack_overflows"] == 0 and 0 < ocnt["hits"] < ocnt["rays"]
+    ctx.set_kernel_variant(14)
+    try:
+        assert ctx.active_variant() == want_variant
+        ctx.reset_counters()
+        pc.gpu_frame(ctx, u)
+        got, cnt = ctx.read_texture(capi.TEX_OUTPUT), ctx.counters()
+        assert ctx.last_launch()["variant"] == want_variant and ctx.last_launch()["lean"]
+        assert pc.same_bits(got, want), pc.describe_diff(got, want)
+        pc.check_counters(cnt, ocnt, culled=True, what=f"variant {want_variant}, depth {depth}")
+        if want_variant == 14:
+            # every ray enters every box of the spine: at least one node step (eight box tests) per level
+            assert cnt["box_tests"] >= 8 * depth * ocnt["rays"] * 0.9
+    finally:
+        ctx.set_kernel_variant(0)
+        ctx.resize(64, 64)
+
+
 def test_demo_scene_1080p_and_the_share_of_boxes_skipped(gpu_ctx, demo, env):
     ctx = gpu_ctx
     pc.upload_scene(ctx, demo, env)
@@ -229,11 +319,12 @@ def test_demo_scene_1080p_and_the_share_of_boxes_skipped(gpu_ctx, demo, env):
     w, h = 1920, 1080
     ctx.resize(w, h)
     ref, cref = _render(ctx, demo, w, h, range(2, 8), variant=7)
-    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
+    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13, 14)):
         got, cgot = _render(ctx, demo, w, h, range(2, 8), variant=variant)
         assert pc.same_bits(got, ref), pc.describe_diff(got, ref)
         pc.check_counters(cgot, cref, culled=True)
-        assert cgot["box_tests"] < cref["box_tests"]           # (this view: both walks test fewer boxes than the reference)
+        if variant != 14:
+            assert cgot["box_tests"] < cref["box_tests"]       # (this view: both walks test fewer boxes than the reference; the 8-wide walk tests eight per step)
     ctx.resize(64, 64)
 
 
@@ -263,9 +354,9 @@ def test_nan_rays_take_the_known_answer(gpu_ctx, orc, demo, env):
     ref, cref = _render(ctx, sc, w, h, frames, 2, bounces=4)
     assert pc.same_bits(ref, acc), pc.describe_diff(ref, acc)
     assert cref["rays"] == orays
-    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
+    for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13, 14)):
         got, cgot = _render(ctx, sc, w, h, frames, variant, bounces=4)
-        assert ctx.active_variant() in (variant, 10, 11, 12, 13)
+        assert ctx.active_variant() in (variant, 10, 11, 12, 13, 14)
         assert pc.same_bits(got, acc), pc.describe_diff(got, acc)
         for k in pc.PATH_COUNTERS:
             assert cgot[k] == cref[k], (variant, k, cgot[k], cref[k])

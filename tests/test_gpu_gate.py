@@ -60,6 +60,36 @@ def test_a_launch_whose_predecessor_never_publishes_is_released_from_the_host(bu
         assert ctx.get_option(capi.OPT_GATE_RELEASES) == 0
 
 
+def test_a_long_healthy_queue_keeps_its_gate(built, demo, env):
+    """The time-out measures how long NOTHING has moved, not how long the host has waited (round-5 advice): a deep queue of
+    launches that each publish their drain mark on time is progress, however long the blocking read at its end waits -- here
+    forty launches behind one read with a time-out far below the job's length.  No release, the gate stays on, same image as an
+    ungated run."""
+    w, h = 640, 360
+    with capi.Context(0) as ctx:
+        pc.upload_scene(ctx, demo, env)
+        ctx.resize(w, h)
+        if not ctx.get_option(capi.OPT_GATE):
+            pytest.skip("no stream memory operations here / a profiler is attached: launches are not gated")
+        ctx.set_option(capi.OPT_BATCH, 32)
+        ctx.resize(w, h)
+        ctx.set_option(capi.OPT_GATE, 0)
+        want = _job(ctx, demo, w, h, 40, 32, bounces=8)
+        ctx.set_option(capi.OPT_GATE, 1)
+        _job(ctx, demo, w, h, 2, 32, bounces=8)             # (warm)
+        t0 = time.perf_counter()
+        _job(ctx, demo, w, h, 4, 32, bounces=8)
+        per_launch_ms = (time.perf_counter() - t0) * 1e3 / 4
+        timeout_ms = max(int(4 * per_launch_ms), 8)          # several launches' worth: a launch publishes long before it
+        ctx.set_option(capi.OPT_GATE_TIMEOUT_MS, timeout_ms)
+        t0 = time.perf_counter()
+        got = _job(ctx, demo, w, h, 40, 32, bounces=8)
+        waited_ms = (time.perf_counter() - t0) * 1e3
+        assert waited_ms > 3 * timeout_ms, (waited_ms, timeout_ms)      # the host did wait for several time-outs' worth
+        assert ctx.get_option(capi.OPT_GATE_RELEASES) == 0 and ctx.get_option(capi.OPT_GATE) == 1, capi.last_error()
+        assert pc.same_bits(got, want), pc.describe_diff(got, want)
+
+
 def test_batches_beyond_the_packing_limits_publish_their_drain_mark(built, demo, env):
     """maxBounces >= 65536 sends a batch to the per-pixel kernels, which never store a drain mark: the host side of the
     stream publishes it after the batch's last frame, so the NEXT batch is not left waiting (round-4 advice: it hung)."""

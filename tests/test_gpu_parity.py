@@ -309,7 +309,7 @@ FRAME_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 13, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])      # 0 = `auto`, 13 = what it ships
+@pytest.mark.parametrize("variant", [0, 13, 14, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])      # 0 = `auto`, 13 = what it ships, 14 = the 8-wide walk
 @pytest.mark.parametrize("case", FRAME_CASES, ids=[f"{c[0]}x{c[1]}-b{c[2]}-s{c[3]}-a{c[4]}" for c in FRAME_CASES])
 def test_raytrace_pass_bit_identical(gpu_ctx, orc, demo, env, case, variant):
     w, h, bounces, spf, aperture, focal, frame, rotation = case
@@ -332,7 +332,7 @@ def test_raytrace_pass_bit_identical(gpu_ctx, orc, demo, env, case, variant):
     ctx.set_kernel_variant(0)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 9, 10, 13])
+@pytest.mark.parametrize("variant", [0, 2, 9, 10, 13, 14])
 def test_pinhole_camera_with_a_negative_zero_coordinate(gpu_ctx, orc, demo, env, variant):
     """aperture == 0 lets the shipped kernels drop the lens sample's arithmetic (its two rand()
     calls stay): cam_pos + (+-0) is cam_pos -- unless a coordinate of cam_pos is -0, where
@@ -473,7 +473,7 @@ def test_random_configurations_shipped_path_equals_per_pixel_kernel(gpu_ctx, dem
         assert ca[k] == cb[k], (what, k)
 
 
-@pytest.mark.parametrize("variant", [0, 4, 7, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", [0, 4, 7, 9, 10, 11, 12, 13, 14])
 def test_every_reference_setting_runs_the_lean_kernel(gpu_ctx, orc, demo, env, variant):
     """samplesPerFrame 1 .. 16 (the reference's slider, main.ts:188), maxBounces 0 .. 10 (main.ts:195), both storage formats,
     queued frames and a launch per frame (pipelining off), the raytrace pass alone: every one of them runs the lean build of
@@ -701,25 +701,6 @@ def test_full_hd_properties(gpu_ctx, orc, demo, env):
     assert part.shape[0] == 16
     assert pc.same_bits(frame_img[480:496], part), pc.describe_diff(frame_img[480:496], part)
     assert pc.max_rel_err(frame_img[480:496], part) <= REL_TOL
-
-
-def test_walk_probe_reports_the_same_hits(gpu_ctx, demo, env):
-    """mi3pt_debug_walk_probe (the walk-only occupancy experiment of profiles/walk_probe.py) must
-    find the hits raySceneIntersect finds, at every occupancy it offers."""
-    ctx = gpu_ctx
-    if not hasattr(ctx.lib, "mi3pt_debug_walk_probe"):
-        pytest.skip("mi3pt_debug_walk_probe: experiment build only")
-    pc.upload_scene(ctx, demo, env)
-    rays = _random_rays(np.random.default_rng(21), 50000)
-    ref = ctx.debug_intersect(rays)
-    for waves in (4, 5, 6, 8):
-        ms, hits = ctx.walk_probe(rays, waves, repeats=1, want_hits=True, passes=2)
-        assert ms > 0
-        hit = hits[:, 3].view(np.int32) >= 0
-        assert np.array_equal(hit, ref[:, 0] == 1)
-        assert pc.same_bits(hits[hit, 0], ref[hit, 1])            # t of the closest hit
-    with pytest.raises(capi.Mi3ptError):
-        ctx.walk_probe(rays, 7)
 
 
 def test_repeated_runs_are_bit_identical(gpu_ctx, demo, env):
@@ -1094,7 +1075,7 @@ def test_tuned_and_diagnostic_twins_render_the_same_bits(gpu_ctx, demo, env, sto
 
     try:
         ref, cref = job(2)                      # per-pixel kernel, the WGSL control flow
-        for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13)):
+        for variant in pc.variants_available(ctx, (9, 10, 11, 12, 13, 14)):
             tuned, ct = job(variant)
             ctx.enable_wave_times(True)
             try:

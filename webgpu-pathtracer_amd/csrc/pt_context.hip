@@ -72,6 +72,10 @@ struct mi3pt_ctx {
     bool wide_ok = false;
     bool cwide_ok = false;          // compressed wide packets + 64-byte triangle records built (kernel variant 13): needs wide_ok, every box nested and finite
     void *d_cwide = nullptr, *d_tripk64 = nullptr;
+    bool cw8_ok = false;            // 8-wide compressed packets + their triangle records built (kernel variant 14): needs cwide_ok
+    void *d_cw8 = nullptr, *d_tripk8 = nullptr;
+    size_t ncw8 = 0, cw8_records = 0;
+    int cw8_height = 0;
     void *d_wide = nullptr;
     size_t nwide = 0;
     int wide_leaf_cap = 0;
@@ -146,6 +150,7 @@ struct mi3pt_ctx {
     uint32_t launch_seq = 0;              // sequence number of the last batched launch
     int gate_timeout_ms = 2000;           // MI3PT_OPT_GATE_TIMEOUT_MS: a blocking entry point that has waited this long releases a held launch from the host (ctx_wait)
     int gate_releases = 0;                // MI3PT_OPT_GATE_RELEASES: how often that happened
+    int gate_stalls_in_a_row = 0;         // ... how many of them since anything last moved by itself (ctx_wait: three switch the gate off)
     bool debug_suppress_drain = false;    // MI3PT_OPT_DEBUG_SUPPRESS_DRAIN (tests): the gate is armed but no kernel publishes its drain mark
     hipStream_t gate_release_stream = nullptr;
     volatile uint32_t *h_drain_flag = nullptr;   // the drain word as the host sees it, where signal memory is host memory (hipPointerGetAttributes at create); else null
@@ -336,11 +341,25 @@ static bool profiler_attached()
 // drain mark) has no bound of its own, and a held launch whose predecessor never publishes -- a tool that serialises kernels in
 // an order other than the one they were enqueued in and that profiler_attached() does not recognise; a kernel that ends without
 // its store -- would block the host for ever (round-3 advice, round-4 verdict weak #5).  While the gate is armed the host polls
-// instead of blocking; after gate_timeout_ms without completion it publishes the newest sequence number itself (a command-processor
-// write on a third stream, no kernel: what mi3pt_destroy has always done).  An early release only lets launches overlap more than
-// intended -- every launch still runs, same bits.  A legitimately long launch (a 4K frame batch of a 10 M-triangle scene takes
-// seconds) gets the same harmless release and keeps its gate; the gate is switched off, with a warning in mi3pt_last_error,
-// once the predecessor is SEEN to have finished without publishing, or after three releases.
+// instead of blocking, and WATCHES: the drain word (host memory) and whether each of the two launch streams is busy.  In a healthy
+// pipelined job the word advances once per launch, however long the host has been waiting -- that is progress, and resets the
+// clock (round-5 advice: the time-out used to measure how long the host had waited, and a deep healthy queue lost its gate after
+// three 2-second waits).  Only when NOTHING has moved for gate_timeout_ms while a launch is held does the host step in: it
+// publishes the mark the front-most held launch waits for -- the word + 1, what the stalled predecessor would have written; never
+// the newest sequence number, which would un-gate every queued launch at once -- with a command-processor write on a third stream
+// (no kernel), or a plain host store where that is unavailable.  An early release only lets two launches overlap more than
+// intended -- every launch still runs, same bits.  The gate is switched off, with a warning in mi3pt_last_error, once a
+// predecessor is SEEN to have finished without publishing, after three stall releases in a row with nothing else moving in between
+// (a tool that serialises: every launch would cost a time-out), or after three releases where the host cannot read the word.
+// Kernels publish with an atomic max (pt_kernels.hip: draw), so a mark the host has stepped past is never taken back.
+static uint32_t gate_front_mark(const mi3pt_ctx *ctx)
+{
+    // launch number k waits for the word to reach k - 1; with the word at w the front-most held launch is w + 2 and waits for w + 1
+    if (!ctx->h_drain_flag) return ctx->launch_seq;          // (the word is not host-visible: assume the worst, release everything)
+    const uint32_t w = *ctx->h_drain_flag;
+    return (int32_t)(w + 1u - ctx->launch_seq) < 0 ? w + 1u : ctx->launch_seq;
+}
+
 static bool gate_launch_held(const mi3pt_ctx *ctx)
 {
     // launch number launch_seq waits for the word to reach launch_seq - 1 (earlier waits were satisfied before it could be enqueued
@@ -348,28 +367,57 @@ static bool gate_launch_held(const mi3pt_ctx *ctx)
     return !ctx->h_drain_flag || (int32_t)(*ctx->h_drain_flag - (ctx->launch_seq - 1u)) < 0;
 }
 
-static void gate_release_from_host(mi3pt_ctx *ctx, const char *why)
+// what the host can see of the queue's progress: the drain word, and which launch streams are busy
+struct GateView { uint32_t word; bool busy[2]; };
+static GateView gate_view(const mi3pt_ctx *ctx)
 {
+    GateView v;
+    v.word = ctx->h_drain_flag ? *ctx->h_drain_flag : 0u;
+    for (int k = 0; k < 2; k++) v.busy[k] = ctx->rt_stream[k] && hipStreamQuery(ctx->rt_stream[k]) == hipErrorNotReady;
+    (void)hipGetLastError();
+    return v;
+}
+
+// returns false when no way of publishing worked (the caller reports an error instead of waiting on)
+static bool gate_release_from_host(mi3pt_ctx *ctx, const GateView &seen, const char *why, uint32_t *published)
+{
+    // (judged before the write) a launch's stream is idle, the other one still busy, and the word is short of what the busy one waits
+    // for: its predecessor finished without publishing -- nobody is left to do it
+    const bool silent = ctx->h_drain_flag && gate_launch_held(ctx) && (seen.busy[0] != seen.busy[1]);
+    const uint32_t mark = gate_front_mark(ctx);
+    bool written = false;
     if (!ctx->gate_release_stream && hipStreamCreateWithFlags(&ctx->gate_release_stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
         ctx->gate_release_stream = nullptr;
-        return;
     }
-    // (read before the write) a launch's stream is idle, the other one still busy, and the word is short of what the busy one waits
-    // for: its predecessor finished without publishing -- nobody is left to do it
-    bool silent = false;
-    if (ctx->h_drain_flag && gate_launch_held(ctx))
-        for (int k = 0; k < 2; k++)
-            if (ctx->rt_stream[k] && hipStreamQuery(ctx->rt_stream[k]) == hipSuccess && hipStreamQuery(ctx->rt_stream[k ^ 1]) == hipErrorNotReady) silent = true;
+    if (ctx->gate_release_stream && hipStreamWriteValue32(ctx->gate_release_stream, ctx->d_drain_flag, mark, 0) == hipSuccess) written = true;
+    else (void)hipGetLastError();
+    if (!written && hipStreamWriteValue32(ctx->stream, ctx->d_drain_flag, mark, 0) == hipSuccess && hipStreamQuery(ctx->stream) != hipErrorNotReady) written = true;
     (void)hipGetLastError();
-    if (hipStreamWriteValue32(ctx->gate_release_stream, ctx->d_drain_flag, ctx->launch_seq, 0) != hipSuccess) (void)hipGetLastError();
+    if (!written && ctx->h_drain_flag) {          // signal memory is host memory: a plain store reaches the command processor's poll
+        __atomic_store_n(const_cast<uint32_t *>(ctx->h_drain_flag), mark, __ATOMIC_RELEASE);
+        written = true;
+    }
+    if (!written) return false;
+    *published = mark;
     ctx->gate_releases++;
-    if (silent || ctx->gate_releases >= 3) {
+    ctx->gate_stalls_in_a_row++;
+    const bool blind = !ctx->h_drain_flag && ctx->gate_releases >= 3;
+    if (silent || ctx->gate_stalls_in_a_row >= 3 || blind) {
         ctx->gate_enabled = false;
+        // (off for good: whatever is still queued behind a wait is released with it)
+        if (mark != ctx->launch_seq) {
+            if (!(ctx->gate_release_stream && hipStreamWriteValue32(ctx->gate_release_stream, ctx->d_drain_flag, ctx->launch_seq, 0) == hipSuccess)) {
+                (void)hipGetLastError();
+                if (ctx->h_drain_flag) __atomic_store_n(const_cast<uint32_t *>(ctx->h_drain_flag), ctx->launch_seq, __ATOMIC_RELEASE);
+            }
+        }
         pt_set_error(MI3PT_OK, std::string("warning: launch gate released from the host after ") + std::to_string(ctx->gate_timeout_ms) +
-                     " ms (" + why + (silent ? "; the predecessor finished without publishing its drain mark" : "; third release") +
+                     " ms without progress (" + why + (silent ? "; the predecessor finished without publishing its drain mark"
+                                                              : (blind ? "; third release, the drain word is not host-visible" : "; third stall in a row")) +
                      "): the gate is off for this context from now on, launches queue behind each other");
     }
+    return true;
 }
 
 static hipError_t ctx_wait(mi3pt_ctx *ctx, hipStream_t s, hipEvent_t ev, const char *why)
@@ -378,15 +426,33 @@ static hipError_t ctx_wait(mi3pt_ctx *ctx, hipStream_t s, hipEvent_t ev, const c
         return ev ? hipEventSynchronize(ev) : hipStreamSynchronize(s);
     using clock = std::chrono::steady_clock;
     const clock::time_point t0 = clock::now();
-    clock::time_point mark = t0;
+    clock::time_point mark = t0;            // the last time anything was seen to move
+    GateView last = gate_view(ctx);
     for (unsigned spins = 0;; spins++) {
         const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
         (void)hipGetLastError();
         const clock::time_point now = clock::now();
-        if (std::chrono::duration_cast<std::chrono::milliseconds>(now - mark).count() >= ctx->gate_timeout_ms) {
-            if (gate_launch_held(ctx)) gate_release_from_host(ctx, why);      // (nothing held: an ordinary long wait)
-            mark = now;
+        // progress is looked for at the polling rate once the wait is long (two stream queries and a host read: microseconds)
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(now - mark).count() >= (ctx->gate_timeout_ms < 8 ? ctx->gate_timeout_ms : ctx->gate_timeout_ms / 8)) {
+            const GateView v = gate_view(ctx);
+            if (v.word != last.word || v.busy[0] != last.busy[0] || v.busy[1] != last.busy[1]) {
+                last = v;
+                mark = now;
+                ctx->gate_stalls_in_a_row = 0;          // something moved by itself
+            } else if (std::chrono::duration_cast<std::chrono::milliseconds>(now - mark).count() >= ctx->gate_timeout_ms) {
+                if (gate_launch_held(ctx)) {            // (nothing held: an ordinary long wait for a long launch)
+                    uint32_t published = v.word;
+                    if (!gate_release_from_host(ctx, v, why, &published)) {
+                        ctx->gate_enabled = false;
+                        pt_set_error(MI3PT_ERR_HIP, std::string("launch gate: a launch is held and no way of publishing its mark from the host works (") + why + ")");
+                        return hipErrorUnknown;
+                    }
+                    last = gate_view(ctx);
+                    last.word = published;              // (our own write, whenever it lands, is not progress)
+                }
+                mark = now;
+            }
         }
         if (!ctx->gate_enabled) return ev ? hipEventSynchronize(ev) : hipStreamSynchronize(s);      // (released for good: nothing is held any more)
         // the first 3 ms poll back to back (an interactive host's frame), then yield the core between looks
@@ -546,7 +612,7 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     if (ctx->gate_release_stream) (void)hipStreamDestroy(ctx->gate_release_stream);
     free_textures(ctx);
-    for (void *p : { ctx->d_cwide, ctx->d_tripk64, ctx->d_wide, ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
+    for (void *p : { ctx->d_cw8, ctx->d_tripk8, ctx->d_cwide, ctx->d_tripk64, ctx->d_wide, ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
                      (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow, (void *)ctx->d_park, (void *)ctx->d_service, ctx->d_fs_taps })
         if (p) (void)hipFree(p);
     for (int p = 0; p < 3; p++)
@@ -610,7 +676,7 @@ extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 {
     PT_GROUP_ALL(ctx, false, mi3pt_set_kernel_variant(m, variant));
     if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
-    if (variant < 0 || variant > 13) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..13");
+    if (variant < 0 || variant > 14) return pt_set_error(MI3PT_ERR_INVALID, "variant must be 0..14");
 #ifndef MI3PT_EXPERIMENTS
     if (variant == 3 || variant == 5 || variant == 6 || variant == 8 || variant == 11 || variant == 12)
         return pt_set_error(MI3PT_ERR_INVALID, "kernel variants 3, 5, 6, 8 (measured, not adopted) and 11, 12 (superseded by 13) exist in the experiment build only: make -C webgpu-pathtracer_amd/csrc experiments");
@@ -665,7 +731,7 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
     case MI3PT_OPT_WAVES_PER_CU: ctx->waves_per_cu = value; break;
     case MI3PT_OPT_CULL: ctx->cull_enabled = value != 0; break;
     case MI3PT_OPT_WIDE: ctx->wide_enabled = value != 0; break;
-    case MI3PT_OPT_GATE: ctx->gate_enabled = value != 0 && ctx->d_drain_flag != nullptr; if (ctx->gate_enabled) ctx->gate_releases = 0; break;
+    case MI3PT_OPT_GATE: ctx->gate_enabled = value != 0 && ctx->d_drain_flag != nullptr; if (ctx->gate_enabled) { ctx->gate_releases = 0; ctx->gate_stalls_in_a_row = 0; } break;
     case MI3PT_OPT_CAMERA_BASE: ctx->cam_base_enabled = value != 0; break;
     case MI3PT_OPT_SIX_WAVES: ctx->six_waves = value < 0 ? -1 : (value != 0 ? 1 : 0); break;
     case MI3PT_OPT_PACKET_ORDER:
@@ -1234,6 +1300,8 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.wide = static_cast<const float4 *>(ctx->d_wide);
     s.cwide = static_cast<const float4 *>(ctx->cwide_ok ? ctx->d_cwide : nullptr);
     s.tripk64 = static_cast<const float4 *>(ctx->cwide_ok ? ctx->d_tripk64 : nullptr);
+    s.cw8 = static_cast<const float4 *>(ctx->cwide_ok && ctx->cw8_ok ? ctx->d_cw8 : nullptr);
+    s.tripk8 = static_cast<const float4 *>(ctx->cwide_ok && ctx->cw8_ok ? ctx->d_tripk8 : nullptr);
     s.wide_leaf_cap = ctx->wide_ok ? ctx->wide_leaf_cap : 0;
     s.wide_root = ctx->wide_root;
     s.cdf = static_cast<const float4 *>(ctx->d_cdf);
@@ -1371,10 +1439,218 @@ static inline uint32_t round_up_16(float f)
     return r > 0x7f80u ? 0x7f80u : r;
 }
 
+// ---- Eight-wide compressed packets + their triangle records (kernel variant 14; pt_kernels.h: CW8Packet).
+// Built from the reference's binary tree (`src`: the uploaded 48-byte records, every internal box containing its children's -- the
+// caller has checked -- and every coordinate finite): a packet stands for a binary node and holds up to eight of its descendants,
+// obtained by opening the internal one with the largest surface area until eight are in hand (the 4-ary collapse, carried on).
+// The children then take SLOTS by where they lie: slot s points towards (s & 1 ? +x : -x, s & 2 ? +y : -y, s & 4 ? +z : -z), and
+// pairs (child, slot) are matched greedily by the projection of the child's centre, relative to the node's, onto the slot's
+// direction -- so that a ray whose direction signs form the octant o meets the slots in descending `s ^ o` roughly front to back.
+// Internal children are numbered consecutively in ascending slot order (breadth-first queue); a node's leaf children get the
+// records base + slot of a record array of their own (slots between its first and last leaf slot are allocated; a slot in
+// between that holds no leaf stays an inert record).  Weights: 8 bits against a per-node power of two, rounded up.
+struct Cw8Build {
+    std::vector<pt::CW8Packet> packets;
+    std::vector<pt::TriPacket64> records;
+    int height = 0;             // levels of packets: the walk's node stack never holds more entries (one per level)
+    double mean_children = 0.0;
+};
+static bool build_cw8(const uint8_t *src, size_t n, const float *verts /* 12 floats per triangle: a, pad, b, pad, c, pad */, size_t nt,
+                      const std::vector<float> &wmax, Cw8Build &out)
+{
+    auto is_leaf = [&](size_t i) { return ldi(src + i * MI3PT_BVHNODE_STRIDE, 28) == 1; };
+    auto box = [&](size_t i, int k) { return ldf(src + i * MI3PT_BVHNODE_STRIDE, (size_t)(k < 3 ? 4 * k : 16 + 4 * (k - 3))); };
+    auto area = [&](size_t i) {
+        const double x = (double)box(i, 3) - box(i, 0), y = (double)box(i, 4) - box(i, 1), z = (double)box(i, 5) - box(i, 2);
+        const double a = x * y + x * z + y * z;
+        return a == a ? a : 0.0;
+    };
+    if (n == 0 || is_leaf(0)) return false;
+    const float inf = __builtin_inff();
+    std::vector<uint32_t> queue, depth;         // binary node a packet stands for; its level
+    std::vector<std::array<int32_t, 8>> kids;   // per packet: binary node per SLOT (-1: empty)
+    std::vector<uint32_t> child_base;
+    queue.push_back(0); depth.push_back(1);
+    int height = 1;
+    size_t total_children = 0;
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        const uint32_t x = queue[qi];
+        const uint8_t *r = src + (size_t)x * MI3PT_BVHNODE_STRIDE;
+        int32_t set[8] = { ldi(r, 32), ldi(r, 36), -1, -1, -1, -1, -1, -1 };
+        if (set[0] < 0 || set[1] < 0 || (size_t)set[0] >= n || (size_t)set[1] >= n) return false;
+        int cnt = 2;
+        while (cnt < 8) {
+            int pick = -1;
+            double best_area = -1.0;
+            for (int k = 0; k < cnt; k++) {
+                if (is_leaf((size_t)set[k])) continue;
+                const double a = area((size_t)set[k]);
+                if (a > best_area) { best_area = a; pick = k; }
+            }
+            if (pick < 0) break;
+            const uint8_t *cr = src + (size_t)set[pick] * MI3PT_BVHNODE_STRIDE;
+            const int32_t cl = ldi(cr, 32), crr = ldi(cr, 36);
+            if (cl < 0 || crr < 0 || (size_t)cl >= n || (size_t)crr >= n) return false;
+            set[pick] = cl;
+            set[cnt++] = crr;
+        }
+        total_children += (size_t)cnt;
+        // slots: greedy matching of (child, slot) by the projection of the child's centre offset on the slot's direction
+        double off[8][3];
+        for (int k = 0; k < cnt; k++)
+            for (int a = 0; a < 3; a++)
+                off[k][a] = 0.5 * ((double)box((size_t)set[k], a) + box((size_t)set[k], 3 + a)) - 0.5 * ((double)box(x, a) + box(x, 3 + a));
+        std::array<int32_t, 8> slots = { -1, -1, -1, -1, -1, -1, -1, -1 };
+        bool child_done[8] = { false, false, false, false, false, false, false, false };
+        for (int round = 0; round < cnt; round++) {
+            int bk = -1, bs = -1;
+            double bscore = -1e300;
+            for (int k = 0; k < cnt; k++) {
+                if (child_done[k]) continue;
+                for (int sl = 0; sl < 8; sl++) {
+                    if (slots[(size_t)sl] >= 0) continue;
+                    const double sc = (sl & 1 ? off[k][0] : -off[k][0]) + (sl & 2 ? off[k][1] : -off[k][1]) + (sl & 4 ? off[k][2] : -off[k][2]);
+                    if (sc > bscore) { bscore = sc; bk = k; bs = sl; }
+                }
+            }
+            if (bk < 0) return false;
+            slots[(size_t)bs] = set[bk];
+            child_done[bk] = true;
+        }
+        kids.push_back(slots);
+        child_base.push_back((uint32_t)queue.size());
+        for (int sl = 0; sl < 8; sl++) {
+            const int32_t c = slots[(size_t)sl];
+            if (c >= 0 && !is_leaf((size_t)c)) {
+                queue.push_back((uint32_t)c);
+                depth.push_back(depth[qi] + 1);
+                if ((int)depth[qi] + 1 > height) height = (int)depth[qi] + 1;
+            }
+        }
+        if (queue.size() >= (1u << 24)) return false;
+    }
+    const size_t np = kids.size();
+    out.packets.assign(np, pt::CW8Packet());
+    std::memset(out.packets.data(), 0, np * sizeof(pt::CW8Packet));
+    std::vector<uint32_t> rec_base(np, 0);
+    size_t next_rec = 8;
+    for (size_t w = 0; w < np; w++) {
+        int first = -1, last = -1;
+        for (int sl = 0; sl < 8; sl++)
+            if (kids[w][(size_t)sl] >= 0 && is_leaf((size_t)kids[w][(size_t)sl])) { if (first < 0) first = sl; last = sl; }
+        if (first >= 0) { rec_base[w] = (uint32_t)(next_rec - (size_t)first); next_rec += (size_t)(last - first + 1); }
+    }
+    if (next_rec + 8 >= (1u << 24)) return false;
+    out.records.assign(next_rec, pt::TriPacket64());
+    for (auto &q : out.records) {      // inert: an empty box, a degenerate triangle
+        for (int k = 0; k < 3; k++) { q.a[k] = q.e1[k] = q.e2[k] = 0.0f; q.bmin[k] = 1.0f; q.bmax[k] = -1.0f; }
+        q.unsafe = 0;
+    }
+    for (size_t w = 0; w < np; w++) {
+        pt::CW8Packet &c = out.packets[w];
+        const auto &ks = kids[w];
+        uint32_t imask = 0, nchild = 0;
+        for (int sl = 0; sl < 8; sl++)
+            if (ks[(size_t)sl] >= 0) { nchild++; if (!is_leaf((size_t)ks[(size_t)sl])) imask |= 1u << sl; }
+        uint32_t meta = imask << 24;
+        for (int ax = 0; ax < 3; ax++) {
+            double lo = 1e300, hi = -1e300, maxabs = 0.0;
+            for (int sl = 0; sl < 8; sl++) {
+                if (ks[(size_t)sl] < 0) continue;
+                const size_t ci = (size_t)ks[(size_t)sl];
+                lo = std::min(lo, (double)box(ci, ax)); hi = std::max(hi, (double)box(ci, 3 + ax));
+                maxabs = std::max({ maxabs, std::fabs((double)box(ci, ax)), std::fabs((double)box(ci, 3 + ax)) });
+            }
+            if (!(lo <= hi)) return false;
+            if (!(maxabs < 1e30)) return false;
+            // (the grid of CWidePacket: the extent in at most 248 cells, no finer than 2^-20 of the largest coordinate)
+            int e = -100;
+            if (hi > lo) e = std::max(e, (int)std::ceil(std::log2((hi - lo) / 248.0)));
+            if (maxabs > 0.0) e = std::max(e, (int)std::floor(std::log2(maxabs)) - 20);
+            double cell = std::ldexp(1.0, e);
+            float o = 0.0f;
+            for (;; e++, cell *= 2.0) {
+                o = (float)(lo - 2.0 * cell);
+                if ((double)o > lo - cell) continue;
+                if (std::ceil((hi - (double)o) / cell) + 1.0 <= 254.0) break;
+            }
+            if (e + 127 < 1 || e + 127 > 254) return false;
+            c.o[ax] = o;
+            meta |= (uint32_t)(e + 127) << (8 * ax);
+            const float cf = (float)cell;
+            for (int sl = 0; sl < 8; sl++) {
+                uint32_t a = 255u, z = 0u;
+                if (ks[(size_t)sl] >= 0) {
+                    const size_t ci = (size_t)ks[(size_t)sl];
+                    const float b0 = box(ci, ax), b1 = box(ci, 3 + ax);
+                    const double x0 = ((double)b0 - (double)o) / cell, x1 = ((double)b1 - (double)o) / cell;
+                    const double f0 = std::floor(x0) - 1.0, f1 = std::ceil(x1) + 1.0;
+                    if (!(f0 >= 0.0 && f1 <= 254.0 && f0 < f1)) return false;
+                    a = (uint32_t)f0; z = (uint32_t)f1;
+                    if (!(std::fma((float)a, cf, o) <= b0 && std::fma((float)z, cf, o) >= b1)) return false;      // (the plain-division path's decode: see CWidePacket's builder)
+                }
+                c.qlo[ax][sl >> 2] |= a << (8 * (sl & 3));
+                c.qhi[ax][sl >> 2] |= z << (8 * (sl & 3));
+            }
+        }
+        c.meta = meta;
+        // culling weights: wq_k * 2^(wexp - 127) >= W_k; a child that must never be skipped (W = +inf) makes the whole node
+        // never skip (wexp 255: the scale is +inf, every product +inf or NaN, neither of which skips)
+        double wm = 0.0;
+        bool never = false;
+        for (int sl = 0; sl < 8; sl++) {
+            if (ks[(size_t)sl] < 0) continue;
+            const float wv = wmax[(size_t)ks[(size_t)sl]];
+            if (!(wv < inf) || wv < 0.0f) never = true; else wm = std::max(wm, (double)wv);
+        }
+        uint32_t wexp = 255;
+        if (!never) {
+            int e = wm > 0.0 ? (int)std::ceil(std::log2(wm / 255.0)) : -63;
+            if (e < -63) e = -63;                  // (no smaller: the kernel's product rc * 2^e must stay far from the denormals)
+            while (std::ceil(wm / std::ldexp(1.0, e)) > 255.0) e++;
+            if (e + 127 > 254) never = true; else wexp = (uint32_t)(e + 127);
+        }
+        if (never) wexp = 255;
+        for (int sl = 0; sl < 8; sl++) {
+            uint32_t q = 0;
+            if (ks[(size_t)sl] >= 0) {
+                if (never) q = 1;
+                else {
+                    const double sc = std::ldexp(1.0, (int)wexp - 127);
+                    q = (uint32_t)std::ceil((double)wmax[(size_t)ks[(size_t)sl]] / sc);
+                    if (q > 255u) return false;
+                    if ((double)q * sc < (double)wmax[(size_t)ks[(size_t)sl]]) return false;
+                }
+            }
+            c.wq[sl >> 2] |= q << (8 * (sl & 3));
+        }
+        c.child = (child_base[w] & 0xffffffu) | (wexp << 24);
+        c.tri = (rec_base[w] & 0xffffffu) | (nchild << 24);
+        for (int sl = 0; sl < 8; sl++) {
+            if (ks[(size_t)sl] < 0 || !is_leaf((size_t)ks[(size_t)sl])) continue;
+            const size_t li = (size_t)ks[(size_t)sl];
+            const uint8_t *lr = src + li * MI3PT_BVHNODE_STRIDE;
+            const int32_t ti = ldi(lr, 40);
+            if (ti < 0 || (size_t)ti >= nt) return false;
+            const float *v = verts + (size_t)ti * 12;
+            pt::TriPacket64 &q = out.records[(size_t)rec_base[w] + (size_t)sl];
+            for (int k = 0; k < 3; k++) {
+                volatile float e1 = v[4 + k] - v[k], e2 = v[8 + k] - v[k];        // one fp32 rounding each (see tri_packet_of)
+                q.a[k] = v[k]; q.e1[k] = e1; q.e2[k] = e2;
+                q.bmin[k] = ldf(lr, 4 * (size_t)k); q.bmax[k] = ldf(lr, 16 + 4 * (size_t)k);
+            }
+            q.unsafe = (node_box_safe(src, li) ? 0u : 0x80000000u) | (uint32_t)ti;
+        }
+    }
+    out.height = height;
+    out.mean_children = np ? (double)total_children / (double)np : 0.0;
+    return true;
+}
+
 static int prepare_cull(mi3pt_ctx *ctx)
 {
     if (!ctx->cull_dirty) return MI3PT_OK;
-    const bool wanted = (ctx->variant >= 9 && ctx->variant <= 13) || (ctx->variant == 0 && ctx->cull_enabled);
+    const bool wanted = (ctx->variant >= 9 && ctx->variant <= 14) || (ctx->variant == 0 && ctx->cull_enabled);
     if (!wanted || ctx->layout_active || !ctx->cull_stack_ok || ctx->env_sampling || ctx->nnodes == 0 || ctx->ntris == 0 || ctx->npackets == 0)
         return MI3PT_OK;       // stays dirty: pick_variant falls back to the reference-counter walk
     if (int rc = flush_pending(ctx)) return rc;
@@ -1671,6 +1947,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
             // with the triangle.  Offered when every internal box contains its children's (the reference then reaches a leaf iff
             // the leaf's box passes) and every coordinate is finite and of ordinary magnitude.
             ctx->cwide_ok = false;
+            ctx->cw8_ok = false;
             {
                 bool ok = true;
                 for (size_t i = 0; i < n && ok; i++) {
@@ -1764,6 +2041,18 @@ static int prepare_cull(mi3pt_ctx *ctx)
                     if (int rc = replace_buffer(ctx, &ctx->d_cwide, cp.data(), cp.size() * sizeof(pt::CWidePacket))) return rc;
                     if (int rc = replace_buffer(ctx, &ctx->d_tripk64, t64.data(), t64.size() * sizeof(pt::TriPacket64))) return rc;
                     ctx->cwide_ok = true;
+                    // ---- the 8-wide packets of kernel variant 14 (same preconditions; its walk's node stack holds one entry per level)
+                    ctx->cw8_ok = false;
+                    Cw8Build b8;
+                    if (ctx->ntris < 0x7fffffffu && build_cw8(src, n, reinterpret_cast<const float *>(tris.data()), nt, wmax, b8) &&
+                        b8.height <= pt::SM_W8_MIN_LDS_NODES + pt::SM_W8_OVERFLOW_NODES) {
+                        if (int rc = replace_buffer(ctx, &ctx->d_cw8, b8.packets.data(), b8.packets.size() * sizeof(pt::CW8Packet))) return rc;
+                        if (int rc = replace_buffer(ctx, &ctx->d_tripk8, b8.records.data(), b8.records.size() * sizeof(pt::TriPacket64))) return rc;
+                        ctx->cw8_ok = true;
+                        ctx->ncw8 = b8.packets.size();
+                        ctx->cw8_height = b8.height;
+                        ctx->cw8_records = b8.records.size();
+                    }
                 }
             }
             ctx->nwide = wp.size();
@@ -1864,7 +2153,8 @@ static int pick_variant(const mi3pt_ctx *ctx)
     // admit it and as the diagnostic twin's walk
     if (ctx->variant == 0)
         return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? (ctx->cwide_ok ? 13 : auto_exact_wide(ctx)) : 9) : (defer_ok ? 7 : 4);
-    if (ctx->variant == 13 && !(wide_ok && ctx->cwide_ok)) return wide_ok ? auto_exact_wide(ctx) : (cull_ok ? 9 : (defer_ok ? 7 : 4));
+    if (ctx->variant == 14 && wide_ok && ctx->cwide_ok && !ctx->cw8_ok) return 13;
+    if ((ctx->variant == 13 || ctx->variant == 14) && !(wide_ok && ctx->cwide_ok)) return wide_ok ? auto_exact_wide(ctx) : (cull_ok ? 9 : (defer_ok ? 7 : 4));
     if (ctx->variant >= 10 && ctx->variant <= 12 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);
     if (ctx->variant == 9 && !cull_ok) return defer_ok ? 7 : 4;
     if ((ctx->variant == 7 || ctx->variant == 8) && !defer_ok) return ctx->variant == 8 ? 6 : 4;
@@ -1921,7 +2211,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     // 44 for trees of a million wide packets and more (deep walks from every camera) on compressed packets, 32 otherwise -- both
     // compile-time constants of their lean builds (as a launch parameter the threshold cost the other scenes 0.8 .. 1.5 %)
     L.walk_min = ctx->variant == 5 ? 48 : (ctx->walk_min > 0 ? ctx->walk_min
-                                           : (ctx->nwide >= (1u << 20) && ctx->wide_ok && ctx->cwide_ok && pick_variant(ctx) == 13 ? PT_DEEP_WALK_MIN : PT_DEFAULT_WALK_MIN));
+                                           : (ctx->nwide >= (1u << 20) && ctx->wide_ok && ctx->cwide_ok && (pick_variant(ctx) == 13 || pick_variant(ctx) == 14) ? PT_DEEP_WALK_MIN : PT_DEFAULT_WALK_MIN));
     L.leaf_min = ctx->leaf_min;
     L.shade_split = ctx->shade_split;
     L.tail_policy = ctx->tail_policy;
@@ -2774,66 +3064,6 @@ extern "C" int mi3pt_device_build_bvh(mi3pt_ctx *ctx, void *nodes_out, size_t no
     return MI3PT_OK;
 }
 
-#ifdef MI3PT_EXPERIMENTS
-extern "C" int mi3pt_debug_walk_probe(mi3pt_ctx *ctx, const float *rays, size_t n, int waves_per_simd, int repeats, int passes,
-                                      float *out_tuvi, float *ms_out)
-{
-    PT_GROUP(ctx, mi3pt_debug_walk_probe(group_member0(ctx), rays, n, waves_per_simd, repeats, passes, out_tuvi, ms_out));
-    if (int rc = require_idle(ctx)) return rc;
-    if (passes < 1) passes = 1;
-    if (!rays || !ms_out || n == 0 || n * (size_t)passes > 0x7fffffffu) return pt_set_error(MI3PT_ERR_INVALID, "bad argument");
-    if (int rc = check_scene(ctx)) return rc;
-    if (waves_per_simd >= 100) {          // the shipped compressed-wide walk: its packets come from the scene analysis
-        if (int rc = prepare_layout(ctx)) return rc;
-        if (int rc = prepare_cull(ctx)) return rc;
-        if (!(ctx->wide_ok && ctx->cwide_ok)) return pt_set_error(MI3PT_ERR_STATE, "the scene does not admit the compressed-wide walk");
-    }
-    const int lcap = ctx->leaf_cap - (pt::SM_LDS_DEPTH - 16);        // the probe keeps 16 stack entries per lane in LDS
-    if (ctx->nnodes == 0 || (lcap < 4 && waves_per_simd < 100)) return pt_set_error(MI3PT_ERR_STATE, "the scene's tree is too deep for the walk probe");
-    float *d_rays = nullptr;
-    float4 *d_out = nullptr;
-    uint32_t *d_counter = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t e = hipMalloc((void **)&d_rays, n * 24);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * 16);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_counter, 16);
-    if (e == hipSuccess) e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * 24, hipMemcpyHostToDevice, ctx->stream);
-    float best_ms = 0.0f;
-    for (int r = 0; e == hipSuccess && r < (repeats > 0 ? repeats : 1); r++) {
-        e = hipMemsetAsync(d_counter, 0, 16, ctx->stream);
-        if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
-        // (the compressed-wide probe takes its refill threshold -- idle lanes that trigger a refill -- where the other one takes lcap: MI3PT_OPT_TOP_PACKETS)
-        if (e == hipSuccess && !pt::launch_walk_probe(scene_refs(ctx), d_rays, (uint32_t)n, (uint32_t)(n * (size_t)passes), d_counter, d_out, waves_per_simd,
-                                                      waves_per_simd >= 100 ? std::max(1, std::min(ctx->top_packets, 64)) : lcap,
-                                                      ctx->leaf_min, ctx->num_cus, ctx->stream)) {
-            pt_set_error(MI3PT_ERR_INVALID, "waves_per_simd must be 4, 5, 6 or 8 (100 + 5 .. 8: the compressed-wide walk)");
-            e = hipErrorInvalidValue;
-        }
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
-        if (e == hipSuccess) e = hipEventSynchronize(e1);
-        float ms = 0.0f;
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-        if (e == hipSuccess && (r == 0 || ms < best_ms)) best_ms = ms;
-    }
-    if (e == hipSuccess && out_tuvi) e = hipMemcpy(out_tuvi, d_out, n * 16, hipMemcpyDeviceToHost);
-    uint32_t stats[4] = { 0, 0, 0, 0 };
-    if (e == hipSuccess) e = hipMemcpy(stats, d_counter, 16, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && waves_per_simd >= 100)       // (a note, not an error: the probe's statistics of its last repeat)
-        pt_set_error(MI3PT_OK, "walk probe: lanes per step " + std::to_string(stats[3] ? (double)stats[2] / stats[3] : 0.0) +
-                               " dropped " + std::to_string(stats[1]));
-    for (void *p : { (void *)d_rays, (void *)d_out, (void *)d_counter })
-        if (p) (void)hipFree(p);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("debug_walk_probe: ") + hipGetErrorString(e));
-    *ms_out = best_ms;
-    return MI3PT_OK;
-}
-#endif      // MI3PT_EXPERIMENTS
-
 extern "C" int mi3pt_debug_math(mi3pt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n)
 {
     PT_GROUP(ctx, mi3pt_debug_math(group_member0(ctx), fn, a, b, out, n));
@@ -3045,6 +3275,8 @@ static int clone_scene(mi3pt_ctx *dst, const mi3pt_ctx *src)
     if (int rc = clone_buffer(dst, &dst->d_wide, src, src->d_wide)) return rc;
     if (int rc = clone_buffer(dst, &dst->d_cwide, src, src->d_cwide)) return rc;
     if (int rc = clone_buffer(dst, &dst->d_tripk64, src, src->d_tripk64)) return rc;
+    if (int rc = clone_buffer(dst, &dst->d_cw8, src, src->d_cw8)) return rc;
+    if (int rc = clone_buffer(dst, &dst->d_tripk8, src, src->d_tripk8)) return rc;
     const size_t env_bytes = (size_t)MI3PT_ENV_WIDTH * MI3PT_ENV_HEIGHT * 16;
     HIP_TRY(hipMemcpyPeerAsync(dst->d_env, dst->device, src->d_env, src->device, env_bytes, dst->stream));
     HIP_TRY(hipMemcpyPeerAsync(dst->d_cdf, dst->device, src->d_cdf, src->device, env_bytes, dst->stream));
@@ -3055,6 +3287,7 @@ static int clone_scene(mi3pt_ctx *dst, const mi3pt_ctx *src)
     dst->leaf_cap = src->leaf_cap; dst->cull_stack_ok = src->cull_stack_ok; dst->tree_proper = src->tree_proper;
     dst->cull_dirty = src->cull_dirty; dst->cull_ok = src->cull_ok; dst->cull_ka = src->cull_ka; dst->cull_kb = src->cull_kb;
     dst->auto_wide_variant = src->auto_wide_variant; dst->wide_ok = src->wide_ok; dst->cwide_ok = src->cwide_ok; dst->nwide = src->nwide;
+    dst->cw8_ok = src->cw8_ok; dst->ncw8 = src->ncw8; dst->cw8_records = src->cw8_records; dst->cw8_height = src->cw8_height;
     dst->wide_leaf_cap = src->wide_leaf_cap; dst->wide_root = src->wide_root;
     dst->layout = src->layout; dst->layout_dirty = src->layout_dirty; dst->layout_active = src->layout_active;
     dst->cost_state = 0;

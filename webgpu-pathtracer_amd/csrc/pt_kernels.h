@@ -30,6 +30,7 @@ constexpr int SM_LDS_DEPTH_SIX_DEEP = 25;       // ... of the six-wave build for
 // Stack entries per lane beyond the LDS part: a wave's slice of the global overflow area (the reference aborts a walk at 64
 // stacked entries, raytrace.wgsl:167-171: PT_MAX_STACK in pt_kernels.hip), sized for the build with the shallowest LDS part
 constexpr int SM_OVERFLOW_ENTRIES = 64 - (SM_LDS_DEPTH_SIX < SM_LDS_DEPTH ? SM_LDS_DEPTH_SIX : SM_LDS_DEPTH);
+// (the 8-wide walk, variant 14, keeps 64-bit node entries -- two dwords each -- in the same column and the same overflow slice: SM_W8_OVERFLOW_NODES below)
 static_assert(SM_LDS_DEPTH_SIX_DEEP >= SM_LDS_DEPTH_SIX && 4 * 6 * SM_LDS_DEPTH_SIX_DEEP * 256 < 160 * 1024, "six-wave deep build: LDS");
 // The culling walks (CULL, WIDE) visit children near first, so their stack occupancy is not the reference order's.
 // They keep a fixed leaf list of SM_CULL_LEAF_CAP entries at the top of the LDS column, node entries in the
@@ -135,6 +136,34 @@ struct TriPacket64 {
 };
 static_assert(sizeof(TriPacket64) == 64, "four 16-B vectors");
 
+// "Eight-wide compressed packet" (kernel variant 14, round 6): up to EIGHT children of a node of the 8-ary collapse, boxes on the
+// node's 8-bit grid rounded outward exactly as in CWidePacket.  What is new is how a walk continues below it: the children sit in
+// SLOTS 0..7 chosen by where they lie in the node (slot bit 0 / 1 / 2 set: towards +x / +y / +z), so that `slot ^ octant` of a
+// ray's direction signs is a front-to-back visiting order without any sort; the internal children are numbered consecutively
+// (breadth-first, ascending slot): child packet = child base + popcount(internal mask below the slot); and the triangle records
+// of the leaf children lie at record base + slot (TriPacket64 records in an array of their own, with the triangle's index).  A node
+// step therefore produces two 8-bit HIT MASKS and pushes at most ONE 64-bit node entry {child base; hits in visiting order, internal
+// mask} and ONE 32-bit leaf entry {record base, leaf hits} -- where the 4-ary walk sorts four (key, reference) pairs and pushes
+// four entries.  80 bytes = five 16-byte loads.  The parity argument is CWidePacket's: above the leaves a test only has to never
+// reject what the reference's exact test passes (every box nested), the leaf's own box is tested exactly in the triangle step,
+// equal-t ties go by leaf rank; the grouping of the reference tree's nodes into packets is free.
+struct CW8Packet {
+    float o[3];              // grid origin (as CWidePacket)
+    uint32_t meta;           // bits 0-7 / 8-15 / 16-23: biased cell exponents per axis; bits 24-31: mask of the slots that hold INTERNAL children
+    uint32_t qlo[3][2];      // per axis: lower cell indices of slots 0-3, 4-7 (one byte each); empty slot: 255
+    uint32_t qhi[3][2];      // ... upper cell indices; empty slot: 0
+    uint32_t wq[2];          // culling weights of slots 0-3, 4-7: W_k <= wq_k * 2^(wexp - 127), rounded up (empty / leafless: 0)
+    uint32_t child;          // bits 0-23: packet index of the first internal child; bits 24-31: wexp (255: never skip below this node)
+    uint32_t tri;            // bits 0-23: record base (slot s -> record base + s); bits 24-27: number of children (the box-test count)
+};
+static_assert(sizeof(CW8Packet) == 80, "five 16-B vectors");
+#ifndef PT_W8_LEAF_CAP_VALUE
+#define PT_W8_LEAF_CAP_VALUE 3
+#endif
+constexpr int SM_W8_LEAF_CAP = PT_W8_LEAF_CAP_VALUE;             // 32-bit leaf entries (each: up to eight parked leaves of one node) at the top of the LDS column
+constexpr int SM_W8_MIN_LDS_NODES = (SM_LDS_DEPTH_SIX - SM_W8_LEAF_CAP) / 2;      // 64-bit node entries in LDS of the build with the shortest column
+constexpr int SM_W8_OVERFLOW_NODES = 22;      // 64-bit node entries per lane in a wave's global overflow slice (2 x 22 <= SM_OVERFLOW_ENTRIES)
+
 // 48-byte triangle record for intersection only: vertex a, the material index, and the two EDGES b - a and c - a as
 // Moller-Trumbore forms them first (raytrace.wgsl:82-83) -- one fp32 subtraction each, rounded to nearest, wherever it is
 // computed: at upload (pt_context.hip: tri_packet_of, the host's float subtraction) instead of per test (six vector
@@ -157,6 +186,8 @@ struct SceneRefs {
     const float4 *tripk;    // TriPacket array, or null
     const float4 *cwide;    // CWidePacket array (kernel variant 13: same numbering as `wide`), or null
     const float4 *tripk64;  // TriPacket64 array (kernel variant 13), or null
+    const float4 *cw8;      // CW8Packet array (kernel variant 14), or null
+    const float4 *tripk8;   // TriPacket64 array of variant 14: record base + slot; `unsafe` = guard flag << 31 | triangle index
     const uint32_t *leaf_rank;  // per triangle: rank of its leaf in the reference's visiting order
     int32_t leaf_cap;       // > 0: leaves may be tested out of order; LDS slots available for deferred leaves
     int32_t wide_leaf_cap;  // > 0: the WIDE walk is offered (wide packets built, stack bound holds)
@@ -290,10 +321,6 @@ void launch_fullscreen(const FsUniforms &fs, const float4 *tex, int tex_w, int t
 void launch_debug_intersect(const SceneRefs &scene, const float *rays, size_t n, float *out, int variant,
                             hipStream_t s);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s);
-#ifdef MI3PT_EXPERIMENTS
-int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, uint32_t total, uint32_t *counter, float4 *out, int waves_per_simd,
-                      int lcap, int leaf_min, int num_cus, hipStream_t s);
-#endif
 int raytrace_grid_blocks(const Tile &tile);
 int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned = false, int waves_per_simd = 0);
 // packs the three position vectors of `ntris` 112-byte triangle records into 48-byte rows (the context's cull analysis)

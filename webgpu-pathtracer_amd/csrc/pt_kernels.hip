@@ -1299,11 +1299,15 @@ PT_DEV T uniform_block(const T &v)
 // WMIN: the lean build's walk_min (a constant there: as a launch parameter in a scalar register it cost the 870 k-triangle scene 0.8 %
 // and the demo scene 1.5 %, profiles/r04_o_walkmin2.log): 32, or 44 for the deep walks of very large trees (compressed packets only).
 // WAVES: resident waves per SIMD of a lean build (5: 96 registers, SM_LDS_DEPTH stack entries in LDS; 6: 80 registers, SM_LDS_DEPTH_SIX).
+// W8 (with CW): the walk on EIGHT-wide compressed packets (variant 14; pt_kernels.h CW8Packet): a node step tests eight boxes and leaves two
+// 8-bit hit masks -- the internal children in the visiting order `slot ^ octant`, the leaves by slot -- pushes at most one 64-bit node entry
+// and one 32-bit leaf entry, and the next step pops the nearest internal child by a find-first-bit: no sort, no per-child references.
 template <bool DEFER, bool CULL, bool WIDE, bool FILT, bool YMAX, bool DIAG, bool TOPLDS = false, bool LITE = false, bool CW = false,
-          int WMIN = PT_DEFAULT_WALK_MIN, int WAVES = SM_TUNED_WAVES_PER_SIMD>
+          int WMIN = PT_DEFAULT_WALK_MIN, int WAVES = SM_TUNED_WAVES_PER_SIMD, bool W8 = false>
 __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_raytrace_sm(const RtLaunch L)
 {
     static_assert(!CULL || DEFER, "the culling walks park their leaves");
+    static_assert(!W8 || (CW && !DIAG && !TOPLDS), "the 8-wide walk runs on compressed packets, lean builds only");
     static_assert((!WIDE || CULL) && (!FILT || WIDE) && (!YMAX || FILT) && (!CW || FILT), "WIDE needs CULL, FILT needs WIDE, YMAX and CW need FILT");
     // DIAG = false (the shipped walks' batched launches when no diagnostic buffer is bound): the per-wave step statistics
     // and stamps are compiled out -- two dozen scalar registers that the walk loop's own scalars were spilled for
@@ -1330,7 +1334,9 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
     constexpr bool PARKG = SIX && WMIN == PT_DEEP_WALK_MIN;
 #endif
     constexpr int DEPTH = PARKG ? SM_LDS_DEPTH_SIX_DEEP : (SIX ? SM_LDS_DEPTH_SIX : PT_SM_LDS_DEPTH);      // LDS stack entries per lane
-    constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
+    constexpr int LCAP = W8 ? SM_W8_LEAF_CAP : SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
+    constexpr int NCAP8 = (DEPTH - SM_W8_LEAF_CAP) / 2;             // 8-wide walk: 64-bit node entries in LDS (two dwords each, from slot 0)
+    static_assert(!W8 || (NCAP8 >= SM_W8_MIN_LDS_NODES && 2 * SM_W8_OVERFLOW_NODES <= SM_OVERFLOW_ENTRIES), "8-wide walk: node entries in LDS + overflow slice");
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
     // deeper entries (rare: the stack holds about one entry per tree level) go to this
     // wave's slice of a global overflow area, so the 64-entry abort semantics are kept
@@ -1467,8 +1473,10 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
             // back (a stream wait on this word) until then, so that launches run back to back with
             // only their tails overlapping instead of queueing for slots behind each other.
             const int drain_mark = max(ntiles - (int)(gridDim.x >> 1), 0);
+            // (an atomic max: the host may have stepped past this mark while releasing a launch that looked stalled -- ctx_wait in
+            // pt_context.hip -- and the word must never go backwards under a later launch's wait)
             if (t <= drain_mark && drain_mark < t + c && S.L.drain_flag)
-                __hip_atomic_store(S.L.drain_flag, S.L.drain_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                (void)__hip_atomic_fetch_max(S.L.drain_flag, S.L.drain_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         have_at = __builtin_amdgcn_readfirstlane(t);
         have = c;
@@ -1513,7 +1521,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
             // conjunction costs two more vector instructions to re-materialise the mask)
             const bool has_node = CULL ? sp > 0 : (trav && sp > 0), has_leaf = CULL ? nl > 0 : (trav && nl > 0);
             const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
-            const bool full = __ballot(CULL ? nl > lcap - (WIDE ? 4 : 2) : (trav && nl > lcap - (WIDE ? 4 : 2))) != 0ull;      // a node step may park two (WIDE: four) more
+            const bool full = __ballot(CULL ? nl > lcap - (W8 ? 1 : (WIDE ? 4 : 2)) : (trav && nl > lcap - (WIDE ? 4 : 2))) != 0ull;      // a node step may park two (WIDE: four; 8-wide: one leaf ENTRY) more
             // (drain: whichever kind of step serves more lanes -- waiting for n_node == 0 would leave the lanes
             // that only have leaves idle for as long as the slowest descent takes)
             if (full || n_node == 0 || n_leaf >= k_leaf_min || (feed_empty && (k_tail_policy & 1) && n_leaf >= n_node)) {
@@ -1527,11 +1535,32 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
                   if (has_leaf) {
                     // compressed-wide walk: a parked leaf is a CANDIDATE (its packet's box was rounded outward); the reference tests the
                     // triangle iff the leaf's own box passes its exact test -- made here, from the 64-byte record that carries that box
-                    nl--;
-                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu;
-                    uint32_t tj = ti;
-                    if (two) { nl--; tj = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu; }
-                    float4 pa = sc.tripk64[(size_t)ti * 4 + 0], pb = sc.tripk64[(size_t)ti * 4 + 1], pc = sc.tripk64[(size_t)ti * 4 + 2], pd = sc.tripk64[(size_t)ti * 4 + 3];
+                    uint32_t ti, tj;
+                    bool two_;
+                    if constexpr (W8) {
+                        // 8-wide walk: the top leaf entry {record base, hit slots in visiting order}: the nearest one or two of them
+                        const int li = DEPTH - nl;
+                        const uint32_t le = stack[li * 64];
+                        uint32_t lh = le & 0xffu;
+                        const uint32_t rb = le >> 8;
+                        const uint32_t oct = (pre.flags >> 4) & 7u;
+                        uint32_t pb = 31u - (uint32_t)__clz((int)lh);          // (hits in visiting order: the highest bit is the nearest slot)
+                        ti = rb + (pb ^ oct);
+                        lh &= ~(1u << pb);
+                        two_ = k_tri_pair && lh != 0u;
+                        tj = ti;
+                        if (two_) { pb = 31u - (uint32_t)__clz((int)lh); tj = rb + (pb ^ oct); lh &= ~(1u << pb); }
+                        stack[li * 64] = (le & 0xffffff00u) | lh;
+                        nl -= lh == 0u ? 1 : 0;
+                    } else {
+                        two_ = two;
+                        nl--;
+                        ti = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu;
+                        tj = ti;
+                        if (two_) { nl--; tj = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu; }
+                    }
+                    const float4 *const TR = W8 ? sc.tripk8 : sc.tripk64;
+                    float4 pa = TR[(size_t)ti * 4 + 0], pb = TR[(size_t)ti * 4 + 1], pc = TR[(size_t)ti * 4 + 2], pd = TR[(size_t)ti * 4 + 3];
                     // (the second triangle's registers are only read under `two`.  Left unset otherwise, and with whole-tuple barriers below,
                     // the step loses ~40 register moves -- 15 to zero-fill them, 15 to copy the loaded values into the filled registers, a dozen
                     // out of the first triangle's load tuples -- where the instantiation has registers for that: the one-axis-culling builds
@@ -1539,35 +1568,38 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
                     // registers with either change and keep the zero fill and the per-dword barriers; forming their culling value inside the
                     // box test to free those twelve registers was tried and costs the forest 11 %: profiles/r04_w_ab_tuple_barriers.log)
                     float4 qa, qb, qc, qd;
-                    if constexpr (!YMAX) { qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f); qb = qa; qc = qa; qd = qa; }
-                    if (two) { qa = sc.tripk64[(size_t)tj * 4 + 0]; qb = sc.tripk64[(size_t)tj * 4 + 1]; qc = sc.tripk64[(size_t)tj * 4 + 2]; qd = sc.tripk64[(size_t)tj * 4 + 3]; }
-                    keep16<YMAX>(pa);
-                    keep16<YMAX>(pb);
-                    keep16<YMAX>(pc);
-                    keep16<YMAX>(pd);
+                    if constexpr (!YMAX || W8) { qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f); qb = qa; qc = qa; qd = qa; }
+                    if (two_) { qa = TR[(size_t)tj * 4 + 0]; qb = TR[(size_t)tj * 4 + 1]; qc = TR[(size_t)tj * 4 + 2]; qd = TR[(size_t)tj * 4 + 3]; }
+                    keep16<YMAX && !W8>(pa);
+                    keep16<YMAX && !W8>(pb);
+                    keep16<YMAX && !W8>(pc);
+                    keep16<YMAX && !W8>(pd);
                     {
                         float t, u, v;
-                        const bool inbox = leaf_box_hit(o, d, pre, __float_as_uint(pd.w) != 0u, F3(pc.y, pc.z, pc.w), F3(pd.x, pd.y, pd.z));
+                        // (8-wide walk: the record's last word = guard flag << 31 | the triangle's index; its own index is a record slot)
+                        const uint32_t oi = W8 ? (__float_as_uint(pd.w) & 0x7fffffffu) : ti;
+                        const bool inbox = leaf_box_hit(o, d, pre, W8 ? (__float_as_uint(pd.w) >> 31) != 0u : __float_as_uint(pd.w) != 0u, F3(pc.y, pc.z, pc.w), F3(pd.x, pd.y, pd.z));
                         const bool hit = ray_triangle_flat_e(o, d, F3(pa.x, pa.y, pa.z), F3(pa.w, pb.x, pb.y), F3(pb.z, pb.w, pc.x), t, u, v) && inbox;
                         cnt.tri += inbox ? 1u : 0u;
                         bool take = hit && t < best.t;
-                        if (hit && t == best.t && best.tri >= 0) take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
+                        if (hit && t == best.t && best.tri >= 0) take = sc.leaf_rank[oi] < sc.leaf_rank[best.tri];
                         best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
-                        best.tri = take ? (int32_t)ti : best.tri;
+                        best.tri = take ? (int32_t)oi : best.tri;
                     }
-                    if (two) {
-                        keep16<YMAX>(qa);
-                        keep16<YMAX>(qb);
-                        keep16<YMAX>(qc);
-                        keep16<YMAX>(qd);
+                    if (two_) {
+                        keep16<YMAX && !W8>(qa);
+                        keep16<YMAX && !W8>(qb);
+                        keep16<YMAX && !W8>(qc);
+                        keep16<YMAX && !W8>(qd);
                         float t, u, v;
-                        const bool inbox = leaf_box_hit(o, d, pre, __float_as_uint(qd.w) != 0u, F3(qc.y, qc.z, qc.w), F3(qd.x, qd.y, qd.z));
+                        const uint32_t oj = W8 ? (__float_as_uint(qd.w) & 0x7fffffffu) : tj;
+                        const bool inbox = leaf_box_hit(o, d, pre, W8 ? (__float_as_uint(qd.w) >> 31) != 0u : __float_as_uint(qd.w) != 0u, F3(qc.y, qc.z, qc.w), F3(qd.x, qd.y, qd.z));
                         const bool hit = ray_triangle_flat_e(o, d, F3(qa.x, qa.y, qa.z), F3(qa.w, qb.x, qb.y), F3(qb.z, qb.w, qc.x), t, u, v) && inbox;
                         cnt.tri += inbox ? 1u : 0u;
                         bool take = hit && t < best.t;
-                        if (hit && t == best.t && best.tri >= 0) take = sc.leaf_rank[tj] < sc.leaf_rank[best.tri];
+                        if (hit && t == best.t && best.tri >= 0) take = sc.leaf_rank[oj] < sc.leaf_rank[best.tri];
                         best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
-                        best.tri = take ? (int32_t)tj : best.tri;
+                        best.tri = take ? (int32_t)oj : best.tri;
                     }
                     if (sp == 0 && nl == 0) mode = M_SHADE;
                   }
@@ -1621,7 +1653,105 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
                 if (wave_times) { st_switch(0); if (feed_empty) { st_tail_node++; st_tail_lanes += (uint32_t)n_node; } }
                 if (count_on) { st_walk_steps++; st_walk_lanes += (uint32_t)n_node; }
                 // (CULL) can any lane's node entries leave the LDS part of its stack in this step?  One pop, then up to two / four pushes.
-                const bool shallow = CULL && __ballot(sp > NCAP - (WIDE ? 3 : 1)) == 0ull;
+                const bool shallow = CULL && __ballot(W8 ? sp >= NCAP8 : sp > NCAP - (WIDE ? 3 : 1)) == 0ull;
+                if constexpr (W8) {
+                  if (has_node) {
+                    // ---- pop: the top entry names the internal children of one packet still to visit {first child packet; hits in visiting
+                    // order (bits 0-7) | internal-slot mask (bits 8-15)}: the nearest is the highest bit, its slot that bit ^ octant, its packet
+                    // the first child + the number of internal slots below it
+                    const int top = sp - 1;
+                    uint32_t e0, e1;
+                    if (shallow) { e0 = stack[(2 * top) * 64]; e1 = stack[(2 * top + 1) * 64]; }
+                    else {
+                        const int tl = top < NCAP8 ? top : 0;
+                        e0 = stack[(2 * tl) * 64]; e1 = stack[(2 * tl + 1) * 64];
+                        asm volatile("" : "+v"(e0), "+v"(e1));          // keep these ds_reads of their own
+                        if (top >= NCAP8) { e0 = ovf[(2 * (top - NCAP8)) * 64]; e1 = ovf[(2 * (top - NCAP8) + 1) * 64]; }
+                    }
+                    const uint32_t oct = (pre.flags >> 4) & 7u;
+                    const uint32_t pbit = 31u - (uint32_t)__clz((int)(e1 & 0xffu));
+                    const uint32_t slot8 = pbit ^ oct;
+                    const uint32_t e1n = e1 & ~(1u << pbit);
+                    const bool more = (e1n & 0xffu) != 0u;
+                    const uint32_t node = e0 + (uint32_t)__popc((e1 >> 8) & ((1u << slot8) - 1u));
+                    if (shallow) stack[(2 * top + 1) * 64] = e1n;            // (when nothing is left the slot is free: written all the same)
+                    else if (more) { if (top < NCAP8) stack[(2 * top + 1) * 64] = e1n; else ovf[(2 * (top - NCAP8) + 1) * 64] = e1n; }
+                    sp = more ? sp : top;
+                    const float4 *P = sc.cw8 + (size_t)node * 5;
+                    float4 c0 = P[0], c1 = P[1], c2 = P[2], c3 = P[3], c4 = P[4];
+                    const uint32_t meta = __float_as_uint(c0.w), cb = __float_as_uint(c4.z), tb = __float_as_uint(c4.w);
+                    const uint32_t imn = meta >> 24;
+                    uint32_t mask = 0u;
+                    const float cx = __uint_as_float((meta & 0xffu) << 23), cy = __uint_as_float(((meta >> 8) & 0xffu) << 23), cz = __uint_as_float(((meta >> 16) & 0xffu) << 23);
+                    if ((pre.flags & 8u) == 0u) {
+                        const float Ax = (c0.x - o.x) * pre.ix, Ay = (c0.y - o.y) * pre.iy, Az = (c0.z - o.z) * pre.iz;
+                        const float Bx = cx * pre.ix, By = cy * pre.iy, Bz = cz * pre.iz;
+                        // near and far plane per axis by the sign of the ray's reciprocal (see the 4-ary compressed walk below): twelve selects
+                        // on the packed index words for the eight children
+                        const bool nx_ = pre.ix < 0.0f, ny_ = pre.iy < 0.0f, nz_ = pre.iz < 0.0f;
+                        const uint32_t lx0 = __float_as_uint(c1.x), lx1 = __float_as_uint(c1.y), ly0 = __float_as_uint(c1.z), ly1 = __float_as_uint(c1.w);
+                        const uint32_t lz0 = __float_as_uint(c2.x), lz1 = __float_as_uint(c2.y), hx0 = __float_as_uint(c2.z), hx1 = __float_as_uint(c2.w);
+                        const uint32_t hy0 = __float_as_uint(c3.x), hy1 = __float_as_uint(c3.y), hz0 = __float_as_uint(c3.z), hz1 = __float_as_uint(c3.w);
+                        const uint32_t ex0 = nx_ ? hx0 : lx0, ex1 = nx_ ? hx1 : lx1, fx0 = nx_ ? lx0 : hx0, fx1 = nx_ ? lx1 : hx1;
+                        const uint32_t ey0 = ny_ ? hy0 : ly0, ey1 = ny_ ? hy1 : ly1, fy0 = ny_ ? ly0 : hy0, fy1 = ny_ ? ly1 : hy1;
+                        const uint32_t ez0 = nz_ ? hz0 : lz0, ez1 = nz_ ? hz1 : lz1, fz0 = nz_ ? lz0 : hz0, fz1 = nz_ ? lz1 : hz1;
+                        // distance bound per child: W_k = wq_k * 2^(wexp - 127), one conversion and one product per child
+                        const uint32_t wq0 = __float_as_uint(c4.x), wq1 = __float_as_uint(c4.y);
+                        const float rcw = fmaf(cull_ka, best.t, cull_kb) * __uint_as_float((cb & 0xff000000u) >> 1);
+                        const float bt = best.t * 1.00000095367431640625f;
+                        const float aix = fabsf(pre.ix), aiy = fabsf(pre.iy), aiz = fabsf(pre.iz);
+                        const float ymax = fmaxf(fmaxf(aix, aiy), aiz);
+#define PT_C8(K)                                                                                                              \
+                        {                                                                                                      \
+                            const uint32_t xe_ = (K) < 4 ? ex0 : ex1, xf_ = (K) < 4 ? fx0 : fx1, ye_ = (K) < 4 ? ey0 : ey1, yf_ = (K) < 4 ? fy0 : fy1; \
+                            const uint32_t ze_ = (K) < 4 ? ez0 : ez1, zf_ = (K) < 4 ? fz0 : fz1, ww_ = (K) < 4 ? wq0 : wq1;   \
+                            const float ax_ = fmaf((float)((xe_ >> (8 * ((K) & 3))) & 0xffu), Bx, Ax), bx_ = fmaf((float)((xf_ >> (8 * ((K) & 3))) & 0xffu), Bx, Ax); \
+                            const float ay_ = fmaf((float)((ye_ >> (8 * ((K) & 3))) & 0xffu), By, Ay), by_ = fmaf((float)((yf_ >> (8 * ((K) & 3))) & 0xffu), By, Ay); \
+                            const float az_ = fmaf((float)((ze_ >> (8 * ((K) & 3))) & 0xffu), Bz, Az), bz_ = fmaf((float)((zf_ >> (8 * ((K) & 3))) & 0xffu), Bz, Az); \
+                            const float key_ = fmaxf(fmaxf(ax_, ay_), az_), f_ = fminf(fminf(bx_, by_), bz_);                 \
+                            const float dk_ = (float)((ww_ >> (8 * ((K) & 3))) & 0xffu) * rcw;                               \
+                            float tc_;                                                                                        \
+                            if constexpr (YMAX) tc_ = fmaf(-dk_, ymax, key_);                                                 \
+                            else tc_ = fmaxf(fmaxf(fmaf(-dk_, aix, ax_), fmaf(-dk_, aiy, ay_)), fmaf(-dk_, aiz, az_));         \
+                            mask |= (cwide_hit(key_, f_) && !(tc_ > bt)) ? (1u << (K)) : 0u;                                   \
+                        }
+                        PT_C8(0) PT_C8(1) PT_C8(2) PT_C8(3) PT_C8(4) PT_C8(5) PT_C8(6) PT_C8(7)
+#undef PT_C8
+                    } else {
+                        // a ray on the plain-division path: the reference's test on the decoded boxes (conservative: see the 4-ary walk below);
+                        // its culling constants are +inf, nothing is skipped.  Rare: a loop, not eight copies of the divisions
+#pragma unroll 1
+                        for (int k = 0; k < 8; k++) {
+                            const uint32_t sh = 8u * (uint32_t)(k & 3);
+                            const bool hi_ = k >= 4;
+                            const uint32_t lxw = __float_as_uint(hi_ ? c1.y : c1.x), lyw = __float_as_uint(hi_ ? c1.w : c1.z), lzw = __float_as_uint(hi_ ? c2.y : c2.x);
+                            const uint32_t hxw = __float_as_uint(hi_ ? c2.w : c2.z), hyw = __float_as_uint(hi_ ? c3.y : c3.x), hzw = __float_as_uint(hi_ ? c3.w : c3.z);
+                            const bool h_ = ray_aabb(o, d, fmaf((float)((lxw >> sh) & 0xffu), cx, c0.x), fmaf((float)((lyw >> sh) & 0xffu), cy, c0.y), fmaf((float)((lzw >> sh) & 0xffu), cz, c0.z),
+                                                     fmaf((float)((hxw >> sh) & 0xffu), cx, c0.x), fmaf((float)((hyw >> sh) & 0xffu), cy, c0.y), fmaf((float)((hzw >> sh) & 0xffu), cz, c0.z));
+                            mask |= h_ ? (1u << k) : 0u;
+                        }
+                    }
+                    cnt.box += (tb >> 24) & 15u;         // the packet's number of children
+                    // the leaves that were hit: ONE entry {record base, hit slots} in the lane's leaf list (nl <= LCAP - 1 before the step: the slot is free)
+                    // both hit masks -- internal children in bits 0-7, leaves in bits 8-15 -- moved from slot order into visiting order
+                    // (bit s -> bit s ^ octant: three conditional swaps, on both bytes at once)
+                    uint32_t hb = (mask & imn) | ((mask & ~imn & 0xffu) << 8);
+                    hb = (oct & 1u) ? (((hb & 0x5555u) << 1) | ((hb >> 1) & 0x5555u)) : hb;
+                    hb = (oct & 2u) ? (((hb & 0x3333u) << 2) | ((hb >> 2) & 0x3333u)) : hb;
+                    hb = (oct & 4u) ? (((hb & 0x0f0fu) << 4) | ((hb >> 4) & 0x0f0fu)) : hb;
+                    const uint32_t lh = hb >> 8, hp = hb & 0xffu;
+                    stack[(DEPTH - 1 - nl) * 64] = (tb << 8) | lh;
+                    nl += lh != 0u ? 1 : 0;
+                    const uint32_t n0 = cb & 0xffffffu, n1 = hp | (imn << 8);
+                    if (shallow) { stack[(2 * sp) * 64] = n0; stack[(2 * sp + 1) * 64] = n1; }
+                    else if (hp != 0u) {
+                        if (sp < NCAP8) { stack[(2 * sp) * 64] = n0; stack[(2 * sp + 1) * 64] = n1; }
+                        else { ovf[(2 * (sp - NCAP8)) * 64] = n0; ovf[(2 * (sp - NCAP8) + 1) * 64] = n1; }
+                    }
+                    sp += hp != 0u ? 1 : 0;
+                    if (sp == 0 && nl == 0) mode = M_SHADE;
+                  }
+                } else
                 if (WIDE) {
                   if (has_node) {
                     if (DIAG) lane_cost += 4u;
@@ -2265,6 +2395,12 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
                     if (!ASSUME && DEFER && (sc.root_ref & PT_REF_LEAF)) {      // one-triangle scene
                         stack[(DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu;
                         sp = 0; nl = 1;
+                    } else if constexpr (W8) {
+                        // the octant of the ray's direction signs (bits 4-6 of the ray's flags: set where the component is not negative), and a
+                        // first entry that stands for the root packet alone: child base 0, one hit, no internal-slot mask (rank 0 whatever the slot)
+                        pre.flags |= (pre.ix < 0.0f ? 0u : 16u) | (pre.iy < 0.0f ? 0u : 32u) | (pre.iz < 0.0f ? 0u : 64u);
+                        stack[0] = 0u; stack[64] = 1u;
+                        sp = 1; nl = 0;
                     } else {
                         st_store(0, WIDE ? sc.wide_root : sc.root_ref);
                         sp = 1; nl = 0;
@@ -2413,13 +2549,14 @@ static RtRoute route_launch(const RtLaunch &L, int variant)
     if (!launch_packs(L)) return r;                      // per-pixel kernel 2, frame by frame
     r.kind = 1;
     r.lean = launch_is_lean(L);
+    if (variant == 14 && !(L.scene.cw8 && L.scene.tripk8 && (L.scene.flags & 2u))) variant = 13;      // (the 8-wide walk never tests the root's own box)
     if (variant == 13 && !(L.scene.cwide && L.scene.tripk64)) variant = 10;
-    if (L.walk_min == PT_DEEP_WALK_MIN && variant != 13) r.lean = false;        // (the deep-walk threshold is instantiated for the compressed-wide walk only)
+    if (L.walk_min == PT_DEEP_WALK_MIN && variant != 13 && variant != 14) r.lean = false;        // (the deep-walk threshold is instantiated for the compressed-wide walk only)
 #ifndef MI3PT_EXPERIMENTS
     if (variant == 11 || variant == 12) variant = 10;       // (release builds: superseded by 13; the exact-packet walk with the exact slab test stands in -- same bits)
 #endif
-    if (variant >= 9 && variant <= 13 && r.lean && !launch_assumptions_hold(L)) variant = L.scene.leaf_cap >= 4 ? 7 : 4;
-    if (variant >= 10 && variant <= 13 && !r.lean) variant = 10;      // the diagnostic twin of the wide walks runs the exact slab test: same bits
+    if (variant >= 9 && variant <= 14 && r.lean && !launch_assumptions_hold(L)) variant = L.scene.leaf_cap >= 4 ? 7 : 4;
+    if (variant >= 10 && variant <= 14 && !r.lean) variant = 10;      // the diagnostic twin of the wide walks runs the exact slab test: same bits
 #ifndef MI3PT_EXPERIMENTS
     if (variant < 9 && !r.lean) {
         // release builds carry diagnostic twins for the culling walks only: the lean build runs (options and the diagnostic buffer
@@ -2451,7 +2588,7 @@ bool raytrace_variant_fuses(int variant)
 static int route_waves_per_simd(const RtLaunch &L, const RtRoute &r)
 {
     if (!(r.kind == 1 && r.lean)) return SM_OTHER_WAVES_PER_SIMD;
-    if (r.variant == 13) {
+    if (r.variant == 13 || r.variant == 14) {
 #ifdef MI3PT_EXPERIMENTS
         if (L.wave_times && L.diag_lite) return SM_TUNED_WAVES_PER_SIMD;      // (the lean build + lane counts: five)
 #endif
@@ -2498,6 +2635,8 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
         //                               DEFER  CULL   WIDE   FILT   YMAX   DIAG
 #ifdef MI3PT_EXPERIMENTS
         if (r.lean && L.wave_times && L.diag_lite && r.variant >= 10) switch (r.variant) {      // the lean build + lane counts
+            case 14: if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, false, true, true, PT_DEFAULT_WALK_MIN, SM_TUNED_WAVES_PER_SIMD, true);
+                     else PT_SM(true, true, true, true, false, false, false, true, true, PT_DEFAULT_WALK_MIN, SM_TUNED_WAVES_PER_SIMD, true); break;
             case 13: if (L.scene.flags & 4u) PT_SM(true, true, true, true, true, false, false, true, true); else PT_SM(true, true, true, true, false, false, false, true, true); break;
             case 12: PT_SM(true,  true,  true,  true,  true,  false, false, true); break;
             case 11: PT_SM(true,  true,  true,  true,  false, false, false, true); break;
@@ -2509,6 +2648,16 @@ void launch_raytrace(const RtLaunch &L, bool fuse, int variant, hipStream_t s)
 #else
 #define PT_TOP_CW true          // (A/B build: the first PT_X_TOP_CW compressed packets staged in LDS per wave)
 #endif
+        if (r.lean && r.variant == 14) {        // eight-wide compressed packets
+            const bool six = route_waves_per_simd(L, r) == SM_SIX_WAVES_PER_SIMD, ymax = (L.scene.flags & 4u) != 0u;
+            if (L.walk_min == PT_DEEP_WALK_MIN) {
+                if (six) { if (ymax) PT_SM(true, true, true, true, true, false, false, false, true, PT_DEEP_WALK_MIN, SM_SIX_WAVES_PER_SIMD, true); else PT_SM(true, true, true, true, false, false, false, false, true, PT_DEEP_WALK_MIN, SM_SIX_WAVES_PER_SIMD, true); }
+                else { if (ymax) PT_SM(true, true, true, true, true, false, false, false, true, PT_DEEP_WALK_MIN, SM_TUNED_WAVES_PER_SIMD, true); else PT_SM(true, true, true, true, false, false, false, false, true, PT_DEEP_WALK_MIN, SM_TUNED_WAVES_PER_SIMD, true); }
+            } else {
+                if (six) { if (ymax) PT_SM(true, true, true, true, true, false, false, false, true, PT_DEFAULT_WALK_MIN, SM_SIX_WAVES_PER_SIMD, true); else PT_SM(true, true, true, true, false, false, false, false, true, PT_DEFAULT_WALK_MIN, SM_SIX_WAVES_PER_SIMD, true); }
+                else { if (ymax) PT_SM(true, true, true, true, true, false, false, false, true, PT_DEFAULT_WALK_MIN, SM_TUNED_WAVES_PER_SIMD, true); else PT_SM(true, true, true, true, false, false, false, false, true, PT_DEFAULT_WALK_MIN, SM_TUNED_WAVES_PER_SIMD, true); }
+            }
+        } else
         if (r.lean && r.variant == 13) {        // compressed wide packets (SceneRefs::flags bit 2: the one-axis culling condition suits this scene)
             const bool six = route_waves_per_simd(L, r) == SM_SIX_WAVES_PER_SIMD, ymax = (L.scene.flags & 4u) != 0u;
             if (L.walk_min == PT_DEEP_WALK_MIN) {
@@ -3055,349 +3204,6 @@ __global__ void __launch_bounds__(256) k_debug_math(int fn, const float *__restr
     }
     out[i] = r;
 }
-
-#ifdef MI3PT_EXPERIMENTS
-// ---------------------------------------------------------------------------------
-// Experiment kernel: the deferred-leaf walk ALONE (no shading, no camera) over a given list of
-// rays, as a persistent kernel at a chosen occupancy.  It answers one design question -- how
-// much would a walk that needs few registers gain from 5..8 resident waves per SIMD -- and is
-// not part of the rendering path (mi3pt_debug_walk_probe).  LDS: DEPTH entries per lane; the
-// caller guarantees that the scene's stack bound fits (leaf_cap is recomputed for DEPTH).
-// ---------------------------------------------------------------------------------
-template <int MINW, int DEPTH>
-__global__ void __launch_bounds__(64, MINW) k_walk_probe(const SceneRefs sc, const float *__restrict__ rays, uint32_t nrays, uint32_t total,
-                                                         uint32_t *__restrict__ counter, float4 *__restrict__ out, int lcap, int leaf_min)
-{
-    __shared__ uint32_t stack_lds[DEPTH * 64];
-    const int lane = threadIdx.x;
-    uint32_t *stack = stack_lds + lane;
-    float4 root0 = sc.nodes[0], root1 = sc.nodes[1];
-    f3 o = F3(0.0f, 0.0f, 0.0f), d = o;
-    RayPre pre;
-    pre.ix = pre.iy = pre.iz = 0.0f; pre.flags = 8u;
-    Best best;
-    best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
-    int sp = 0, nl = 0;
-    uint32_t ray = 0xffffffffu;          // 0xffffffff: idle
-    bool exhausted = false;
-    uint32_t chunk_next = 0u, chunk_left = 0u;
-    for (;;) {
-        // refill: idle lanes take the next rays of this wave's chunk (one atomic per 2048 rays)
-        const unsigned long long idle = __ballot(ray == 0xffffffffu);
-        if (idle != 0ull && !exhausted) {
-            if (chunk_left == 0u) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(counter, 2048u);
-                chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                chunk_left = chunk_next < total ? min(2048u, total - chunk_next) : 0u;
-                if (chunk_left == 0u) exhausted = true;
-            }
-            const uint32_t take = min((uint32_t)__popcll(idle), chunk_left);
-            const uint32_t rank = (uint32_t)lane_rank(idle);
-            if (ray == 0xffffffffu && rank < take) {
-                uint32_t mine = chunk_next + rank;
-                {
-                    mine %= nrays;                 // the list is walked `total / nrays` times (amortises the drain)
-                    ray = mine;
-                    o = F3(rays[(size_t)mine * 6 + 0], rays[(size_t)mine * 6 + 1], rays[(size_t)mine * 6 + 2]);
-                    d = F3(rays[(size_t)mine * 6 + 3], rays[(size_t)mine * 6 + 4], rays[(size_t)mine * 6 + 5]);
-                    best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
-                    pre = ray_prepare(o, d, sc.flags);
-                    sp = nl = 0;
-                    if (ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
-                        if (sc.root_ref & PT_REF_LEAF) { stack[(DEPTH - 1) * 64] = sc.root_ref & 0x7fffffffu; nl = 1; }
-                        else { stack[0] = sc.root_ref; sp = 1; }
-                    }
-                }
-            }
-            chunk_next += take;
-            chunk_left -= take;
-        }
-        // retire finished rays
-        if (ray != 0xffffffffu && sp == 0 && nl == 0) {
-            out[ray] = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
-            ray = 0xffffffffu;
-        }
-        const bool trav = ray != 0xffffffffu;
-        const unsigned long long walking = __ballot(trav);
-        if (walking == 0ull) { if (exhausted) break; else continue; }
-        // a few walk steps between refills
-        for (int it = 0; it < 8; it++) {
-            const bool t2 = ray != 0xffffffffu && (sp > 0 || nl > 0);
-            const bool has_node = t2 && sp > 0, has_leaf = t2 && nl > 0;
-            const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
-            if (n_node == 0 && n_leaf == 0) break;
-            const bool full = __ballot(t2 && nl > lcap - 2) != 0ull;
-            if (full || n_node == 0 || n_leaf >= leaf_min) {
-                if (has_leaf) {
-                    nl--;
-                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64];
-                    const float4 pa = sc.tripk[(size_t)ti * 3 + 0];
-                    const float4 pb = sc.tripk[(size_t)ti * 3 + 1];
-                    const float4 pc = sc.tripk[(size_t)ti * 3 + 2];
-                    float t, u, v;
-                    if (ray_triangle_e(o, d, xyz(pa), xyz(pb), xyz(pc), t, u, v)) {
-                        bool take = t < best.t;
-                        if (t == best.t && best.tri >= 0) take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
-                        if (take) { best.t = t; best.u = u; best.v = v; best.tri = (int32_t)ti; }
-                    }
-                }
-            } else if (has_node) {
-                sp--;
-                const uint32_t ref = stack[sp * 64];
-                const float4 p0 = sc.packets[(size_t)ref * 4 + 0], p1 = sc.packets[(size_t)ref * 4 + 1];
-                const float4 p2 = sc.packets[(size_t)ref * 4 + 2], p3 = sc.packets[(size_t)ref * 4 + 3];
-                const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
-                const uint32_t pf = __float_as_uint(p3.z);
-                bool hl, hr;
-                if (((pre.flags & 8u) | pf) == 0u) {
-                    hl = ray_aabb_fast(o, d, pre, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-                    hr = ray_aabb_fast(o, d, pre, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
-                } else {
-                    hl = ray_aabb_pre(o, d, pre, (pf & 1u) != 0u, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-                    hr = ray_aabb_pre(o, d, pre, (pf & 2u) != 0u, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w);
-                }
-                const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
-                stack[(ll ? DEPTH - 1 - nl : sp) * 64] = ll ? (lref & 0x7fffffffu) : lref;
-                nl += (hl && ll) ? 1 : 0;
-                sp += (hl && !ll) ? 1 : 0;
-                stack[(rl ? DEPTH - 1 - nl : sp) * 64] = rl ? (rref & 0x7fffffffu) : rref;
-                nl += (hr && rl) ? 1 : 0;
-                sp += (hr && !rl) ? 1 : 0;
-            }
-        }
-    }
-}
-
-// The same experiment with the SHIPPED walk (round 5): compressed wide packets, distance culling, deferred leaves with the paired
-// triangle step -- k_raytrace_sm's node and triangle steps transcribed -- over a list of rays with every idle lane refilled at once.
-// What a wave that does NOTHING but walk sustains, at 5 .. 8 waves per SIMD: the walking half of a design whose waves specialise
-// (DESIGN.md 7).  Rays whose node entries would leave the LDS part of the stack lose them (counted in counter[1]): the probe is for
-// timing on trees whose walks fit, and its hits are compared with the reference walk's by the caller.
-template <int MINW, int DEPTH, bool YMAX>
-__global__ void __launch_bounds__(64, MINW) k_walk_probe_cw(const SceneRefs sc, const float *__restrict__ rays, uint32_t nrays, uint32_t total,
-                                                            uint32_t *__restrict__ counter, float4 *__restrict__ out, int leaf_min, int refill_min)
-{
-    constexpr int LCAP = SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;
-    __shared__ uint32_t stack_lds[DEPTH * 64];
-    const int lane = threadIdx.x;
-    uint32_t *stack = stack_lds + lane;
-    f3 o = F3(0.0f, 0.0f, 0.0f), d = o;
-    RayPre pre;
-    pre.ix = pre.iy = pre.iz = 0.0f; pre.flags = 8u;
-    Best best;
-    best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
-    float cull_ka = __builtin_inff(), cull_kb = __builtin_inff();
-    int sp = 0, nl = 0;
-    uint32_t ray = 0xffffffffu, dropped = 0u, lanes_sum = 0u, steps_sum = 0u;
-    uint32_t nray = 0xfffffffeu;          // the ray fetched ahead (0xfffffffe: none yet -- a dummy that is retired without a result)
-    f3 no = F3(0.0f, 0.0f, 0.0f), nd = F3(0.0f, 1.0f, 0.0f);
-    bool exhausted = false;
-    uint32_t chunk_next = 0u, chunk_left = 0u;
-    auto push = [&](uint32_t ref) {
-        const bool lf = (ref & PT_REF_LEAF) != 0u;
-        if (lf || sp < NCAP) stack[(lf ? DEPTH - 1 - nl : sp) * 64] = ref;
-        else dropped++;
-        nl += (lf && ref != PT_REF_NONE) ? 1 : 0;
-        sp += (lf || sp >= NCAP) ? 0 : 1;
-    };
-    auto start_segment = [&]() {
-        best.t = PT_INF; best.u = best.v = 0.0f; best.tri = -1;
-        sp = nl = 0;
-        const bool nan_ray = !(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z) || !(o.x == o.x) || !(o.y == o.y) || !(o.z == o.z);
-        if (!nan_ray && ray != 0xfffffffeu) {
-            pre = ray_prepare(o, d, sc.flags);
-            cull_setup(d, pre, sc.cull_ka, sc.cull_kb, cull_ka, cull_kb);
-            const float4 root0 = sc.nodes[0], root1 = sc.nodes[1];
-            if ((sc.flags & 2u) != 0u || ray_aabb_pre(o, d, pre, (sc.flags & 1u) == 0u, root0.x, root0.y, root0.z, root1.x, root1.y, root1.z)) {
-                stack[0] = sc.wide_root;
-                sp = 1;
-            }
-        }
-    };
-    for (;;) {
-        // retire finished rays, then refill -- once at least refill_min lanes are idle (or nothing is left to walk): every refill is a
-        // memory round trip for the wave (the rays come from a list), as a service step is in the real kernel
-        if (ray != 0xffffffffu && sp == 0 && nl == 0) {
-            if (ray != 0xfffffffeu) out[ray] = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
-            ray = 0xffffffffu;
-        }
-        const unsigned long long idle = __ballot(ray == 0xffffffffu);
-        if ((int)__popcll(idle) >= refill_min || (idle != 0ull && __ballot(ray != 0xffffffffu) == 0ull))
-        if (idle != 0ull && !exhausted) {
-            if (chunk_left == 0u) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(counter, 2048u);
-                chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                chunk_left = chunk_next < total ? min(2048u, total - chunk_next) : 0u;
-                if (chunk_left == 0u) exhausted = true;
-            }
-            const uint32_t take = min((uint32_t)__popcll(idle), chunk_left);
-            const uint32_t rank = (uint32_t)lane_rank(idle);
-            if (ray == 0xffffffffu && rank < take) {
-                // the ray this lane fetched while it walked its last one (nray: one ray ahead; the first refill of a lane walks a
-                // dummy that misses everything): no memory round trip in the refill -- what a refill from an LDS queue filled by a
-                // serving wave would cost -- and the fetch of the ray after it goes out now
-                ray = nray;
-                o = no; d = nd;
-                const uint32_t mine = (chunk_next + rank) % nrays;
-                nray = mine;
-                no = F3(rays[(size_t)mine * 6 + 0], rays[(size_t)mine * 6 + 1], rays[(size_t)mine * 6 + 2]);
-                nd = F3(rays[(size_t)mine * 6 + 3], rays[(size_t)mine * 6 + 4], rays[(size_t)mine * 6 + 5]);
-                start_segment();
-            }
-            chunk_next += take;
-            chunk_left -= take;
-        }
-        if (exhausted && ray == 0xffffffffu && nray != 0xfffffffeu) {      // the list is handed out: the ray fetched ahead is this lane's last
-            ray = nray; nray = 0xfffffffeu;
-            o = no; d = nd;
-            start_segment();
-        }
-        if (__ballot(ray != 0xffffffffu && (sp > 0 || nl > 0)) == 0ull) { if (exhausted && __ballot(ray != 0xffffffffu || nray != 0xfffffffeu) == 0ull) break; else continue; }
-        lanes_sum += (uint32_t)__popcll(__ballot(ray != 0xffffffffu && (sp > 0 || nl > 0)));
-        steps_sum++;
-        {
-            const bool has_node = sp > 0, has_leaf = nl > 0;
-            const int n_node = (int)__popcll(__ballot(has_node)), n_leaf = (int)__popcll(__ballot(has_leaf));
-            const bool full = __ballot(nl > LCAP - 4) != 0ull;
-            if (full || n_node == 0 || n_leaf >= leaf_min) {
-                const bool two = nl > 1;
-                if (has_leaf) {
-                    nl--;
-                    const uint32_t ti = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu;
-                    uint32_t tj = ti;
-                    if (two) { nl--; tj = stack[(DEPTH - 1 - nl) * 64] & 0x7fffffffu; }
-                    float4 pa = sc.tripk64[(size_t)ti * 4 + 0], pb = sc.tripk64[(size_t)ti * 4 + 1], pc = sc.tripk64[(size_t)ti * 4 + 2], pd = sc.tripk64[(size_t)ti * 4 + 3];
-                    float4 qa, qb, qc, qd;
-                    if constexpr (!YMAX) { qa = make_float4(0.0f, 0.0f, 0.0f, 0.0f); qb = qa; qc = qa; qd = qa; }
-                    if (two) { qa = sc.tripk64[(size_t)tj * 4 + 0]; qb = sc.tripk64[(size_t)tj * 4 + 1]; qc = sc.tripk64[(size_t)tj * 4 + 2]; qd = sc.tripk64[(size_t)tj * 4 + 3]; }
-                    keep16<YMAX>(pa); keep16<YMAX>(pb); keep16<YMAX>(pc); keep16<YMAX>(pd);
-                    {
-                        float t, u, v;
-                        const bool inbox = leaf_box_hit(o, d, pre, __float_as_uint(pd.w) != 0u, F3(pc.y, pc.z, pc.w), F3(pd.x, pd.y, pd.z));
-                        const bool hit = ray_triangle_flat_e(o, d, F3(pa.x, pa.y, pa.z), F3(pa.w, pb.x, pb.y), F3(pb.z, pb.w, pc.x), t, u, v) && inbox;
-                        bool take = hit && t < best.t;
-                        if (hit && t == best.t && best.tri >= 0) take = sc.leaf_rank[ti] < sc.leaf_rank[best.tri];
-                        best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
-                        best.tri = take ? (int32_t)ti : best.tri;
-                    }
-                    if (two) {
-                        keep16<YMAX>(qa); keep16<YMAX>(qb); keep16<YMAX>(qc); keep16<YMAX>(qd);
-                        float t, u, v;
-                        const bool inbox = leaf_box_hit(o, d, pre, __float_as_uint(qd.w) != 0u, F3(qc.y, qc.z, qc.w), F3(qd.x, qd.y, qd.z));
-                        const bool hit = ray_triangle_flat_e(o, d, F3(qa.x, qa.y, qa.z), F3(qa.w, qb.x, qb.y), F3(qb.z, qb.w, qc.x), t, u, v) && inbox;
-                        bool take = hit && t < best.t;
-                        if (hit && t == best.t && best.tri >= 0) take = sc.leaf_rank[tj] < sc.leaf_rank[best.tri];
-                        best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
-                        best.tri = take ? (int32_t)tj : best.tri;
-                    }
-                }
-            } else if (has_node) {
-                sp--;
-                const uint32_t ref = stack[sp * 64];
-                uint32_t cr[4];
-                bool hit[4];
-                float key[4];
-                f3 tn[4];
-                if constexpr (YMAX) { key[0] = key[1] = key[2] = key[3] = -PT_INF; }
-                const float4 *P = sc.cwide + (size_t)ref * 4;
-                const float4 c0 = P[0], c1 = P[1], c2 = P[2], c3 = P[3];
-                cr[0] = __float_as_uint(c3.x); cr[1] = __float_as_uint(c3.y); cr[2] = __float_as_uint(c3.z); cr[3] = __float_as_uint(c3.w);
-                const uint32_t meta = __float_as_uint(c0.w);
-                const uint32_t w01 = __float_as_uint(c2.z), w23 = __float_as_uint(c2.w);
-                const uint32_t lx = __float_as_uint(c1.x), ly = __float_as_uint(c1.y), lz = __float_as_uint(c1.z);
-                const uint32_t hx = __float_as_uint(c1.w), hy = __float_as_uint(c2.x), hz = __float_as_uint(c2.y);
-                const float cx = __uint_as_float((meta & 0xffu) << 23), cy = __uint_as_float(((meta >> 8) & 0xffu) << 23), cz = __uint_as_float(((meta >> 16) & 0xffu) << 23);
-                if ((pre.flags & 8u) == 0u) {
-                    const float Ax = (c0.x - o.x) * pre.ix, Ay = (c0.y - o.y) * pre.iy, Az = (c0.z - o.z) * pre.iz;
-                    const float Bx = cx * pre.ix, By = cy * pre.iy, Bz = cz * pre.iz;
-                    const bool nx_ = pre.ix < 0.0f, ny_ = pre.iy < 0.0f, nz_ = pre.iz < 0.0f;
-                    const uint32_t ex = nx_ ? hx : lx, fx = nx_ ? lx : hx, ey = ny_ ? hy : ly, fy = ny_ ? ly : hy, ez = nz_ ? hz : lz, fz = nz_ ? lz : hz;
-#define PT_CBOX(K)                                                                                                          \
-                    {                                                                                                      \
-                        const float ax_ = fmaf((float)((ex >> (8 * K)) & 0xffu), Bx, Ax), bx_ = fmaf((float)((fx >> (8 * K)) & 0xffu), Bx, Ax); \
-                        const float ay_ = fmaf((float)((ey >> (8 * K)) & 0xffu), By, Ay), by_ = fmaf((float)((fy >> (8 * K)) & 0xffu), By, Ay); \
-                        const float az_ = fmaf((float)((ez >> (8 * K)) & 0xffu), Bz, Az), bz_ = fmaf((float)((fz >> (8 * K)) & 0xffu), Bz, Az); \
-                        const f3 a_ = F3(ax_, ay_, az_);                                                                   \
-                        const float f_ = fminf(fminf(bx_, by_), bz_);                                                      \
-                        key[K] = fmaxf(fmaxf(a_.x, a_.y), a_.z);                                                           \
-                        if constexpr (!YMAX) tn[K] = a_;                                                                   \
-                        hit[K] = cwide_hit(key[K], f_);                                                                    \
-                    }
-                    PT_CBOX(0) PT_CBOX(1) PT_CBOX(2) PT_CBOX(3)
-#undef PT_CBOX
-                } else {
-                    if constexpr (!YMAX) {
-                        key[0] = key[1] = key[2] = key[3] = -PT_INF;
-                        tn[0] = tn[1] = tn[2] = tn[3] = F3(-PT_INF, -PT_INF, -PT_INF);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        hit[k] = ray_aabb(o, d, fmaf((float)((lx >> (8 * k)) & 0xffu), cx, c0.x), fmaf((float)((ly >> (8 * k)) & 0xffu), cy, c0.y), fmaf((float)((lz >> (8 * k)) & 0xffu), cz, c0.z),
-                                          fmaf((float)((hx >> (8 * k)) & 0xffu), cx, c0.x), fmaf((float)((hy >> (8 * k)) & 0xffu), cy, c0.y), fmaf((float)((hz >> (8 * k)) & 0xffu), cz, c0.z));
-                }
-                const float rc = fmaf(cull_ka, best.t, cull_kb);
-                const float bt = best.t * 1.00000095367431640625f;
-                const float wgt[4] = { __uint_as_float(w01 & 0xffff0000u), __uint_as_float(w01 << 16), __uint_as_float(w23 & 0xffff0000u), __uint_as_float(w23 << 16) };
-                const float ymax = fmaxf(fmaxf(fabsf(pre.ix), fabsf(pre.iy)), fabsf(pre.iz));
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float dk = wgt[k] * rc;
-                    float tc;
-                    if constexpr (YMAX) tc = fmaf(-dk, ymax, key[k]);
-                    else tc = fmaxf(fmaxf(fmaf(-dk, fabsf(pre.ix), tn[k].x), fmaf(-dk, fabsf(pre.iy), tn[k].y)), fmaf(-dk, fabsf(pre.iz), tn[k].z));
-                    cr[k] = (hit[k] && !(tc > bt)) ? cr[k] : PT_REF_NONE;
-                }
-#define PT_CSWAP(A, B)                                                                         \
-                {                                                                              \
-                    const bool sw = key[A] < key[B];                                           \
-                    const float ka_ = sw ? key[B] : key[A], kb_ = sw ? key[A] : key[B];        \
-                    const uint32_t ra_ = sw ? cr[B] : cr[A], rb_ = sw ? cr[A] : cr[B];         \
-                    key[A] = ka_; key[B] = kb_; cr[A] = ra_; cr[B] = rb_;                      \
-                }
-                PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
-#undef PT_CSWAP
-#pragma unroll
-                for (int k = 0; k < 4; k++) push(cr[k]);
-            }
-        }
-    }
-    if (dropped) atomicAdd(counter + 1, dropped);
-    if (lane == 0) { atomicAdd(counter + 2, lanes_sum >> 6); atomicAdd(counter + 3, steps_sum >> 6); }      // (in units of 64: mean walking lanes per step = 64 x c[2] / c[3]... both scaled alike)
-}
-
-// returns 0 when the occupancy is not instantiated
-int launch_walk_probe(const SceneRefs &sc, const float *rays, uint32_t nrays, uint32_t total, uint32_t *counter, float4 *out, int waves_per_simd,
-                      int lcap, int leaf_min, int num_cus, hipStream_t s)
-{
-    const dim3 block(64);
-    if (waves_per_simd >= 100) {          // 100 + w: the shipped compressed-wide walk at w waves per SIMD (k_walk_probe_cw)
-        const int w = waves_per_simd - 100;
-        if (!sc.cwide || !sc.tripk64) return 0;
-        const dim3 g((num_cus > 0 ? num_cus : 256) * 4 * w);
-        const bool ymax = (sc.flags & 4u) != 0u;
-#define PT_WP(W, D) do { if (ymax) hipLaunchKernelGGL((k_walk_probe_cw<W, D, true>), g, block, 0, s, sc, rays, nrays, total, counter, out, leaf_min, lcap); \
-                         else hipLaunchKernelGGL((k_walk_probe_cw<W, D, false>), g, block, 0, s, sc, rays, nrays, total, counter, out, leaf_min, lcap); return 1; } while (0)
-        switch (w) {      // LDS per wave = DEPTH x 256 B, in 1 280-byte granules: 20 / 24 / 28 / 32 waves per CU
-        case 5: PT_WP(5, 30);
-        case 6: PT_WP(6, 25);
-        case 7: PT_WP(7, 20);
-        case 8: PT_WP(8, 20);
-        default: return 0;
-        }
-#undef PT_WP
-    }
-    const dim3 grid((num_cus > 0 ? num_cus : 256) * 4 * waves_per_simd);
-    switch (waves_per_simd) {
-    case 4: hipLaunchKernelGGL((k_walk_probe<4, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
-    case 5: hipLaunchKernelGGL((k_walk_probe<5, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
-    case 6: hipLaunchKernelGGL((k_walk_probe<6, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
-    case 8: hipLaunchKernelGGL((k_walk_probe<8, 16>), grid, block, 0, s, sc, rays, nrays, total, counter, out, lcap, leaf_min); return 1;
-    default: return 0;
-    }
-}
-#endif      // MI3PT_EXPERIMENTS (walk probe)
 
 __global__ void __launch_bounds__(256) k_patch_cull(float4 *__restrict__ packets, const uint32_t *__restrict__ cull, uint32_t n)
 {

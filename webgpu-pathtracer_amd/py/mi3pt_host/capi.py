@@ -115,8 +115,6 @@ def load_library(path=None):
     lib.mi3pt_debug_intersect.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.mi3pt_debug_math.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t]
     lib.mi3pt_device_build_bvh.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
-    if hasattr(lib, "mi3pt_debug_walk_probe"):        # (the experiment build only)
-        lib.mi3pt_debug_walk_probe.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.mi3pt_debug_wave_times.argtypes = [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]
     lib.mi3pt_host_build_bvh.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
     lib.mi3pt_host_build_bvh_f64.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
@@ -454,17 +452,6 @@ class Context:
         nodes = np.zeros(2 * ntris - 1, layout.BVH_NODE)
         self._c(self.lib.mi3pt_device_build_bvh(self.handle, _ptr(nodes), nodes.nbytes, ctypes.byref(n), ctypes.byref(ms)))
         return nodes[: n.value], ms.value
-
-    def walk_probe(self, rays, waves_per_simd, repeats=3, want_hits=False, passes=1):
-        """Walk-only occupancy experiment (mi3pt_debug_walk_probe; the experiment build of the library only): returns (ms, hits or None)."""
-        if not hasattr(self.lib, "mi3pt_debug_walk_probe"):
-            raise Mi3ptError(2, "mi3pt_debug_walk_probe exists in the experiment build only: make -C webgpu-pathtracer_amd/csrc experiments")
-        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
-        out = np.zeros((len(r), 4), np.float32) if want_hits else None
-        ms = ctypes.c_float()
-        self._c(self.lib.mi3pt_debug_walk_probe(self.handle, _ptr(r), len(r), int(waves_per_simd), int(repeats), int(passes),
-                                                _ptr(out) if out is not None else None, ctypes.byref(ms)))
-        return ms.value, out
 
     def debug_math(self, fn, a, b=None):
         a = np.ascontiguousarray(a, np.float32)
