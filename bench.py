@@ -556,6 +556,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (children of this process)")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (demo scene, close-up camera)")
+    ap.add_argument("--no-gather-check", action="store_true", help="N > 1: skip the re-rendering of two ranks' shares on rank 0 after the timed region (it renders "
+                                                                    "every frame of the job twice more, outside the timed region)")
     ap.add_argument("--no-forest", action="store_true", help="skip the forest leg (config 5's scene: ~1 min of scene build, render and counter passes)")
     ap.add_argument("--image", default=None, help="WxH override (experiments only)")
     ap.add_argument("--tile", default=None, help="R/N: render only rank R's share of an N-way tile split on this one GPU, no gather "
@@ -606,7 +608,19 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MI3PT_BENCH_RCCL_SELFTEST=1 (one rank): the N > 1 code path on the REAL backend -- process group over RCCL, the gather of device
+    # tensors on the context's stream, the reductions -- with a world of one (what a one-GPU box can run of it: two ranks on one GPU
+    # are refused by RCCL, which is why the N = 2 rehearsal goes over gloo)
+    selftest = world == 1 and not group_devices and os.environ.get("MI3PT_BENCH_RCCL_SELFTEST") == "1"
+    use_dist = world > 1 or selftest
+    if selftest:
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            free_port = sk.getsockname()[1]
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", str(free_port))):
+            os.environ.setdefault(k, v)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -624,7 +638,7 @@ def main():
     red_dev = "cpu" if rehearsal else "cuda"
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -650,7 +664,7 @@ def main():
         send = gathered = None
         gathered_host = []                 # (rehearsal: the gloo gather's host tensors on rank 0)
         ev_g0, ev_g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if world > 1 and gather:
+        if use_dist and gather:
             send = torch.zeros((max_rows, width, 4), dtype=torch.float32, device="cuda")
             if rank == 0:
                 gathered = [torch.empty_like(send) for _ in range(world)]
@@ -708,7 +722,7 @@ def main():
         mine = torch.tensor([elapsed * 1e3, submit_ms, span_ms, gather_ms if gather_ms is not None else -1.0, float(ctx.local_rows)],
                             dtype=torch.float64, device=red_dev)
         per_rank = [mine]
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
             per_rank = [torch.empty_like(mine) for _ in range(world)]
@@ -752,7 +766,7 @@ def main():
         # discarded.)  Rank 0 renders the shares of two OTHER ranks again, alone, on its own GPU -- every row, every frame of the
         # job (warm-up included: the accumulation image is the mean since frame 2) -- and compares them bit for bit with what
         # arrived; its own rows against its own image.  A rank's pixels depend on nothing but (global pixel, frame).
-        if gather and not args.tile and (send is not None or use_group):
+        if gather and not args.tile and not args.no_gather_check and (send is not None or use_group):
             verdict = None
             if rank == 0:
                 import numpy as np
@@ -768,7 +782,7 @@ def main():
                     parts = {r: got[r].cpu().numpy()[: capi.tile_local_rows(height, r, world, BLOCK_ROWS)] for r in range(world)}
                     own = accum.cpu().numpy()
                     verdict = {"own_rows_identical": bool(np.array_equal(parts[0].view(np.uint32), own.view(np.uint32)))}
-                checked = sorted({1, n_split - 1} - {0})
+                checked = sorted(r for r in {1, n_split - 1} - {0} if r < n_split)
                 same = True
                 for r in checked:
                     cj = Job(workload, width, height, r, n_split, local_rank, args.variant, nthreads=threads, scene=(job.sc, job.env))
@@ -811,11 +825,16 @@ def main():
                                      "jobs; batches alternate between two streams; one ordered multi-frame "
                                      "accumulate per batch on the main stream"},
         }
+        if selftest:
+            out["rccl_selftest"] = "world of ONE over the real backend (torch.distributed 'nccl' = RCCL): process group, barrier, gather of the device-resident accumulation image on the context's stream, all_reduce / all_gather of the timings"
         if "gather_verified" in m:
             # the gathered image against shares rendered again on rank 0 (measure(): outside the timed region)
             out["gather_verified"] = m["gather_verified"]
-            out["gather_check"] = dict(m["gather_check"], what="rank 0 rendered the listed ranks' shares again, alone (every row, every frame of "
-                                       "the job incl. warm-up), and compared them bit for bit with the gathered buffers; its own rows with its own image")
+            out["gather_check"] = dict(m["gather_check"], what="a SELF-CONSISTENCY check of the gather and the de-interleave: rank 0 rendered the listed ranks' shares "
+                                       "again with the same library, alone (every row, every frame of the job incl. warm-up), and compared them bit for bit with "
+                                       "the gathered buffers; its own rows with its own image.  It proves that what arrived is what those ranks rendered and where "
+                                       "it belongs -- not that the kernels are right: that is what the parity tests hold against the oracle (tests/test_gpu_configs.py, "
+                                       "tests/test_tiles_gloo.py)")
     job.ctx.close()
 
     # ---- secondary workloads (N = 1): BASELINE.json configs[1], the default demo mesh; and the headline scene seen from
@@ -914,7 +933,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.tile:
             out["cpu_baseline"] = cpu_baseline(job)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and out is not None and out.get("gather_verified") is False:

@@ -132,6 +132,26 @@ def test_two_rank_rehearsal_of_the_headline_job_carries_a_roofline():
     assert "cpu_baseline" not in j and "forest" not in j
 
 
+def test_rccl_path_with_a_world_of_one():
+    """What a one-GPU box can run of the REAL multi-GPU path: torch.distributed over RCCL ('nccl'), the gather of the device-resident
+    accumulation image on the context's stream inside the timed region, the reductions of timings and counters -- with a world of one
+    (two ranks on one GPU are refused by RCCL: the N = 2 rehearsals above go over gloo).  Same job, same rays, same image as the plain
+    single-GPU run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MI3PT_BENCH_RCCL_SELFTEST"] = "1"
+    args = ["--steps", "4", "--warmup", "1", "--workload", "demo", "--no-pmc", "--no-cpu-baseline", "--no-also", "--no-forest"]
+    r = subprocess.run([*PLAIN, *args], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert "RCCL" in j["rccl_selftest"] and j["n_gpus"] == 1
+    assert j["gather_verified"] is True and j["gather_check"]["own_rows_identical"] is True and j["gather_check"]["ranks_rerendered"] == []
+    rank0 = j["config"]["per_rank"][0]
+    assert rank0["gather_ms"] is not None and rank0["gather_ms"] > 0 and rank0["rows"] == 1080
+    plain = subprocess.run([*PLAIN, *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    assert _line(plain.stdout)["config"]["rays_per_step"] == j["config"]["rays_per_step"]
+
+
 def test_device_group_rehearsal_line():
     """`bench.py --gpus 2 --group`: one process, the library's own tile split and peer-copy gather (mi3pt_create_group) -- here
     with both members on the box's one GPU.  Same job, same rays as two processes over torch.distributed."""

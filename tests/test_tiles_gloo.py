@@ -161,3 +161,10 @@ def test_deinterleave_is_the_inverse_of_the_row_deal():
             pad[:len(rows)] = img[rows]
             parts.append(pad)
         assert np.array_equal(deinterleave_rows(parts, h, world, block), img)
+        # the deal is the LIBRARY's (tiles.local_rows_of asks it row by row): every image row has exactly one owner, mi3pt_tile_owner names
+        # it, and a rank's rows come in ascending order, in whole blocks of `block` rows except at the image's end
+        assert sorted(y for r in range(world) for y in local_rows_of(h, r, world, block)) == list(range(h))
+        for r in range(world):
+            rows = local_rows_of(h, r, world, block)
+            assert rows == sorted(rows) and all(capi.tile_owner(y, world, block) == r for y in rows)
+            assert all(rows[i + 1] == rows[i] + 1 for i in range(len(rows) - 1) if (i + 1) % block)

@@ -1300,8 +1300,8 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.wide = static_cast<const float4 *>(ctx->d_wide);
     s.cwide = static_cast<const float4 *>(ctx->cwide_ok ? ctx->d_cwide : nullptr);
     s.tripk64 = static_cast<const float4 *>(ctx->cwide_ok ? ctx->d_tripk64 : nullptr);
-    s.cw8 = static_cast<const float4 *>(ctx->cwide_ok && ctx->cw8_ok ? ctx->d_cw8 : nullptr);
-    s.tripk8 = static_cast<const float4 *>(ctx->cwide_ok && ctx->cw8_ok ? ctx->d_tripk8 : nullptr);
+    s.cw8 = static_cast<const float4 *>(ctx->cw8_ok ? ctx->d_cw8 : nullptr);
+    s.tripk8 = static_cast<const float4 *>(ctx->cw8_ok ? ctx->d_tripk8 : nullptr);
     s.wide_leaf_cap = ctx->wide_ok ? ctx->wide_leaf_cap : 0;
     s.wide_root = ctx->wide_root;
     s.cdf = static_cast<const float4 *>(ctx->d_cdf);
@@ -1310,7 +1310,7 @@ static pt::SceneRefs scene_refs(const mi3pt_ctx *ctx)
     s.npackets = (uint32_t)ctx->npackets;
     s.root_ref = ctx->root_ref;
     s.flags = ctx->scene_flags;
-    if (ctx->wide_ok && ctx->wide_root_nested) s.flags |= 2u;      // (pt_kernels.h SceneRefs::flags bit 1)
+    if ((ctx->wide_ok && ctx->wide_root_nested) || ctx->cw8_ok) s.flags |= 2u;      // (pt_kernels.h SceneRefs::flags bit 1; the 8-wide packets are only built for trees whose every box is nested)
     if (ctx->wide_ok && ctx->auto_wide_variant == 12) s.flags |= 4u;  // (bit 2: the one-axis culling condition suits this scene -- variant 13 takes the hint)
     s.cull_ka = ctx->cull_ka; s.cull_kb = ctx->cull_kb;
 #ifdef MI3PT_EXPERIMENTS
@@ -1947,7 +1947,6 @@ static int prepare_cull(mi3pt_ctx *ctx)
             // with the triangle.  Offered when every internal box contains its children's (the reference then reaches a leaf iff
             // the leaf's box passes) and every coordinate is finite and of ordinary magnitude.
             ctx->cwide_ok = false;
-            ctx->cw8_ok = false;
             {
                 bool ok = true;
                 for (size_t i = 0; i < n && ok; i++) {
@@ -2041,18 +2040,6 @@ static int prepare_cull(mi3pt_ctx *ctx)
                     if (int rc = replace_buffer(ctx, &ctx->d_cwide, cp.data(), cp.size() * sizeof(pt::CWidePacket))) return rc;
                     if (int rc = replace_buffer(ctx, &ctx->d_tripk64, t64.data(), t64.size() * sizeof(pt::TriPacket64))) return rc;
                     ctx->cwide_ok = true;
-                    // ---- the 8-wide packets of kernel variant 14 (same preconditions; its walk's node stack holds one entry per level)
-                    ctx->cw8_ok = false;
-                    Cw8Build b8;
-                    if (ctx->ntris < 0x7fffffffu && build_cw8(src, n, reinterpret_cast<const float *>(tris.data()), nt, wmax, b8) &&
-                        b8.height <= pt::SM_W8_MIN_LDS_NODES + pt::SM_W8_OVERFLOW_NODES) {
-                        if (int rc = replace_buffer(ctx, &ctx->d_cw8, b8.packets.data(), b8.packets.size() * sizeof(pt::CW8Packet))) return rc;
-                        if (int rc = replace_buffer(ctx, &ctx->d_tripk8, b8.records.data(), b8.records.size() * sizeof(pt::TriPacket64))) return rc;
-                        ctx->cw8_ok = true;
-                        ctx->ncw8 = b8.packets.size();
-                        ctx->cw8_height = b8.height;
-                        ctx->cw8_records = b8.records.size();
-                    }
                 }
             }
             ctx->nwide = wp.size();
@@ -2060,6 +2047,35 @@ static int prepare_cull(mi3pt_ctx *ctx)
             ctx->wide_root = 0;
             ctx->wide_ok = true;
             ctx->wide_root_nested = nested[0] != 0;
+        }
+    }
+    // ---- the 8-wide packets of kernel variant 14: its own preconditions -- every internal box contains its children's boxes, every
+    // coordinate is finite and of ordinary magnitude (what the compressed 4-ary packets ask for) -- and its own stack bound: the walk's
+    // node stack holds one entry per packet LEVEL, whatever the order (the 4-ary walk's bound, up to three entries per level, does not apply)
+    ctx->cw8_ok = false;
+    if (!is_leaf(0) && nt < 0x7fffffffu) {
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++) {
+            const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+            for (int k = 0; k < 6 && ok; k++) { const float v = ldf(r, (size_t)(k < 3 ? 4 * k : 16 + 4 * (k - 3))); if (!(std::fabs(v) < 1e30f)) ok = false; }
+            if (is_leaf(i)) continue;
+            for (int32_t c : { ldi(r, 32), ldi(r, 36) }) {
+                if (c < 0 || (size_t)c >= n) { ok = false; break; }
+                const uint8_t *cr = src + (size_t)c * MI3PT_BVHNODE_STRIDE;
+                float mn[3], mx[3];
+                for (int k = 0; k < 3; k++) { mn[k] = ldf(cr, 4 * k); mx[k] = ldf(cr, 16 + 4 * k); }
+                if (!inside(r, mn, mx)) ok = false;
+            }
+        }
+        Cw8Build b8;
+        if (ok && build_cw8(src, n, reinterpret_cast<const float *>(tris.data()), nt, wmax, b8) &&
+            b8.height <= pt::SM_W8_MIN_LDS_NODES + pt::SM_W8_OVERFLOW_NODES) {
+            if (int rc = replace_buffer(ctx, &ctx->d_cw8, b8.packets.data(), b8.packets.size() * sizeof(pt::CW8Packet))) return rc;
+            if (int rc = replace_buffer(ctx, &ctx->d_tripk8, b8.records.data(), b8.records.size() * sizeof(pt::TriPacket64))) return rc;
+            ctx->cw8_ok = true;
+            ctx->ncw8 = b8.packets.size();
+            ctx->cw8_height = b8.height;
+            ctx->cw8_records = b8.records.size();
         }
     }
     // ---- which wide walk `auto` means for this scene (variants 10 / 11 / 12 render the same bits; this is speed only).
@@ -2153,7 +2169,8 @@ static int pick_variant(const mi3pt_ctx *ctx)
     // admit it and as the diagnostic twin's walk
     if (ctx->variant == 0)
         return cull_ok && ctx->cull_enabled ? (wide_ok && ctx->wide_enabled ? (ctx->cwide_ok ? 13 : auto_exact_wide(ctx)) : 9) : (defer_ok ? 7 : 4);
-    if (ctx->variant == 14 && wide_ok && ctx->cwide_ok && !ctx->cw8_ok) return 13;
+    if (ctx->variant == 14 && cull_ok && ctx->cw8_ok) return 14;      // (its own packets and its own stack bound: independent of the 4-ary walk's)
+    if ((ctx->variant == 13 || ctx->variant == 14) && wide_ok && ctx->cwide_ok) return 13;
     if ((ctx->variant == 13 || ctx->variant == 14) && !(wide_ok && ctx->cwide_ok)) return wide_ok ? auto_exact_wide(ctx) : (cull_ok ? 9 : (defer_ok ? 7 : 4));
     if (ctx->variant >= 10 && ctx->variant <= 12 && !wide_ok) return cull_ok ? 9 : (defer_ok ? 7 : 4);
     if (ctx->variant == 9 && !cull_ok) return defer_ok ? 7 : 4;
@@ -2211,7 +2228,7 @@ static pt::RtLaunch build_launch(const mi3pt_ctx *ctx, const uint8_t *u, const p
     // 44 for trees of a million wide packets and more (deep walks from every camera) on compressed packets, 32 otherwise -- both
     // compile-time constants of their lean builds (as a launch parameter the threshold cost the other scenes 0.8 .. 1.5 %)
     L.walk_min = ctx->variant == 5 ? 48 : (ctx->walk_min > 0 ? ctx->walk_min
-                                           : (ctx->nwide >= (1u << 20) && ctx->wide_ok && ctx->cwide_ok && (pick_variant(ctx) == 13 || pick_variant(ctx) == 14) ? PT_DEEP_WALK_MIN : PT_DEFAULT_WALK_MIN));
+                                           : ((pick_variant(ctx) == 13 ? (ctx->nwide >= (1u << 20) && ctx->wide_ok && ctx->cwide_ok) : (pick_variant(ctx) == 14 && ctx->ncw8 >= (1u << 19))) ? PT_DEEP_WALK_MIN : PT_DEFAULT_WALK_MIN));
     L.leaf_min = ctx->leaf_min;
     L.shade_split = ctx->shade_split;
     L.tail_policy = ctx->tail_policy;
