@@ -1256,6 +1256,12 @@ PT_DEV T uniform_block(const T &v)
 #define PT_CW_NO_PAIR_TEST 0
 #endif
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
+#ifndef PT_DEEP_LEAF_MIN
+#define PT_DEEP_LEAF_MIN 32
+#endif
+#ifndef PT_DEEP_LEAF_CAP
+#define PT_DEEP_LEAF_CAP 10
+#endif
 #ifdef PT_X_TOP_CW
 #define PT_X_TOP_CW_N PT_X_TOP_CW
 #else
@@ -1314,7 +1320,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
     uint64_t *const wave_times = DIAG ? L.wave_times : nullptr;
     const bool count_on = DIAG ? wave_times != nullptr : LITE;        // the step / lane counts (LITE: always; the lean build: never)
     // ... and the step-voting knobs are the defaults as constants (launch_raytrace sends any other setting to the DIAG twin)
-    const int k_walk_min = DIAG ? L.walk_min : WMIN, k_leaf_min = DIAG ? L.leaf_min : PT_DEFAULT_LEAF_MIN;
+    const int k_walk_min = DIAG ? L.walk_min : WMIN, k_leaf_min = DIAG ? L.leaf_min : (WMIN == PT_DEEP_WALK_MIN && CW && !W8 ? PT_DEEP_LEAF_MIN : PT_DEFAULT_LEAF_MIN);
     const int k_shade_split = DIAG ? L.shade_split : PT_DEFAULT_SHADE_SPLIT, k_tail_policy = DIAG ? L.tail_policy : PT_DEFAULT_TAIL_POLICY;
     const int k_job_chunk = DIAG ? L.job_chunk : PT_DEFAULT_JOB_CHUNK;
     const bool k_tri_pair = DIAG ? L.tri_pair != 0 : !PT_CW_NO_PAIR_TEST;
@@ -1334,7 +1340,9 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
     constexpr bool PARKG = SIX && WMIN == PT_DEEP_WALK_MIN;
 #endif
     constexpr int DEPTH = PARKG ? SM_LDS_DEPTH_SIX_DEEP : (SIX ? SM_LDS_DEPTH_SIX : PT_SM_LDS_DEPTH);      // LDS stack entries per lane
-    constexpr int LCAP = W8 ? SM_W8_LEAF_CAP : SM_CULL_LEAF_CAP, NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
+    // (the builds for very large trees: a leaf list of PT_DEEP_LEAF_CAP and a triangle step from PT_DEEP_LEAF_MIN lanes on -- round 6,
+    // profiles/r06_c_leaf_step_sweep.log: the forest's walks park more leaves per ray than any other scene's)
+    constexpr int LCAP = W8 ? SM_W8_LEAF_CAP : (WMIN == PT_DEEP_WALK_MIN && CW && TUNED && DEPTH >= SM_LDS_DEPTH ? PT_DEEP_LEAF_CAP : SM_CULL_LEAF_CAP), NCAP = DEPTH - LCAP;     // culling walks: leaf list / node slots in LDS
     constexpr int NCAP8 = (DEPTH - SM_W8_LEAF_CAP) / 2;             // 8-wide walk: 64-bit node entries in LDS (two dwords each, from slot 0)
     static_assert(!W8 || (NCAP8 >= SM_W8_MIN_LDS_NODES && 2 * SM_W8_OVERFLOW_NODES <= SM_OVERFLOW_ENTRIES), "8-wide walk: node entries in LDS + overflow slice");
     // The first PT_SM_LDS_DEPTH stack entries live in LDS ([depth][lane]: conflict free);
