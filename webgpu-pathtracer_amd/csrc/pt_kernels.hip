@@ -301,10 +301,16 @@ PT_DEV bool slab_hit(float tmin, float tfar) { return fmaxf(tmin - tfar, -tfar) 
 // bound's factor (1 + 2^-20) has room for 16u.
 // ---------------------------------------------------------------------------------
 #define PT_CW_BAND 9.5367431640625e-07f      // 2^-20
+// (round 6) The first condition in the form  tmin~ (1 - 2^-20) > tfar~ , ONE fma whose sign is the exact sign of tmin~ (1 - 2^-20) - tfar~
+// (1 - 2^-20 is a binary32 number; a single rounding keeps the sign of a non-zero real, and a result that underflows to zero reads "not
+// greater": the conservative side).  It is the same condition wherever it matters: a box with tfar~ < 0 is rejected by the second condition
+// whatever the first says; with tfar~ >= 0 the product can only exceed tfar~ when tmin~ > tfar~ >= 0, i.e. M = tmin~, and then
+// tmin~ (1 - 2^-20) > tfar~  <=>  tmin~ - tfar~ > 2^-20 M.  Two instructions (a max of two magnitudes, a subtraction) fewer per box than
+// the form with M spelled out, and no rounding of its own between the quotients and the decision.
+#define PT_CW_SHRINK 0.99999904632568359375f      // 1 - 2^-20
 PT_DEV bool cwide_hit(float tmin, float tfar)
 {
-    const float m = fmaxf(fabsf(tmin), fabsf(tfar));
-    return !(fmaf(-PT_CW_BAND, m, tmin - tfar) > 0.0f) && !(tfar < 0.0f);
+    return !(fmaf(tmin, PT_CW_SHRINK, -tfar) > 0.0f) && !(tfar < 0.0f);
 }
 
 // the reference's test of a LEAF's box (raytrace.wgsl:186, 194) for the compressed-wide walk's triangle step: the filtered test,
@@ -1709,6 +1715,7 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
                         const float bt = best.t * 1.00000095367431640625f;
                         const float aix = fabsf(pre.ix), aiy = fabsf(pre.iy), aiz = fabsf(pre.iz);
                         const float ymax = fmaxf(fmaxf(aix, aiy), aiz);
+                        const float rcwy = rcw * ymax;
 #define PT_C8(K)                                                                                                              \
                         {                                                                                                      \
                             const uint32_t xe_ = (K) < 4 ? ex0 : ex1, xf_ = (K) < 4 ? fx0 : fx1, ye_ = (K) < 4 ? ey0 : ey1, yf_ = (K) < 4 ? fy0 : fy1; \
@@ -1717,10 +1724,10 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
                             const float ay_ = fmaf((float)((ye_ >> (8 * ((K) & 3))) & 0xffu), By, Ay), by_ = fmaf((float)((yf_ >> (8 * ((K) & 3))) & 0xffu), By, Ay); \
                             const float az_ = fmaf((float)((ze_ >> (8 * ((K) & 3))) & 0xffu), Bz, Az), bz_ = fmaf((float)((zf_ >> (8 * ((K) & 3))) & 0xffu), Bz, Az); \
                             const float key_ = fmaxf(fmaxf(ax_, ay_), az_), f_ = fminf(fminf(bx_, by_), bz_);                 \
-                            const float dk_ = (float)((ww_ >> (8 * ((K) & 3))) & 0xffu) * rcw;                               \
+                            const float wk_ = (float)((ww_ >> (8 * ((K) & 3))) & 0xffu);                                       \
                             float tc_;                                                                                        \
-                            if constexpr (YMAX) tc_ = fmaf(-dk_, ymax, key_);                                                 \
-                            else tc_ = fmaxf(fmaxf(fmaf(-dk_, aix, ax_), fmaf(-dk_, aiy, ay_)), fmaf(-dk_, aiz, az_));         \
+                            if constexpr (YMAX) tc_ = fmaf(-wk_, rcwy, key_);                                                 \
+                            else { const float dk_ = wk_ * rcw; tc_ = fmaxf(fmaxf(fmaf(-dk_, aix, ax_), fmaf(-dk_, aiy, ay_)), fmaf(-dk_, aiz, az_)); } \
                             mask |= (cwide_hit(key_, f_) && !(tc_ > bt)) ? (1u << (K)) : 0u;                                   \
                         }
                         PT_C8(0) PT_C8(1) PT_C8(2) PT_C8(3) PT_C8(4) PT_C8(5) PT_C8(6) PT_C8(7)
@@ -1884,12 +1891,17 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
                     // YMAX: (S) on the axis that sets the entry distance, with |RN(1/d_i)| replaced by the largest of the
                     // three -- a weaker condition than (S) on that axis, hence still sufficient
                     const float ymax = fmaxf(fmaxf(fabsf(pre.ix), fabsf(pre.iy)), fabsf(pre.iz));
+                    // (one axis: W_k (rc ymax) with the product of the two per-step factors formed ONCE -- one multiplication per child less than
+                    // (W_k rc) ymax, the same two roundings: PROOFS.md 1 budgets six for the left side of (S))
+                    const float rcy = rc * ymax;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const float dk = wgt[k] * rc;
                         float tc;
-                        if constexpr (YMAX) tc = fmaf(-dk, ymax, key[k]);
-                        else tc = fmaxf(fmaxf(fmaf(-dk, fabsf(pre.ix), tn[k].x), fmaf(-dk, fabsf(pre.iy), tn[k].y)), fmaf(-dk, fabsf(pre.iz), tn[k].z));
+                        if constexpr (YMAX) tc = fmaf(-wgt[k], rcy, key[k]);
+                        else {
+                            const float dk = wgt[k] * rc;
+                            tc = fmaxf(fmaxf(fmaf(-dk, fabsf(pre.ix), tn[k].x), fmaf(-dk, fabsf(pre.iy), tn[k].y)), fmaf(-dk, fabsf(pre.iz), tn[k].z));
+                        }
                         // a child that is missed or skipped becomes an empty entry: the sort below then moves (key, reference)
                         // pairs only -- selects, no branches, no lane masks to swap
                         cr[k] = (hit[k] && !(tc > bt)) ? cr[k] : PT_REF_NONE;
