@@ -45,7 +45,9 @@ extern "C" {
  * MI3PT_OPT_BATCH defaults to 256 frames per launch (was 64), MI3PT_OPT_WALK_MIN reads 0 = "by the size of the tree" (was 32);
  * new exports mi3pt_tile_global_row, mi3pt_tile_owner; new options MI3PT_OPT_GATE_TIMEOUT_MS, MI3PT_OPT_GATE_RELEASES, MI3PT_OPT_CAMERA_BASE,
  * MI3PT_OPT_PACKET_ORDER, MI3PT_OPT_SIX_WAVES (22 .. 27); MI3PT_OPT_WAVES_PER_CU reads up to 24 (six waves per SIMD). */
-#define MI3PT_ABI_VERSION 3
+/* 4 (round 6): mi3pt_set_rows and mi3pt_measure_tile_cost are GONE (contiguous cost-balanced bands: measured 7 % slower than the dealt
+ * 8-row blocks in round 4 and kept since as dead surface); mi3pt_set_kernel_variant accepts 14 (the eight-wide walk: an option). */
+#define MI3PT_ABI_VERSION 4
 
 typedef enum mi3pt_status {
     MI3PT_OK = 0,
@@ -173,23 +175,6 @@ int mi3pt_tile_local_rows(int height, int rank, int nranks, int block_rows); /* 
  * (may be >= height in a ragged last round: such rows do not exist; -1 for bad arguments), and the rank that owns image row y. */
 int mi3pt_tile_global_row(int local_row, int rank, int nranks, int block_rows);
 int mi3pt_tile_owner(int y, int nranks, int block_rows);
-/* The other split: this context renders the CONTIGUOUS band of rows [first_row, first_row + nrows) of the image (clipped to
- * it; nrows < 0: no band -- mi3pt_set_tile's split applies again); its textures are compact nrows x width images and a gather
- * is one contiguous copy.  Any partition of the rows renders the same pixels -- the seed comes from the global pixel index,
- * raytrace.wgsl:435-436.  Bands of equal height are badly balanced (the model sits in the middle of the image: 3x between the
- * ranks of an 8-way split of the headline view); mi3pt_measure_tile_cost + mi3pt_host.tiles.balanced_bands cut them by measured
- * cost.  MEASURED SLOWER than the round-robin tiles (slowest rank of eight 34.9 against 32.5 us per frame,
- * profiles/r04_e_bands.log): kept for experiments and for hosts that need contiguous bands, not used by the bench or by
- * device groups.  Takes effect at the next mi3pt_resize(). */
-int mi3pt_set_rows(mi3pt_ctx *ctx, int first_row, int nrows);
-/* (Experiments, like mi3pt_set_rows: it runs the 128-VGPR diagnostic twin of the walk, and its frame does not count towards
- * mi3pt_get_counters.)  One frame of this context's share of the image at the current raytrace uniforms, measured: cost[ty * ceil(width / 8) + tx]
- * receives what the paths of 8x8 tile (tx, ty) cost -- 4 per BVH packet popped, 3 per triangle tested, 10 per path segment
- * (about their shares of a wave's time).  ntiles = ceil(width / 8) * ceil(local rows / 8).  Repeatable to a fraction of a per
- * cent, not to the unit (the number of boxes a culling walk tests depends on which rays share its wave), so in a multi-process
- * job ONE rank measures and broadcasts the bands it cut.  Overwrites MI3PT_TEX_OUTPUT like a raytrace pass; needs a scene that admits kernel variants
- * 9 .. 13 (MI3PT_ERR_STATE otherwise). */
-int mi3pt_measure_tile_cost(mi3pt_ctx *ctx, uint32_t *cost, size_t ntiles);
 
 /* ---- scene upload: queue.writeBuffer of the structured views ----
  * raytrace.ts:104-121 (triangles), :138-160 (materials), :177-193 (BVH nodes).

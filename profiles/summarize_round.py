@@ -15,6 +15,10 @@ def load(name):
 
 def row(name, value, ms, r, extra=""):
     w = r.get("wave_cycles", {})
+    by = r.get("frac_by_rule")
+    if by:
+        print(f"    frac_by_rule: valu {by['valu']}  hbm_counter {by['hbm_counter']}  hbm_counter_upper {by['hbm_counter_upper']}  survey_8d_algorithmic {by['survey_8d_algorithmic']}; "
+              f"launches {[(b['frames'], b['waves_per_simd'], b['kernel_ms']) for b in r.get('launches', [])]}; requests {r.get('fabric_read_requests')}")
     print(f"| {name} | {value:,.0f} | {ms:.2f} | {r['frac']} = {r.get('valu_issue_frac')} · {r.get('lane_utilisation')} | {r['hbm']['achieved']:,.0f} → {r['hbm']['frac']} "
           f"({r['hbm']['frac_of_achievable']}) | {r.get('l2', {}).get('achieved', 0):,.0f}, {r.get('l2', {}).get('hit_rate')} | "
           f"{w.get('issuing')} / {w.get('waiting_for_memory')} / {w.get('issue_stalled')} | {r['box_tests_per_ray']} + {r['tri_tests_per_ray']} |{extra}")

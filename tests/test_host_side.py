@@ -70,7 +70,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"libmi3pt.so does not export {name}"
-    assert lib.mi3pt_abi_version() == 3
+    assert lib.mi3pt_abi_version() == 4
     out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (mi3pt_\w+)", out))
     assert exported == set(declared)
@@ -371,29 +371,6 @@ def test_ticket_division_by_multiplication():
                 assert (t * m) >> sh == t // d, (t, d)
 
 
-def test_balanced_bands_partition_the_rows():
-    """tiles.balanced_bands: contiguous bands of whole tile rows with nearly equal measured cost; pure integer arithmetic
-    (the same measurement gives the same bands); degenerate inputs."""
-    import numpy as np
-    from mi3pt_host import tiles
-    rng = np.random.default_rng(5)
-    for height, n in ((1080, 8), (1080, 4), (99, 3), (13, 4), (8, 8), (2160, 8)):
-        ty = (height + 7) // 8
-        cost = rng.integers(0, 5000, size=(ty, 17)).astype(np.uint32)
-        cost[ty // 3: ty // 2] *= 9                       # the model
-        b = tiles.balanced_bands(cost, height, n)
-        assert len(b) == n + 1 and b[0] == 0 and b[-1] == height and b == sorted(b)
-        assert all(x % 8 == 0 or x == height for x in b)
-        assert b == tiles.balanced_bands(cost.copy(), height, n)
-        if ty > n:
-            share = [int(cost[b[r] // 8:(b[r + 1] + 7) // 8].sum()) for r in range(n)]
-            assert max(share) <= cost.sum() / n + cost.sum(axis=1).max()
-        parts = [np.full((b[r + 1] - b[r], 5, 4), r, np.float32) for r in range(n)]
-        whole = tiles.stack_bands(parts, b)
-        assert whole.shape == (height, 5, 4) and all((whole[b[r]:b[r + 1]] == r).all() for r in range(n))
-    assert tiles.balanced_bands(np.zeros((5, 3)), 37, 2) == [0, 8, 37]
-
-
 def test_tile_deal_helpers_agree_with_each_other_and_the_oracle(built, orc):
     """mi3pt_tile_global_row / mi3pt_tile_owner (ABI 3): the deal for hosts that de-interleave on their own, so that nobody
     re-implements mi3pt_set_tile's formula -- it changed once (round 4: back and forth) under an unchanged ABI number."""
@@ -412,19 +389,3 @@ def test_tile_deal_helpers_agree_with_each_other_and_the_oracle(built, orc):
     assert capi.tile_global_row(0, 4, 4, 8) == -1 and capi.tile_owner(-1, 4, 8) == -1 and capi.tile_owner(5, 0, 8) == -1
 
 
-def test_balanced_bands_never_cut_twice_at_one_row():
-    """One tile row that holds several ranks' shares of the cost: every rank still gets at least one tile row, no bound repeats
-    (round-4 advice: the same bound was emitted several times and those ranks idled)."""
-    from mi3pt_host import tiles
-    rng = np.random.default_rng(5)
-    for nranks in (2, 4, 8):
-        for trows in (nranks + 1, 17, 135):
-            cost = rng.integers(1, 50, (trows, 30))
-            cost[trows // 3] *= 4000                      # the model's row: far more than a rank's share
-            h = trows * 8 - 3
-            b = tiles.balanced_bands(cost, h, nranks)
-            assert b[0] == 0 and b[-1] == h and len(b) == nranks + 1
-            assert all(b[i] < b[i + 1] for i in range(nranks)), b
-    # a flat cost is split evenly
-    b = tiles.balanced_bands(np.ones((16, 4), np.int64), 128, 4)
-    assert b == [0, 32, 64, 96, 128]

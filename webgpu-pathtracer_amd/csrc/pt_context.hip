@@ -113,9 +113,7 @@ struct mi3pt_ctx {
     int width = 0, height = 0, local_rows = 0;
     int rank = 0, nranks = 1, block_rows = 8;                 // active tile
     int next_rank = 0, next_nranks = 1, next_block_rows = 8;  // applied at resize
-    int row0 = 0, band_rows = -1;                             // active band (mi3pt_set_rows; band_rows < 0: none -- the tile above applies)
-    int next_row0 = 0, next_band_rows = -1;
-    bool partial() const { return nranks != 1 || (band_rows >= 0 && (row0 != 0 || local_rows != height)); }     // this context holds part of the image
+    bool partial() const { return nranks != 1; }     // this context holds part of the image
     float4 *d_radiance = nullptr, *d_accum_own = nullptr, *d_accum = nullptr, *d_canvas = nullptr;
     // Batched frames write per-frame radiance slots, one set per launch parity.  Allocated on
     // demand (an interactive host that presents every frame only ever needs one slot per
@@ -690,7 +688,7 @@ static void recompute_batch_cap(mi3pt_ctx *ctx)
 {
     if (ctx->width == 0) return;
     // (a band of 1 / k of the image batches k times as many frames per launch, like a rank of a k-way tile split)
-    ctx->batch_cap = batch_limit(ctx, ctx->band_rows >= 0 ? (ctx->local_rows > 0 ? std::max(1, ctx->height / ctx->local_rows) : 1) : ctx->nranks);
+    ctx->batch_cap = batch_limit(ctx, ctx->nranks);
     const size_t tex_bytes = (size_t)ctx->local_rows * ctx->width * 16;
     size_t free_b = 0, total_b = 0;
     if (tex_bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -840,16 +838,6 @@ extern "C" int mi3pt_set_pipelining(mi3pt_ctx *ctx, int enabled)
     HIP_TRY(ctx_stream_sync(ctx, ctx->stream));
     ctx->pipeline = enabled != 0;
     ctx->main_dirty = true;
-    return MI3PT_OK;
-}
-
-extern "C" int mi3pt_set_rows(mi3pt_ctx *ctx, int first_row, int nrows)
-{
-    PT_GROUP(ctx, group_unsupported("mi3pt_set_rows: a device group deals the image's rows to its members itself"));
-    if (!ctx) return pt_set_error(MI3PT_ERR_INVALID, "null context");
-    if (nrows >= 0 && first_row < 0) return pt_set_error(MI3PT_ERR_INVALID, "bad band: need first_row >= 0");
-    ctx->next_row0 = nrows < 0 ? 0 : first_row;
-    ctx->next_band_rows = nrows < 0 ? -1 : nrows;
     return MI3PT_OK;
 }
 
@@ -1167,8 +1155,6 @@ static pt::Tile tile_of(const mi3pt_ctx *ctx)
     pt::Tile t;
     t.tex_w = ctx->width; t.tex_h = ctx->height; t.local_rows = ctx->local_rows;
     t.rank = ctx->rank; t.nranks = ctx->nranks; t.block_rows = ctx->block_rows;
-    t.row0 = 0;
-    if (ctx->band_rows >= 0) { t.rank = 0; t.nranks = 1; t.block_rows = 8; t.row0 = ctx->row0; }     // a contiguous band: local row ly is image row row0 + ly
     return t;
 }
 
@@ -1216,13 +1202,11 @@ extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
     free_textures(ctx);
     ctx->width = ctx->height = ctx->local_rows = 0;
     const int rank = ctx->next_rank, nranks = ctx->next_nranks, block_rows = ctx->next_block_rows;
-    const int row0 = ctx->next_row0, band_rows = ctx->next_band_rows;
-    const int local_rows = band_rows >= 0 ? std::max(0, std::min(band_rows, height - std::min(row0, height)))      // (a band past the image's bottom: no rows)
-                                          : mi3pt_tile_local_rows(height, rank, nranks, block_rows);
+    const int local_rows = mi3pt_tile_local_rows(height, rank, nranks, block_rows);
     const size_t tex_bytes = (size_t)local_rows * width * 16;
     const size_t canvas_px = (size_t)width * height;
     pt::Tile t;
-    t.tex_w = width; t.tex_h = height; t.local_rows = local_rows; t.rank = rank; t.nranks = nranks; t.block_rows = block_rows; t.row0 = 0;
+    t.tex_w = width; t.tex_h = height; t.local_rows = local_rows; t.rank = rank; t.nranks = nranks; t.block_rows = block_rows;
     // per-wave counter slots: one per tile for the per-pixel kernels' grids, one per resident wave for the persistent kernels'
     // (whose grid is capped by the launch's JOBS -- tiles x frames -- and may exceed the tiles of one frame)
     const int ntiles_frame = pt::raytrace_grid_blocks(t);
@@ -1245,7 +1229,6 @@ extern "C" int mi3pt_resize(mi3pt_ctx *ctx, int width, int height)
         return pt_set_error(MI3PT_ERR_HIP, std::string("mi3pt_resize: allocating the textures failed: ") + hipGetErrorString(e));
     }
     ctx->rank = rank; ctx->nranks = nranks; ctx->block_rows = block_rows;
-    ctx->row0 = row0; ctx->band_rows = band_rows;
     ctx->width = width; ctx->height = height; ctx->local_rows = local_rows;
     ctx->d_radiance = radiance; ctx->d_accum_own = accum; ctx->d_accum = accum;
     ctx->d_canvas = canvas; ctx->d_canvas8 = canvas8; ctx->d_block_counters = counters;
@@ -2474,7 +2457,7 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame *frames, i
         std::memset(key, 0, sizeof key);
         std::memcpy(key, first.u_rt, 12);                 // resolution, aspect
         std::memcpy(key + 12, first.u_rt + 32, 36);       // camera position, direction, fov, focal distance (32 .. 68)
-        const int32_t tl[7] = { L.tile.tex_w, L.tile.tex_h, L.tile.local_rows, L.tile.rank, L.tile.nranks, L.tile.block_rows, L.tile.row0 };
+        const int32_t tl[6] = { L.tile.tex_w, L.tile.tex_h, L.tile.local_rows, L.tile.rank, L.tile.nranks, L.tile.block_rows };
         std::memcpy(key + 48, tl, sizeof tl);
         if (!ctx->d_cam_base[par]) {
             if (hipMalloc((void **)&ctx->d_cam_base[par], L.slot_pixels * sizeof(float4)) != hipSuccess) {
@@ -2735,49 +2718,6 @@ extern "C" int mi3pt_submit_frames(mi3pt_ctx *ctx, unsigned pass_mask, uint32_t 
                 if (int rc = flush_pending(ctx)) return rc;
         }
     }
-    return MI3PT_OK;
-}
-
-// One frame of this context's part of the image at the current raytrace uniforms, traced by the diagnostic twin, which adds up
-// what every path cost (4 per node popped, 3 per triangle tested, 10 per segment: about their shares of a wave's time) per 8x8
-// tile.  What a cost-balanced split of the image is computed from (mi3pt_host.tiles.balanced_bands).  Repeatable to a fraction of a
-// per cent only (test counts of the culling walks depend on wave scheduling): one rank measures, the bands are broadcast.
-extern "C" int mi3pt_measure_tile_cost(mi3pt_ctx *ctx, uint32_t *cost, size_t ntiles)
-{
-    PT_GROUP(ctx, group_unsupported("mi3pt_measure_tile_cost: ask a member (mi3pt_group_member)"));
-    if (int rc = require_idle(ctx)) return rc;
-    if (!cost) return pt_set_error(MI3PT_ERR_INVALID, "null argument");
-    if (ctx->width == 0) return pt_set_error(MI3PT_ERR_STATE, "measure before resize");
-    if (int rc = check_scene(ctx)) return rc;
-    if (int rc = prepare_layout(ctx)) return rc;
-    if (int rc = prepare_cull(ctx)) return rc;
-    const int variant = pick_variant(ctx);
-    if (variant < 9) return pt_set_error(MI3PT_ERR_STATE, "mi3pt_measure_tile_cost: the scene does not admit the culling walks (kernel variants 9 .. 13), whose diagnostic twin does the measuring");
-    pt::RtLaunch L = build_launch(ctx, ctx->u_rt, acc_uniforms(ctx));
-    const size_t n = (size_t)pt::raytrace_grid_blocks(L.tile);
-    if (n != ntiles) return pt_set_error(MI3PT_ERR_INVALID, "mi3pt_measure_tile_cost: ntiles must be ceil(width / 8) * ceil(local rows / 8)");
-    if (n == 0) return MI3PT_OK;
-    uint32_t *d_cost = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_cost, n * 4));
-    hipError_t e = hipMemsetAsync(d_cost, 0, n * 4, ctx->stream);
-    L.tile_cost = d_cost;
-    L.block_counters = nullptr;          // a measuring frame is no rendered frame: mi3pt_get_counters does not see it (round-4 advice: a bench's Mrays/s after a measurement was inflated)
-    L.service = reinterpret_cast<pt::RtService *>(ctx->d_service + (size_t)SERVICE_SLOTS * service_slot_bytes());
-    if (e == hipSuccess) {
-        ctx->last_route = pt::raytrace_route(L, variant);
-        pt::launch_raytrace_setup(L, false, variant, ctx->stream);
-        pt::launch_raytrace(L, false, variant, ctx->stream);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream, "read-back");      // (a copy to pageable memory blocks the host until the stream gets there: the bounded wait comes first)
-    if (e == hipSuccess) e = hipMemcpyAsync(cost, d_cost, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = ctx_stream_sync(ctx, ctx->stream);
-    (void)hipFree(d_cost);
-    ctx->last_radiance = ctx->d_radiance;       // (the frame was written like a raytrace pass's: MI3PT_TEX_OUTPUT shows it)
-    ctx->output_is_accum = false;
-    ctx->main_dirty = true;
-    ctx->accum_version++;
-    if (e != hipSuccess) return pt_set_error(MI3PT_ERR_HIP, std::string("mi3pt_measure_tile_cost: ") + hipGetErrorString(e));
     return MI3PT_OK;
 }
 

@@ -228,7 +228,6 @@ struct Tile {
     int32_t tex_w, tex_h;        // full texture size
     int32_t local_rows;          // rows held by this rank
     int32_t rank, nranks, block_rows;
-    int32_t row0;                // nranks == 1: the image row of local row 0 (mi3pt_set_rows: a contiguous band; 0 for the whole image)
 };
 
 // The step-voting knobs' defaults (the context's initial values; the shipped kernels' tuned instantiation has them as constants)
@@ -283,8 +282,7 @@ struct RtLaunch {
     int32_t num_cus;             // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     uint32_t *tile_cost;         // state-machine kernel (diagnostic twin), or null: [tiles of this rank's frame] what the paths of each 8x8 tile
                                  // cost this launch -- 4 per node popped, 3 per triangle tested, 10 per path segment, about their shares of a
-                                 // wave's time -- added up with one atomic per finished path: the cost feedback behind tile_perm and
-                                 // mi3pt_measure_tile_cost
+                                 // wave's time -- added up with one atomic per finished path: the cost feedback behind tile_perm
     const uint32_t *tile_perm;   // state-machine kernel, or null: position in the job order -> tile of the frame; the context sorts
                                  // the tiles by measured cost, costliest first, so that a launch's last tickets are its cheapest
                                  // tiles and the drain after the queue has run empty is short (any order renders the same bits)

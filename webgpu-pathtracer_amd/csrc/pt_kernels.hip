@@ -721,7 +721,7 @@ PT_DEV int local_to_global_row(int ly, const Tile &t)
     // The tile split (pt_kernels.h, Tile): local block b of rank r is block b * nranks + pos of the image, pos = r in even rounds of the
     // deal and nranks - 1 - r in odd ones -- back and forth, so that a cost that rises or falls down the image (floor, model, sky)
     // is shared out evenly (dealt one way only, rank 0 of eight got 5 % more work than rank 6: profiles/r04_rejected_and_adopted.log)
-    if (t.nranks == 1) return ly + t.row0;            // (wave-uniform fast paths: no division for the whole image or a band of it ...
+    if (t.nranks == 1) return ly;                     // (wave-uniform fast paths: no division for the whole image ...
     if (t.block_rows == 8) {                          // ... nor for the usual 8-row blocks)
         const int b = ly >> 3;
         return (((b * t.nranks + ((b & 1) ? t.nranks - 1 - t.rank : t.rank)) << 3) | (ly & 7));

@@ -91,7 +91,7 @@ assert.throws(() => r.update(empty, camera), /Input nodes array is empty/);
 
 // --- the real addon: loads, fails loudly without a device, host-side builder works
 const native = pt.loadNative();
-assert.strictEqual(native.abiVersion(), 3);
+assert.strictEqual(native.abiVersion(), 4);
 assert.strictEqual(native.tileLocalRows(70, 1, 3, 5), 25);
 // the deal goes back and forth: rank 0 of 3 owns block 0 of round 0 and block 2 of round 1 (rows 25-29 with 5-row blocks)
 assert.strictEqual(native.tileGlobalRow(0, 0, 3, 5), 0);

@@ -39,7 +39,7 @@ SYMBOLS = (
     "mi3pt_accumulation_device_ptr", "mi3pt_bind_accumulation", "mi3pt_enable_timing",
     "mi3pt_pass_time_us", "mi3pt_raytrace_launch_stats", "mi3pt_get_counters", "mi3pt_reset_counters", "mi3pt_set_kernel_variant",
     "mi3pt_set_env_sampling", "mi3pt_device_build_bvh",
-    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_debug_active_variant", "mi3pt_debug_last_launch", "mi3pt_set_rows", "mi3pt_measure_tile_cost", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
+    "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_debug_active_variant", "mi3pt_debug_last_launch", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
     "mi3pt_host_env_cdf", "mi3pt_debug_set_option", "mi3pt_debug_get_option",
     "mi3pt_create_group", "mi3pt_group_size", "mi3pt_group_member",
@@ -101,8 +101,6 @@ def load_library(path=None):
     lib.mi3pt_raytrace_launch_span.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.mi3pt_batch_capacity.argtypes = [c_void_p, ctypes.POINTER(c_int)]
     lib.mi3pt_debug_active_variant.argtypes = [c_void_p, ctypes.POINTER(c_int)]
-    lib.mi3pt_set_rows.argtypes = [c_void_p, c_int, c_int]
-    lib.mi3pt_measure_tile_cost.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.mi3pt_debug_last_launch.argtypes = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.mi3pt_create_group.argtypes = [ctypes.POINTER(c_int), c_int, c_int, ctypes.POINTER(c_void_p)]
     lib.mi3pt_group_size.argtypes = [c_void_p, ctypes.POINTER(c_int)]
@@ -283,18 +281,6 @@ class Context:
         self._c(self.lib.mi3pt_set_tile(self.handle, rank, nranks, block_rows))
         self._next_tile = (rank, nranks, block_rows)
 
-    def set_rows(self, first_row, nrows):
-        """A contiguous band [first_row, first_row + nrows) instead of a tile (nrows < 0: back to the tile); at the next resize."""
-        self._c(self.lib.mi3pt_set_rows(self.handle, int(first_row), int(nrows)))
-        self._next_band = None if nrows < 0 else (int(first_row), int(nrows))
-
-    def measure_tile_cost(self):
-        """mi3pt_measure_tile_cost: (tile rows, tile columns) uint32 costs of this context's share of the image, one frame."""
-        ty, tx = (self.local_rows + 7) // 8, (self.width + 7) // 8
-        out = np.zeros((ty, tx), np.uint32)
-        self._c(self.lib.mi3pt_measure_tile_cost(self.handle, _ptr(out), out.size))
-        return out
-
     def upload_triangles(self, tris):
         a = np.ascontiguousarray(tris)
         self._c(self.lib.mi3pt_upload_triangles(self.handle, _ptr(a), a.nbytes))
@@ -320,11 +306,7 @@ class Context:
         self._c(self.lib.mi3pt_resize(self.handle, width, height))
         self.width, self.height = width, height
         self._tile = self._next_tile
-        self._band = getattr(self, "_next_band", None)
-        if self._band is not None:
-            self.local_rows = max(0, min(self._band[1], height - min(self._band[0], height)))
-        else:
-            self.local_rows = tile_local_rows(height, *self._tile)
+        self.local_rows = tile_local_rows(height, *self._tile)
 
     def reset(self):
         self._c(self.lib.mi3pt_reset(self.handle))
