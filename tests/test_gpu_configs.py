@@ -160,6 +160,10 @@ def test_config5_forest_10m_triangles_4k_tile_split_8(gpu_ctx, orc, forest, env)
     assert pc.same_bits(whole, ref), pc.describe_diff(whole, ref)
     pc.check_counters(csame, cref, culled=False, what="deferred-leaf kernel vs per-pixel kernel")
     pc.check_counters(cwhole, cref, culled=True, what="shipped kernel vs per-pixel kernel")
+    wide8, cwide8 = _render(ctx, forest, w, h, frames, variant=14)     # the eight-wide walk (an option): its packets exist for this tree, same bits
+    assert ctx.last_launch()["variant"] == 14
+    assert pc.same_bits(wide8, ref), pc.describe_diff(wide8, ref)
+    pc.check_counters(cwide8, cref, culled=True, what="eight-wide walk vs per-pixel kernel")
     assert cref["pixels"] == w * h and cref["stack_overflows"] == 0
     assert cref["box_tests"] > 300 * cref["rays"]          # the reference walk: hundreds of boxes per ray in this scene
     assert np.isfinite(whole).all()
@@ -242,6 +246,10 @@ def test_config3_dragon_class_1080p_256spp(gpu_ctx, orc, dragon, env):
     assert ctx.last_launch()["workgroups"] == 24 * 256          # six waves per SIMD: 8.3 M jobs in the launch
     want, cwant = _oracle_image(orc, dragon, env, w, h, range(2, 2 + spp))
     _same_as_oracle(got, cgot, want, cwant, "config 3, 256 spp, the WHOLE image vs oracle")
+    # the eight-wide walk (variant 14: round 6's experiment, an option) at the same 256 spp: the same image, the same paths
+    w8, cw8 = _render_spp(ctx, dragon, w, h, spp, variant=14)
+    assert ctx.last_launch()["variant"] == 14 and ctx.last_launch()["lean"]
+    _same_as_oracle(w8, cw8, want, cwant, "config 3, 256 spp, the eight-wide walk vs oracle")
     for v in pc.variants_available(ctx, (10, 11, 12)):                     # ... and the exact-packet wide walks, on a shorter job
         a, ca = _render_spp(ctx, dragon, w, h, 16, variant=v)
         b, cb = _render_spp(ctx, dragon, w, h, 16)
