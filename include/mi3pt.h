@@ -343,6 +343,11 @@ typedef enum mi3pt_option {
                                    * whose parked path state then lives in memory), 0 = five (96 registers, 24 entries), -1 = by the size of
                                    * the launch: six from 2.5 M jobs (tiles x frames) on -- long launches gain 2 .. 5 % from the extra wave, a
                                    * rank of an 8-way split's 10 ms launches lose 2 .. 3 % to the longer drain (-1) */
+    MI3PT_OPT_COLLAPSE = 28,        /* how the reference tree's nodes are grouped into the walks' wide packets: 1 = the SAH-optimal collapse (round 6:
+                                   * fewest expected packet visits; 5.9 instead of 4.0 children per 8-ary packet), 0 = rounds 2 - 5's greedy one (open
+                                   * the child with the largest area until the packet is full: packets of two at the bottom of the tree), -1 = greedy
+                                   * for the 4-ary packets, optimal for the 8-ary ones: measured, the fuller packets change the boxes a ray tests by
+                                   * < 1 % -- the half-empty packets are the ones rays seldom reach (profiles/r06_g_collapse.log).  Same bits (-1) */
     MI3PT_OPT_DEBUG_SUPPRESS_DRAIN = 24, /* tests: arm the gate but let no kernel publish its mark (forces the situation the time-out exists for) */
     MI3PT_OPT_SLOT_SETS = 15,  /* sets of per-frame radiance slots, 2 or 3; before mi3pt_resize (2) */
     MI3PT_OPT_PIPELINE = 16,   /* = mi3pt_set_pipelining */
@@ -442,6 +447,14 @@ int mi3pt_host_build_bvh_f64(const double *positions, size_t ntris, void *nodes_
 /* updateEnvironmentTexture's CDF texture, renderer.ts:159-266: R marginal CDF,
  * G conditional CDF, B sin-weighted luminance, A 1. */
 int mi3pt_host_env_cdf(const float *rgba, int width, int height, float *cdf_rgba_out);
+/* Host-only self-check of the eight-wide packets of kernel variant 14 (no device; what the CPU tests call): builds them for a tree
+ * (48-byte records) + triangles (112-byte records) as the scene analysis does (greedy = 0: the SAH-optimal grouping, what a context uses by
+ * default for these packets; 1: the greedy one, MI3PT_OPT_COLLAPSE = 0), then walks the result independently of the builder --
+ * every leaf triangle reachable exactly once, every packet referenced once, records carrying their leaf's box and triangle, every
+ * decoded child box containing everything below it.  out[0..5] = packets, records, packet levels, children per packet x 1000,
+ * leaves reached, 1 if a context would offer variant 14 for this tree (levels within the walk's stack).  MI3PT_ERR_STATE with the
+ * reason in mi3pt_last_error when the tree does not admit the packets or a check fails. */
+int mi3pt_host_eight_wide_check(const void *nodes, size_t nodes_bytes, const void *triangles, size_t triangles_bytes, int greedy, uint64_t out[6]);
 
 #ifdef __cplusplus
 }

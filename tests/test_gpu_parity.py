@@ -1235,6 +1235,34 @@ def test_camera_rays_from_the_precomputed_base_equal_the_in_kernel_ones(gpu_ctx,
     assert pc.same_bits(got, oracle(64, 64, 4))
 
 
+@pytest.mark.parametrize("variant", [13, 14])
+def test_grouping_of_the_tree_into_packets_does_not_change_a_bit(built, orc, demo, env, variant):
+    """MI3PT_OPT_COLLAPSE: which descendants of a node its wide packet holds -- the greedy collapse of rounds 2 - 5 (0) or the SAH-optimal one
+    (1; round 6) -- for the 4-ary compressed walk (13) and the 8-wide one (14).  Only the leaves' own boxes decide what a ray tests: same image,
+    same paths; the option re-runs the scene analysis (own context), also when it changes between two frames of one scene."""
+    w, h = 112, 72
+    u = pc.rt_uniforms(demo, w, h, frame=4, bounces=6)
+    want, ocnt = orc.raytrace(pc.oracle_scene(orc, demo, env), u.tobytes(), w, h)
+    with capi.Context(0) as ctx:
+        assert ctx.get_option(capi.OPT_COLLAPSE) == -1          # by the packet width: greedy for 4-ary, optimal for 8-ary
+        pc.upload_scene(ctx, demo, env)
+        ctx.set_kernel_variant(variant)
+        ctx.resize(w, h)
+        boxes = {}
+        for c in (0, 1, -1, 0):
+            ctx.set_option(capi.OPT_COLLAPSE, c)
+            ctx.reset_counters()
+            pc.gpu_frame(ctx, u)
+            img, cnt = ctx.read_texture(capi.TEX_OUTPUT), ctx.counters()
+            assert ctx.last_launch()["variant"] == variant and ctx.get_option(capi.OPT_COLLAPSE) == c
+            assert pc.same_bits(img, want), f"collapse {c}: " + pc.describe_diff(img, want)
+            pc.check_counters(cnt, ocnt, culled=True)
+            boxes[c] = cnt["box_tests"]
+        assert boxes[0] != boxes[1]          # the two groupings ARE different trees of packets (the box-test count shows it)
+        with pytest.raises(capi.Mi3ptError):
+            ctx.set_option(capi.OPT_COLLAPSE, 2)
+
+
 @pytest.mark.parametrize("order", [1, 2])
 def test_packet_numbering_in_memory_does_not_change_a_bit(built, orc, demo, env, order):
     """MI3PT_OPT_PACKET_ORDER: the 4-ary packets numbered depth-first (1) or in three-level treelets (2) instead of breadth-first.

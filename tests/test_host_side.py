@@ -389,3 +389,43 @@ def test_tile_deal_helpers_agree_with_each_other_and_the_oracle(built, orc):
     assert capi.tile_global_row(0, 4, 4, 8) == -1 and capi.tile_owner(-1, 4, 8) == -1 and capi.tile_owner(5, 0, 8) == -1
 
 
+
+
+# ---------------------------------------------------------------- the eight-wide packets of kernel variant 14 (host-side build + self-check)
+
+def test_eight_wide_packets_pass_their_host_side_check(built):
+    """mi3pt_host_eight_wide_check builds kernel variant 14's packets as the scene analysis does and walks them independently of the
+    builder: every leaf triangle reachable exactly once, every packet referenced once, records = their leaf's box and triangle, every
+    decoded child box containing everything below it.  Here: the demo scene, random soups (ragged sizes), a two-triangle tree, the
+    hand-made deep trees of tests/test_gpu_culling.py (24 packet levels: offered; 40: more than the walk's stack holds)."""
+    import importlib.util
+    demo = scenes.demo_scene()
+    demo.build_bvh()
+    r = capi.host_eight_wide_check(demo.nodes, demo.triangles)
+    assert r["leaves"] == len(demo.triangles) == 1998 and r["offered"] and 2 <= r["levels"] <= 8
+    assert 4.0 < r["children_per_packet"] <= 8.0 and r["records"] >= r["leaves"]
+    g = capi.host_eight_wide_check(demo.nodes, demo.triangles, greedy=True)          # the greedy grouping (MI3PT_OPT_COLLAPSE = 0): emptier packets, more of them
+    assert g["leaves"] == 1998 and g["packets"] > r["packets"] and g["children_per_packet"] < r["children_per_packet"]
+    rng = np.random.default_rng(8)
+    for n in (2, 3, 9, 64, 65, 1000, 4097):
+        pos = rng.normal(size=(n, 3, 3)) * 0.1 + rng.normal(size=(n, 1, 3))
+        sc = scenes.Scene(pos, np.tile(np.array([0.0, 0.0, 1.0]), (n, 3, 1)), np.zeros(n, int), [scenes.WHITE], f"soup-{n}")
+        sc.build_bvh()
+        for greedy in (False, True):
+            r = capi.host_eight_wide_check(sc.nodes, sc.triangles, greedy)
+            assert r["leaves"] == n and r["offered"] and r["packets"] >= 1, (n, r)
+            assert r["packets"] <= max(1, n - 1) and r["records"] <= 8 * r["packets"] + 8
+    spec = importlib.util.spec_from_file_location("culling_scenes", os.path.join(ROOT, "tests", "test_gpu_culling.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for depth, offered in ((6, True), (24, True), (40, False)):
+        tris, _, nodes = mod._deep_eight_wide_scene(depth)
+        r = capi.host_eight_wide_check(nodes, tris, greedy=True)          # (the greedy grouping follows the areas these trees are built around;
+        assert r["leaves"] == len(tris) and r["offered"] is offered and depth + 1 <= r["levels"] <= depth + 3, (depth, r)
+        o = capi.host_eight_wide_check(nodes, tris)                       # the optimal one packs them flat)
+        assert o["leaves"] == len(tris) and o["offered"] and o["levels"] < r["levels"]
+    # a one-triangle tree has no packet to build: refused with a reason, not a crash
+    one = scenes.Scene(rng.normal(size=(1, 3, 3)), np.tile(np.array([0.0, 0.0, 1.0]), (1, 3, 1)), np.zeros(1, int), [scenes.WHITE], "one")
+    one.build_bvh()
+    with pytest.raises(capi.Mi3ptError):
+        capi.host_eight_wide_check(one.nodes, one.triangles)

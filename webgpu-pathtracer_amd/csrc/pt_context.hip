@@ -72,6 +72,7 @@ struct mi3pt_ctx {
     bool wide_ok = false;
     bool cwide_ok = false;          // compressed wide packets + 64-byte triangle records built (kernel variant 13): needs wide_ok, every box nested and finite
     void *d_cwide = nullptr, *d_tripk64 = nullptr;
+    bool cw8_tried = false;         // the last scene analysis ran with variant 14 selected: the 8-wide packets were built, or found impossible for this tree
     bool cw8_ok = false;            // 8-wide compressed packets + their triangle records built (kernel variant 14): needs cwide_ok
     void *d_cw8 = nullptr, *d_tripk8 = nullptr;
     size_t ncw8 = 0, cw8_records = 0;
@@ -133,6 +134,7 @@ struct mi3pt_ctx {
     uint8_t cam_base_key[2][80] = {};
     bool cam_base_valid[2] = { false, false };
     bool cam_base_enabled = true;        // MI3PT_OPT_CAMERA_BASE
+    int collapse = -1;                   // MI3PT_OPT_COLLAPSE: 1 = the SAH-optimal grouping of the tree's nodes into wide packets, 0 = the greedy one of rounds 2 - 5, -1 = greedy for the 4-ary packets, optimal for the 8-ary ones (what each measured best with)
     int six_waves = -1;                  // MI3PT_OPT_SIX_WAVES: the compressed-wide walk's build, -1 = by the size of the launch (pt::RtLaunch::six_waves)
     int packet_order = 0;                // MI3PT_OPT_PACKET_ORDER: numbering of the wide packets in memory (prepare_cull): 0 breadth-first, 1 depth-first, 2 treelets
     uint32_t *d_canvas8 = nullptr;
@@ -681,6 +683,7 @@ extern "C" int mi3pt_set_kernel_variant(mi3pt_ctx *ctx, int variant)
 #endif
     if (int rc = require_idle(ctx)) return rc;
     ctx->variant = variant;
+    if (variant == 14 && !ctx->cw8_ok && !ctx->cw8_tried) ctx->cull_dirty = true;      // (the 8-wide packets are built on demand: prepare_cull)
     return MI3PT_OK;
 }
 
@@ -732,6 +735,10 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
     case MI3PT_OPT_GATE: ctx->gate_enabled = value != 0 && ctx->d_drain_flag != nullptr; if (ctx->gate_enabled) { ctx->gate_releases = 0; ctx->gate_stalls_in_a_row = 0; } break;
     case MI3PT_OPT_CAMERA_BASE: ctx->cam_base_enabled = value != 0; break;
     case MI3PT_OPT_SIX_WAVES: ctx->six_waves = value < 0 ? -1 : (value != 0 ? 1 : 0); break;
+    case MI3PT_OPT_COLLAPSE:
+        if (value < -1 || value > 1) return pt_set_error(MI3PT_ERR_INVALID, "collapse: 0 greedy, 1 optimal, -1 by the packet width");
+        if (ctx->collapse != value) { ctx->collapse = value; ctx->cull_dirty = true; }
+        break;
     case MI3PT_OPT_PACKET_ORDER:
         if (value < 0 || value > 2) return pt_set_error(MI3PT_ERR_INVALID, "packet order: 0 breadth-first, 1 depth-first, 2 treelets");
         if (ctx->packet_order != value) { ctx->packet_order = value; ctx->cull_dirty = true; }
@@ -792,6 +799,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_GATE: *value = ctx->gate_enabled ? 1 : 0; break;
     case MI3PT_OPT_CAMERA_BASE: *value = ctx->cam_base_enabled ? 1 : 0; break;
     case MI3PT_OPT_SIX_WAVES: *value = ctx->six_waves; break;
+    case MI3PT_OPT_COLLAPSE: *value = ctx->collapse; break;
     case MI3PT_OPT_PACKET_ORDER: *value = ctx->packet_order; break;
     case MI3PT_OPT_GATE_TIMEOUT_MS: *value = ctx->gate_timeout_ms; break;
     case MI3PT_OPT_GATE_RELEASES: *value = ctx->gate_releases; break;
@@ -1422,6 +1430,87 @@ static inline uint32_t round_up_16(float f)
     return r > 0x7f80u ? 0x7f80u : r;
 }
 
+// ---- Which descendants of a binary node become the children of its W-wide packet: the SAH-optimal collapse (Ylitie, Karras, Laine 2017,
+// section 3.1, with one triangle per leaf).  cost(n, i) = the least expected number of packet visits for the subtree under n when it is
+// represented by at most i packets-or-leaves hanging under ONE parent packet (surface area relative to the root = the chance that a
+// random ray visits):
+//     cost(leaf, i) = 0;   cost(n, 1) = area(n) + min_{0<k<W} cost(left, k) + cost(right, W - k)           (n becomes a packet)
+//     cost(n, i)    = min( cost(n, i - 1),  min_{0<k<i} cost(left, k) + cost(right, i - k) )               (n is opened: its children stand in for it)
+// bottom-up over the nodes (children have larger indices than their parent: checked at upload).  A node that must not be opened (a box that
+// does not contain its children's: `closed`) only has cost(n, 1).  The greedy collapse of rounds 2 - 5 (open the child with the largest area
+// until the packet is full) fills the packets near the root and leaves the bottom of the tree in packets of two: 3.0 children per 4-ary packet
+// and 4.0 per 8-ary one on the 870 k-triangle scene; the optimal one packs what can be packed.
+struct WideCollapse {
+    int W = 4;
+    std::vector<uint8_t> k0;         // per node: how many of its packet's W entries go to the left child's side
+    std::vector<uint8_t> split;      // [node][i], i = 2 .. W-1: entries for the left side when the node is opened into i entries; 0 = "as with i - 1"
+    const uint8_t *src = nullptr;
+    bool leaf(size_t i) const { return ldi(src + i * MI3PT_BVHNODE_STRIDE, 28) == 1; }
+    int32_t left(size_t i) const { return ldi(src + i * MI3PT_BVHNODE_STRIDE, 32); }
+    int32_t right(size_t i) const { return ldi(src + i * MI3PT_BVHNODE_STRIDE, 36); }
+    // the entries of node x's packet (binary node indices)
+    void children_of(size_t x, std::vector<int32_t> &out) const
+    {
+        out.clear();
+        std::vector<std::pair<int32_t, int>> work;      // (node, entries it may use)
+        work.emplace_back(right(x), W - (int)k0[x]);
+        work.emplace_back(left(x), (int)k0[x]);
+        while (!work.empty()) {
+            auto [c, i] = work.back();
+            work.pop_back();
+            if (leaf((size_t)c) || i <= 1) { out.push_back(c); continue; }
+            int k = 0;
+            while (i >= 2 && (k = split[(size_t)c * (size_t)W + (size_t)i]) == 0) i--;
+            if (i < 2) { out.push_back(c); continue; }
+            work.emplace_back(right((size_t)c), i - k);
+            work.emplace_back(left((size_t)c), k);
+        }
+    }
+};
+static bool collapse_optimal(const uint8_t *src, size_t n, int W, const std::vector<uint8_t> *closed, WideCollapse &out)
+{
+    out.W = W; out.src = src;
+    out.k0.assign(n, 1);
+    out.split.assign(n * (size_t)W, 0);
+    std::vector<float> cost(n * (size_t)W, 0.0f);        // [node][i], i = 1 .. W-1 (slot 0 unused)
+    auto area = [&](size_t i) {
+        const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
+        const double x = (double)ldf(r, 16) - ldf(r, 0), y = (double)ldf(r, 20) - ldf(r, 4), z = (double)ldf(r, 24) - ldf(r, 8);
+        const double a = x * y + x * z + y * z;
+        return a == a && a > 0.0 ? a : 0.0;
+    };
+    const double a0 = area(0) > 0.0 ? area(0) : 1.0;
+    for (size_t i = n; i-- > 0;) {
+        if (out.leaf(i)) continue;                        // cost 0 for every i
+        const int32_t l = out.left(i), r = out.right(i);
+        if (l < 0 || r < 0 || (size_t)l >= n || (size_t)r >= n || (size_t)l <= i || (size_t)r <= i) return false;
+        const float *cl = &cost[(size_t)l * (size_t)W], *cr = &cost[(size_t)r * (size_t)W];
+        float *c = &cost[i * (size_t)W];
+        // as a packet of its own
+        float best = 3.0e38f;
+        int bk = 1;
+        for (int k = 1; k < W; k++) {
+            const float v = cl[k] + cr[W - k];
+            if (v < best) { best = v; bk = k; }
+        }
+        out.k0[i] = (uint8_t)bk;
+        c[1] = (float)(area(i) / a0) + best;
+        const bool may_open = !(closed && (*closed)[i]);
+        for (int j = 2; j < W; j++) {
+            float v = c[j - 1];
+            int vk = 0;
+            if (may_open)
+                for (int k = 1; k < j; k++) {
+                    const float d = cl[k] + cr[j - k];
+                    if (d < v) { v = d; vk = k; }
+                }
+            c[j] = v;
+            out.split[i * (size_t)W + (size_t)j] = (uint8_t)vk;
+        }
+    }
+    return true;
+}
+
 // ---- Eight-wide compressed packets + their triangle records (kernel variant 14; pt_kernels.h: CW8Packet).
 // Built from the reference's binary tree (`src`: the uploaded 48-byte records, every internal box containing its children's -- the
 // caller has checked -- and every coordinate finite): a packet stands for a binary node and holds up to eight of its descendants,
@@ -1439,8 +1528,11 @@ struct Cw8Build {
     double mean_children = 0.0;
 };
 static bool build_cw8(const uint8_t *src, size_t n, const float *verts /* 12 floats per triangle: a, pad, b, pad, c, pad */, size_t nt,
-                      const std::vector<float> &wmax, Cw8Build &out)
+                      const std::vector<float> &wmax, Cw8Build &out, bool greedy = false)
 {
+    WideCollapse plan;
+    std::vector<int32_t> entries;
+    if (!greedy && !collapse_optimal(src, n, 8, nullptr, plan)) return false;
     auto is_leaf = [&](size_t i) { return ldi(src + i * MI3PT_BVHNODE_STRIDE, 28) == 1; };
     auto box = [&](size_t i, int k) { return ldf(src + i * MI3PT_BVHNODE_STRIDE, (size_t)(k < 3 ? 4 * k : 16 + 4 * (k - 3))); };
     auto area = [&](size_t i) {
@@ -1462,20 +1554,27 @@ static bool build_cw8(const uint8_t *src, size_t n, const float *verts /* 12 flo
         int32_t set[8] = { ldi(r, 32), ldi(r, 36), -1, -1, -1, -1, -1, -1 };
         if (set[0] < 0 || set[1] < 0 || (size_t)set[0] >= n || (size_t)set[1] >= n) return false;
         int cnt = 2;
-        while (cnt < 8) {
-            int pick = -1;
-            double best_area = -1.0;
-            for (int k = 0; k < cnt; k++) {
-                if (is_leaf((size_t)set[k])) continue;
-                const double a = area((size_t)set[k]);
-                if (a > best_area) { best_area = a; pick = k; }
+        if (greedy) {
+            while (cnt < 8) {
+                int pick = -1;
+                double best_area = -1.0;
+                for (int k = 0; k < cnt; k++) {
+                    if (is_leaf((size_t)set[k])) continue;
+                    const double a = area((size_t)set[k]);
+                    if (a > best_area) { best_area = a; pick = k; }
+                }
+                if (pick < 0) break;
+                const uint8_t *cr = src + (size_t)set[pick] * MI3PT_BVHNODE_STRIDE;
+                const int32_t cl = ldi(cr, 32), crr = ldi(cr, 36);
+                if (cl < 0 || crr < 0 || (size_t)cl >= n || (size_t)crr >= n) return false;
+                set[pick] = cl;
+                set[cnt++] = crr;
             }
-            if (pick < 0) break;
-            const uint8_t *cr = src + (size_t)set[pick] * MI3PT_BVHNODE_STRIDE;
-            const int32_t cl = ldi(cr, 32), crr = ldi(cr, 36);
-            if (cl < 0 || crr < 0 || (size_t)cl >= n || (size_t)crr >= n) return false;
-            set[pick] = cl;
-            set[cnt++] = crr;
+        } else {
+            plan.children_of(x, entries);
+            if (entries.size() < 2 || entries.size() > 8) return false;
+            cnt = (int)entries.size();
+            for (int k = 0; k < cnt; k++) set[k] = entries[(size_t)k];
         }
         total_children += (size_t)cnt;
         // slots: greedy matching of (child, slot) by the projection of the child's centre offset on the slot's direction
@@ -1628,6 +1727,104 @@ static bool build_cw8(const uint8_t *src, size_t n, const float *verts /* 12 flo
     out.height = height;
     out.mean_children = np ? (double)total_children / (double)np : 0.0;
     return true;
+}
+
+// Host-only check of the 8-wide packets (no device: `-m "not gpu"` tests call it): builds them for a tree + triangles in the reference's
+// layouts exactly as prepare_cull does (weights aside: all zero) and walks the result INDEPENDENTLY of the builder's bookkeeping -- every
+// leaf triangle of the tree reachable exactly once, every packet referenced exactly once, a leaf slot's record carrying that triangle's index
+// and its leaf's box bit for bit, every decoded child box (the fma the kernel's plain-division path uses) containing everything below it.
+// out[0..5] = packets, records, packet levels, children per packet x 1000, leaves reached, 1 if the kernel would be offered these packets.
+extern "C" int mi3pt_host_eight_wide_check(const void *nodes, size_t nodes_bytes, const void *triangles, size_t triangles_bytes, int greedy, uint64_t out[6])
+{
+    if (!nodes || !triangles || !out || nodes_bytes % MI3PT_BVHNODE_STRIDE || triangles_bytes % MI3PT_TRIANGLE_STRIDE)
+        return pt_set_error(MI3PT_ERR_INVALID, "mi3pt_host_eight_wide_check: bad argument");
+    const size_t n = nodes_bytes / MI3PT_BVHNODE_STRIDE, nt = triangles_bytes / MI3PT_TRIANGLE_STRIDE;
+    const uint8_t *src = static_cast<const uint8_t *>(nodes);
+    std::vector<float> verts(nt * 12, 0.0f);
+    for (size_t t = 0; t < nt; t++)
+        for (int v = 0; v < 3; v++) std::memcpy(&verts[t * 12 + 4 * (size_t)v], static_cast<const uint8_t *>(triangles) + t * MI3PT_TRIANGLE_STRIDE + 16 * (size_t)v, 12);
+    std::vector<float> wmax(n, 0.0f);
+    Cw8Build b;
+    for (int k = 0; k < 6; k++) out[k] = 0;
+    if (!build_cw8(src, n, verts.data(), nt, wmax, b, greedy != 0)) return pt_set_error(MI3PT_ERR_STATE, "mi3pt_host_eight_wide_check: the tree does not admit the 8-wide packets");
+    auto fail = [](const std::string &what) { return pt_set_error(MI3PT_ERR_STATE, "mi3pt_host_eight_wide_check: " + what); };
+    // leaf of every triangle in the source tree
+    std::vector<int64_t> leaf_of(nt, -1);
+    size_t nleaves = 0;
+    for (size_t i = 0; i < n; i++)
+        if (ldi(src + i * MI3PT_BVHNODE_STRIDE, 28) == 1) {
+            const int32_t ti = ldi(src + i * MI3PT_BVHNODE_STRIDE, 40);
+            if (ti < 0 || (size_t)ti >= nt || leaf_of[(size_t)ti] >= 0) return fail("the source tree is not proper");
+            leaf_of[(size_t)ti] = (int64_t)i;
+            nleaves++;
+        }
+    const size_t np = b.packets.size();
+    std::vector<uint8_t> pseen(np, 0), tseen(nt, 0);
+    std::vector<std::array<float, 6>> below(np);      // union of the LEAF boxes below each packet (filled bottom-up: children have larger indices)
+    size_t reached = 0;
+    int levels = 0;
+    std::vector<int> level(np, 0);
+    level[0] = 1; pseen[0] = 1;
+    for (size_t w = 0; w < np; w++) {                 // parents before children: propagate levels, check references
+        const pt::CW8Packet &c = b.packets[w];
+        if (!pseen[w]) return fail("a packet nobody refers to");
+        const uint32_t imask = c.meta >> 24, base = c.child & 0xffffffu;
+        uint32_t rank = 0;
+        for (int sl = 0; sl < 8; sl++)
+            if (imask & (1u << sl)) {
+                const size_t ch = (size_t)base + rank++;
+                if (ch >= np || ch <= w || pseen[ch]) return fail("a child reference out of range, not after its parent, or shared");
+                pseen[ch] = 1;
+                level[ch] = level[w] + 1;
+            }
+        if (level[w] > levels) levels = level[w];
+    }
+    for (size_t w = np; w-- > 0;) {                   // children before parents: boxes
+        const pt::CW8Packet &c = b.packets[w];
+        const uint32_t imask = c.meta >> 24, base = c.child & 0xffffffu, rbase = c.tri & 0xffffffu;
+        float cell[3];
+        for (int ax = 0; ax < 3; ax++) { const uint32_t e = (c.meta >> (8 * ax)) & 0xffu; const uint32_t bits = e << 23; std::memcpy(&cell[ax], &bits, 4); }
+        std::array<float, 6> u = { 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f };
+        uint32_t rank = 0, children = 0;
+        for (int sl = 0; sl < 8; sl++) {
+            uint32_t qa[3], qz[3];
+            bool empty = true;
+            for (int ax = 0; ax < 3; ax++) {
+                qa[ax] = (c.qlo[ax][sl >> 2] >> (8 * (sl & 3))) & 0xffu; qz[ax] = (c.qhi[ax][sl >> 2] >> (8 * (sl & 3))) & 0xffu;
+                if (!(qa[ax] == 255u && qz[ax] == 0u)) empty = false;
+            }
+            const bool internal = (imask >> sl) & 1u;
+            if (empty) { if (internal) return fail("an empty slot marked internal"); continue; }
+            children++;
+            std::array<float, 6> cb;                   // what lies below this slot
+            if (internal) cb = below[(size_t)base + rank++];
+            else {
+                const pt::TriPacket64 &q = b.records[(size_t)rbase + (size_t)sl];
+                const uint32_t ti = q.unsafe & 0x7fffffffu;
+                if (ti >= nt || leaf_of[ti] < 0 || tseen[ti]) return fail("a record without a leaf of its own");
+                tseen[ti] = 1; reached++;
+                const uint8_t *lr = src + (size_t)leaf_of[ti] * MI3PT_BVHNODE_STRIDE;
+                for (int k = 0; k < 3; k++) {
+                    if (std::memcmp(&q.bmin[k], lr + 4 * (size_t)k, 4) || std::memcmp(&q.bmax[k], lr + 16 + 4 * (size_t)k, 4)) return fail("a record whose box is not its leaf's box");
+                    const float a = verts[(size_t)ti * 12 + (size_t)k];
+                    if (std::memcmp(&q.a[k], &a, 4)) return fail("a record whose vertex is not its triangle's");
+                    cb[(size_t)k] = q.bmin[k]; cb[3 + (size_t)k] = q.bmax[k];
+                }
+            }
+            for (int ax = 0; ax < 3; ax++) {
+                const float lo = std::fma((float)qa[ax], cell[ax], c.o[ax]), hi = std::fma((float)qz[ax], cell[ax], c.o[ax]);
+                if (!(lo <= cb[(size_t)ax] && hi >= cb[3 + (size_t)ax])) return fail("a decoded box that does not contain what is below it");
+                u[(size_t)ax] = std::min(u[(size_t)ax], cb[(size_t)ax]); u[3 + (size_t)ax] = std::max(u[3 + (size_t)ax], cb[3 + (size_t)ax]);
+            }
+        }
+        if (children != ((c.tri >> 24) & 15u) || children < 2) return fail("a packet's child count");
+        below[w] = u;
+    }
+    if (reached != nleaves) return fail("not every leaf is reachable");
+    if (levels != b.height) return fail("the builder's height is not the tree's");
+    out[0] = np; out[1] = b.records.size(); out[2] = (uint64_t)b.height; out[3] = (uint64_t)(b.mean_children * 1000.0 + 0.5); out[4] = reached;
+    out[5] = b.height <= pt::SM_W8_MIN_LDS_NODES + pt::SM_W8_OVERFLOW_NODES ? 1 : 0;
+    return MI3PT_OK;
 }
 
 static int prepare_cull(mi3pt_ctx *ctx)
@@ -1802,11 +1999,28 @@ static int prepare_cull(mi3pt_ctx *ctx)
         std::vector<uint32_t> queue;                           // breadth-first numbering
         queue.push_back(0);
         wide_of[0] = 0;
+        // (round 6) which descendants a packet holds: the SAH-optimal collapse (collapse_optimal above; a node whose box does not contain its
+        // children's is never opened) -- or, MI3PT_OPT_COLLAPSE = 0, the greedy one of rounds 2 - 5
+        WideCollapse plan4;
+        std::vector<int32_t> entries4;
+        bool optimal4 = ctx->collapse == 1;
+        if (optimal4) {
+            std::vector<uint8_t> closed(n, 0);
+            for (size_t i = 0; i < n; i++) closed[i] = nested[i] ? 0 : 1;
+            optimal4 = collapse_optimal(src, n, 4, &closed, plan4);
+        }
         for (size_t qi = 0; qi < queue.size(); qi++) {
             const uint32_t x = queue[qi];
             const uint8_t *r = src + (size_t)x * MI3PT_BVHNODE_STRIDE;
             int32_t set[4] = { ldi(r, 32), ldi(r, 36), -1, -1 };
             int cnt = 2;
+            if (optimal4 && set[0] >= 0 && set[1] >= 0) {
+                plan4.children_of(x, entries4);
+                if (entries4.size() >= 2 && entries4.size() <= 4) {
+                    cnt = (int)entries4.size();
+                    for (int k = 0; k < cnt; k++) set[k] = entries4[(size_t)k];
+                }
+            } else
             while (cnt < 4) {
                 int pick = -1;
                 double best_area = -1.0;
@@ -2035,8 +2249,11 @@ static int prepare_cull(mi3pt_ctx *ctx)
     // ---- the 8-wide packets of kernel variant 14: its own preconditions -- every internal box contains its children's boxes, every
     // coordinate is finite and of ordinary magnitude (what the compressed 4-ary packets ask for) -- and its own stack bound: the walk's
     // node stack holds one entry per packet LEVEL, whatever the order (the 4-ary walk's bound, up to three entries per level, does not apply)
+    // Built only for a context that has asked for the walk (mi3pt_set_kernel_variant(ctx, 14) marks the analysis dirty when they are missing):
+    // an option nobody selected must not cost every scene's first submit the second collapse.
     ctx->cw8_ok = false;
-    if (!is_leaf(0) && nt < 0x7fffffffu) {
+    ctx->cw8_tried = ctx->variant == 14;
+    if (ctx->variant == 14 && !is_leaf(0) && nt < 0x7fffffffu) {
         bool ok = true;
         for (size_t i = 0; i < n && ok; i++) {
             const uint8_t *r = src + i * MI3PT_BVHNODE_STRIDE;
@@ -2051,7 +2268,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
             }
         }
         Cw8Build b8;
-        if (ok && build_cw8(src, n, reinterpret_cast<const float *>(tris.data()), nt, wmax, b8) &&
+        if (ok && build_cw8(src, n, reinterpret_cast<const float *>(tris.data()), nt, wmax, b8, ctx->collapse == 0) &&
             b8.height <= pt::SM_W8_MIN_LDS_NODES + pt::SM_W8_OVERFLOW_NODES) {
             if (int rc = replace_buffer(ctx, &ctx->d_cw8, b8.packets.data(), b8.packets.size() * sizeof(pt::CW8Packet))) return rc;
             if (int rc = replace_buffer(ctx, &ctx->d_tripk8, b8.records.data(), b8.records.size() * sizeof(pt::TriPacket64))) return rc;
@@ -3244,7 +3461,7 @@ static int clone_scene(mi3pt_ctx *dst, const mi3pt_ctx *src)
     dst->leaf_cap = src->leaf_cap; dst->cull_stack_ok = src->cull_stack_ok; dst->tree_proper = src->tree_proper;
     dst->cull_dirty = src->cull_dirty; dst->cull_ok = src->cull_ok; dst->cull_ka = src->cull_ka; dst->cull_kb = src->cull_kb;
     dst->auto_wide_variant = src->auto_wide_variant; dst->wide_ok = src->wide_ok; dst->cwide_ok = src->cwide_ok; dst->nwide = src->nwide;
-    dst->cw8_ok = src->cw8_ok; dst->ncw8 = src->ncw8; dst->cw8_records = src->cw8_records; dst->cw8_height = src->cw8_height;
+    dst->cw8_ok = src->cw8_ok; dst->cw8_tried = src->cw8_tried; dst->ncw8 = src->ncw8; dst->cw8_records = src->cw8_records; dst->cw8_height = src->cw8_height;
     dst->wide_leaf_cap = src->wide_leaf_cap; dst->wide_root = src->wide_root;
     dst->layout = src->layout; dst->layout_dirty = src->layout_dirty; dst->layout_active = src->layout_active;
     dst->cost_state = 0;

@@ -24,7 +24,7 @@ PRESENT_EXACT, PRESENT_LATEST = 0, 1
 (OPT_WALK_MIN, OPT_LEAF_MIN, OPT_SHADE_SPLIT, OPT_TAIL_POLICY, OPT_TOP_PACKETS, OPT_TRI_PAIR, OPT_JOB_REVERSE, OPT_JOB_GROUP,
  OPT_JOB_CHUNK, OPT_BATCH_LIMIT, OPT_BATCH, OPT_WAVES_PER_CU, OPT_CULL, OPT_WIDE, OPT_GATE, OPT_SLOT_SETS, OPT_PIPELINE,
  OPT_COST_ORDER, OPT_PRESENT_DEPTH, OPT_HOST_ANALYSES, OPT_GATHER_STAGED, OPT_DIAG_LITE,
- OPT_GATE_TIMEOUT_MS, OPT_GATE_RELEASES, OPT_DEBUG_SUPPRESS_DRAIN, OPT_CAMERA_BASE, OPT_PACKET_ORDER, OPT_SIX_WAVES) = range(28)
+ OPT_GATE_TIMEOUT_MS, OPT_GATE_RELEASES, OPT_DEBUG_SUPPRESS_DRAIN, OPT_CAMERA_BASE, OPT_PACKET_ORDER, OPT_SIX_WAVES, OPT_COLLAPSE) = range(29)
 COUNTER_NAMES = ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels", "reserved")
 
 # every symbol include/mi3pt.h declares; tests/test_capi_symbols.py checks the header
@@ -41,7 +41,7 @@ SYMBOLS = (
     "mi3pt_set_env_sampling", "mi3pt_device_build_bvh",
     "mi3pt_set_pipelining", "mi3pt_flush", "mi3pt_set_present_mode", "mi3pt_raytrace_launch_span", "mi3pt_batch_capacity", "mi3pt_debug_active_variant", "mi3pt_debug_last_launch", "mi3pt_submit_frames", "mi3pt_debug_set_packet_layout",
     "mi3pt_debug_intersect", "mi3pt_debug_math", "mi3pt_debug_wave_times", "mi3pt_host_build_bvh", "mi3pt_host_build_bvh_f64",
-    "mi3pt_host_env_cdf", "mi3pt_debug_set_option", "mi3pt_debug_get_option",
+    "mi3pt_host_env_cdf", "mi3pt_host_eight_wide_check", "mi3pt_debug_set_option", "mi3pt_debug_get_option",
     "mi3pt_create_group", "mi3pt_group_size", "mi3pt_group_member",
     "mi3pt_tile_global_row", "mi3pt_tile_owner",
 )
@@ -117,6 +117,7 @@ def load_library(path=None):
     lib.mi3pt_host_build_bvh.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
     lib.mi3pt_host_build_bvh_f64.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_int]
     lib.mi3pt_host_env_cdf.argtypes = [c_void_p, c_int, c_int, c_void_p]
+    lib.mi3pt_host_eight_wide_check.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p]
     lib.mi3pt_device_count.argtypes = [ctypes.POINTER(c_int)]
     lib.mi3pt_device_name.argtypes = [c_int, ctypes.c_char_p, c_size_t]
     lib.mi3pt_tile_local_rows.argtypes = [c_int, c_int, c_int, c_int]
@@ -192,6 +193,17 @@ def host_build_bvh_f64(positions, nthreads=0):
     count = ctypes.c_size_t(0)
     _check(lib, lib.mi3pt_host_build_bvh_f64(_ptr(pos), n, _ptr(nodes), nodes.nbytes, ctypes.byref(count), nthreads))
     return nodes[:count.value]
+
+
+def host_eight_wide_check(nodes, triangles, greedy=False):
+    """mi3pt_host_eight_wide_check: builds kernel variant 14's packets on the host and checks them independently of the builder;
+    dict(packets, records, levels, children_per_packet, leaves, offered)."""
+    lib = load_library()
+    nd, tr = np.ascontiguousarray(nodes), np.ascontiguousarray(triangles)
+    out = np.zeros(6, np.uint64)
+    _check(lib, lib.mi3pt_host_eight_wide_check(_ptr(nd), nd.nbytes, _ptr(tr), tr.nbytes, 1 if greedy else 0, _ptr(out)))
+    return {"packets": int(out[0]), "records": int(out[1]), "levels": int(out[2]), "children_per_packet": out[3] / 1000.0,
+            "leaves": int(out[4]), "offered": bool(out[5])}
 
 
 def host_env_cdf(rgba):
