@@ -155,18 +155,22 @@ def soak_options():
                         # round 5: five / six waves per SIMD (walk_min 44 picks the deep builds: six waves = a 25-entry stack and the parked
                         # path state in memory), the camera base image, the packet numbering
                         capi.OPT_SIX_WAVES: int(rng.integers(-1, 2)), capi.OPT_CAMERA_BASE: int(rng.integers(0, 2)),
-                        capi.OPT_PACKET_ORDER: int(rng.integers(0, 3))}
+                        capi.OPT_PACKET_ORDER: int(rng.integers(0, 3)),
+                        # round 6: how the tree's nodes are grouped into packets (greedy / SAH-optimal / by the packet width)
+                        capi.OPT_COLLAPSE: int(rng.integers(-1, 2))}
                 if rng.random() < 0.3:
                     opts[capi.OPT_WALK_MIN] = 44
+                variant = 14 if rng.random() < 0.4 else 0          # round 6: the eight-wide walk (an option) in four cases of ten
                 with capi.Context(0) as c:
                     for k, v in opts.items():
                         c.set_option(k, v)
+                    c.set_kernel_variant(variant)
                     pc.upload_scene(c, sc, ENV)
                     got, cg = render(c, sc, w, h, frames, bounces=6)
                 n += 1
                 if not (pc.same_bits(got, want) and all(cg[k] == cw[k] for k in pc.PATH_COUNTERS)):
                     fails += 1
-                    print("FAIL", name, w, h, frames, opts, flush=True)
+                    print("FAIL", name, w, h, frames, "variant", variant, opts, flush=True)
     return report("options", n, fails, t0)
 
 
