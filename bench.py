@@ -744,11 +744,11 @@ def main():
         # which instantiation the timed launches ran (mi3pt_debug_last_launch: the launches of a job are equal -- Job.plan -- so the last
         # one stands for all): template arguments DEFER, CULL, WIDE, FILT, YMAX, DIAG, TOPLDS, LITE, CW, WMIN, WAVES[, W8] -- csrc/pt_kernels.hip.
         # WAVES from the grid: a launch that fills the machine runs CUs x 4 SIMDs x WAVES one-wave workgroups
-        last = ctx.last_launch() if not use_group else {"variant": ctx.active_variant(), "lean": None, "workgroups": None}
+        last = ctx.last_launch() if not use_group else {"variant": ctx.active_variant(), "lean": None, "workgroups": None, "waves_per_simd": 0, "ymax": None, "walk_min": 0}
         v, wg = last["variant"], last["workgroups"]
-        waves = (wg // (capi_num_cus() * 4)) if wg and wg % (capi_num_cus() * 4) == 0 and wg // (capi_num_cus() * 4) in (4, 5, 6) else None
-        ymax = "YMAX"
-        wmin = 44 if workload == "forest" else 32
+        waves = last["waves_per_simd"] or None                   # (MI3PT_OPT_LAST_BUILD: the template arguments rocprofv3 prints for this launch)
+        ymax = {True: "true", False: "false", None: "YMAX"}[last["ymax"]]
+        wmin = last["walk_min"] or "WMIN"
         names = {14: f"k_raytrace_sm<true,true,true,true,{ymax},false,false,false,true,{wmin},{waves or 'WAVES'},true>",
                  13: f"k_raytrace_sm<true,true,true,true,{ymax},false,false,false,true,{wmin},{waves or 'WAVES'}>",
                  12: "k_raytrace_sm<true,true,true,true,true,false>", 11: "k_raytrace_sm<true,true,true,true,false,false>",

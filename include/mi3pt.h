@@ -343,6 +343,9 @@ typedef enum mi3pt_option {
                                    * whose parked path state then lives in memory), 0 = five (96 registers, 24 entries), -1 = by the size of
                                    * the launch: six from 2.5 M jobs (tiles x frames) on -- long launches gain 2 .. 5 % from the extra wave, a
                                    * rank of an 8-way split's 10 ms launches lose 2 .. 3 % to the longer drain (-1) */
+    MI3PT_OPT_LAST_BUILD = 29,      /* READ-ONLY: which instantiation of the state-machine kernel the most recent raytrace launch ran, beside
+                                   * mi3pt_debug_last_launch: waves per SIMD it is compiled for (bits 0-7), the one-axis culling condition (bit 8),
+                                   * the walk threshold (bits 16-23) -- the template arguments rocprofv3 prints */
     MI3PT_OPT_COLLAPSE = 28,        /* how the reference tree's nodes are grouped into the walks' wide packets: 1 = the SAH-optimal collapse (round 6:
                                    * fewest expected packet visits; 5.9 instead of 4.0 children per 8-ary packet), 0 = rounds 2 - 5's greedy one (open
                                    * the child with the largest area until the packet is full: packets of two at the bottom of the tree), -1 = greedy

@@ -40,7 +40,9 @@ def test_single_gpu_line():
     # per-launch figure averaged the two): one instantiation, named with its waves per SIMD, one block per launch
     assert roof["kernel_ms"] > 0 and roof["launches_timed"] == 2 and roof["frames_per_launch"] == 160.0
     assert len(roof["launches"]) == 2 and all(b["frames"] == 160.0 and b["waves_per_simd"] == 6 for b in roof["launches"])
-    assert roof["launches"][0]["instantiation"] == roof["launches"][1]["instantiation"] and ",32,6>" in roof["launches"][0]["instantiation"]
+    assert roof["launches"][0]["instantiation"] == roof["launches"][1]["instantiation"]
+    assert roof["launches"][0]["instantiation"] == "k_raytrace_sm<true,true,true,true,true,false,false,false,true,32,6>"       # as rocprofv3 prints it (MI3PT_OPT_LAST_BUILD)
+    assert "false,false,false,true,44,6>" in j["forest"]["roofline"]["launches"][0]["instantiation"]                         # the deep-tree build, three-axis culling
     assert "6 waves per SIMD" in roof["real_bound"] and "5 waves" not in roof["real_bound"]
     # three fractions by three rules, at top level: what binds (VALU), north_star's counter-based HBM side (requested bytes, and the
     # upper bound if every request moved its 128-byte class), SURVEY 8(d)'s algorithmic bytes over the HBM peak (cache-served: > 1)

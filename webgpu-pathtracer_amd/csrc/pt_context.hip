@@ -82,7 +82,7 @@ struct mi3pt_ctx {
     int wide_leaf_cap = 0;
     uint32_t wide_root = 0;
     int num_cus = 256;              // hipDeviceProp_t::multiProcessorCount
-    pt::RtRoute last_route = { 0, 0, false, 0 };      // the kernel the most recent raytrace launch ran (mi3pt_debug_last_launch)
+    pt::RtRoute last_route = { 0, 0, false, 0, 0, false, 0 };      // the kernel the most recent raytrace launch ran (mi3pt_debug_last_launch)
     // Debug: packet / triangle numbering (mi3pt_debug_set_packet_layout).  0 = breadth-first packets,
     // triangles as uploaded (shipped).  1 = packets in the reference's visiting order (node, right
     // subtree, left subtree) and triangles in leaf-visiting order: a pure relabelling.
@@ -745,6 +745,7 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
         break;
     case MI3PT_OPT_GATE_TIMEOUT_MS: if (value < 0) return pt_set_error(MI3PT_ERR_INVALID, "gate time-out must be >= 0 ms"); ctx->gate_timeout_ms = value; break;
     case MI3PT_OPT_GATE_RELEASES: return pt_set_error(MI3PT_ERR_INVALID, "MI3PT_OPT_GATE_RELEASES is read-only");
+    case MI3PT_OPT_LAST_BUILD: return pt_set_error(MI3PT_ERR_INVALID, "MI3PT_OPT_LAST_BUILD is read-only");
     case MI3PT_OPT_DEBUG_SUPPRESS_DRAIN: ctx->debug_suppress_drain = value != 0; break;
     case MI3PT_OPT_SLOT_SETS:
         if (value != 2 && value != 3) return pt_set_error(MI3PT_ERR_INVALID, "slot sets: 2 or 3");
@@ -800,6 +801,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_CAMERA_BASE: *value = ctx->cam_base_enabled ? 1 : 0; break;
     case MI3PT_OPT_SIX_WAVES: *value = ctx->six_waves; break;
     case MI3PT_OPT_COLLAPSE: *value = ctx->collapse; break;
+    case MI3PT_OPT_LAST_BUILD: *value = ctx->last_route.waves | (ctx->last_route.ymax ? 0x100 : 0) | (ctx->last_route.walk_min << 16); break;
     case MI3PT_OPT_PACKET_ORDER: *value = ctx->packet_order; break;
     case MI3PT_OPT_GATE_TIMEOUT_MS: *value = ctx->gate_timeout_ms; break;
     case MI3PT_OPT_GATE_RELEASES: *value = ctx->gate_releases; break;

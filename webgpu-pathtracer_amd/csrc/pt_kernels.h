@@ -300,7 +300,7 @@ size_t service_block_bytes();
 // The kernel launch_raytrace runs for a requested variant.  kind: 0 = per-pixel kernel (variant 1 / 2), 1 = state-machine kernel
 // (variant 4, 7, 9 .. 12; experiment builds: 5, 6, 8), 2 = k_raytrace_persistent (variant 3, experiment builds); lean: the build
 // without diagnostics (DIAG = false); blocks: its grid.
-struct RtRoute { int kind, variant; bool lean; int blocks; };
+struct RtRoute { int kind, variant; bool lean; int blocks; int waves; bool ymax; int walk_min; };      // (waves per SIMD the build is compiled for; the one-axis culling condition; the walk threshold: what names the instantiation)
 RtRoute raytrace_route(const RtLaunch &L, int variant);
 bool raytrace_variant_fuses(int variant);      // can launch_raytrace fold the accumulate pass into this variant's kernel?  (the per-pixel kernels)
 void launch_raytrace_setup(const RtLaunch &L, bool fuse_accumulate, int variant, hipStream_t s);    // before launch_raytrace, same stream

@@ -2627,6 +2627,9 @@ RtRoute raytrace_route(const RtLaunch &L, int variant)
 {
     RtRoute r = route_launch(L, variant);
     r.blocks = r.kind == 1 ? persistent_blocks_for(L, r) : raytrace_grid_blocks(L.tile);
+    r.waves = r.kind == 1 ? route_waves_per_simd(L, r) : 0;
+    r.ymax = r.kind == 1 && r.lean && r.variant >= 12 && (L.scene.flags & 4u) != 0u;
+    r.walk_min = r.kind == 1 ? (r.lean ? ((r.variant == 13 || r.variant == 14) && L.walk_min == PT_DEEP_WALK_MIN ? PT_DEEP_WALK_MIN : PT_DEFAULT_WALK_MIN) : L.walk_min) : 0;
     return r;
 }
 

@@ -24,7 +24,7 @@ PRESENT_EXACT, PRESENT_LATEST = 0, 1
 (OPT_WALK_MIN, OPT_LEAF_MIN, OPT_SHADE_SPLIT, OPT_TAIL_POLICY, OPT_TOP_PACKETS, OPT_TRI_PAIR, OPT_JOB_REVERSE, OPT_JOB_GROUP,
  OPT_JOB_CHUNK, OPT_BATCH_LIMIT, OPT_BATCH, OPT_WAVES_PER_CU, OPT_CULL, OPT_WIDE, OPT_GATE, OPT_SLOT_SETS, OPT_PIPELINE,
  OPT_COST_ORDER, OPT_PRESENT_DEPTH, OPT_HOST_ANALYSES, OPT_GATHER_STAGED, OPT_DIAG_LITE,
- OPT_GATE_TIMEOUT_MS, OPT_GATE_RELEASES, OPT_DEBUG_SUPPRESS_DRAIN, OPT_CAMERA_BASE, OPT_PACKET_ORDER, OPT_SIX_WAVES, OPT_COLLAPSE) = range(29)
+ OPT_GATE_TIMEOUT_MS, OPT_GATE_RELEASES, OPT_DEBUG_SUPPRESS_DRAIN, OPT_CAMERA_BASE, OPT_PACKET_ORDER, OPT_SIX_WAVES, OPT_COLLAPSE, OPT_LAST_BUILD) = range(30)
 COUNTER_NAMES = ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels", "reserved")
 
 # every symbol include/mi3pt.h declares; tests/test_capi_symbols.py checks the header
@@ -398,7 +398,9 @@ class Context:
         """The kernel the most recent raytrace launch ran: dict(kind, variant, lean, workgroups) -- mi3pt_debug_last_launch."""
         k, v, l, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self._c(self.lib.mi3pt_debug_last_launch(self.handle, ctypes.byref(k), ctypes.byref(v), ctypes.byref(l), ctypes.byref(w)))
-        return {"kind": k.value, "variant": v.value, "lean": bool(l.value), "workgroups": w.value}
+        b = self.get_option(OPT_LAST_BUILD)
+        return {"kind": k.value, "variant": v.value, "lean": bool(l.value), "workgroups": w.value,
+                "waves_per_simd": b & 0xff, "ymax": bool(b & 0x100), "walk_min": (b >> 16) & 0xff}
 
     def batch_capacity(self):
         n = ctypes.c_int()
