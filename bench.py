@@ -513,6 +513,8 @@ def self_launch(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MI3PT_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (this pool's hosts only support dmabuf IPC: RCCL between processes needs it)
+        env.setdefault("OMP_NUM_THREADS", "1")                  # (what torch.distributed.run sets for its workers; the scene compile has its own thread pool)
         children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                          stdout=None if r == 0 else sys.stderr))
     rc, grace = 0, None
