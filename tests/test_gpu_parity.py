@@ -512,7 +512,9 @@ def test_every_reference_setting_runs_the_lean_kernel(gpu_ctx, orc, demo, env, v
             what = f"variant {variant} spf {spf} bounces {bounces} storage {storage} pipelined {pipelined}"
             assert pc.same_bits(got, want), what + ": " + pc.describe_diff(got, want)
             last = ctx.last_launch()
-            assert last == {"kind": 1, "variant": want_variant, "lean": True, "workgroups": last["workgroups"]}, (what, last)
+            assert (last["kind"], last["variant"], last["lean"]) == (1, want_variant, True), (what, last)
+            # ... and names its instantiation (MI3PT_OPT_LAST_BUILD): this small image's launches run the five-wave build, walk threshold 32
+            assert last["waves_per_simd"] == 5 and last["walk_min"] == 32, (what, last)
         # the raytrace pass alone (no accumulate): the frame's radiance, same kernel
         u = pc.rt_uniforms(demo, w, h, frame=9, bounces=4, spf=3)
         pc.gpu_frame(ctx, u)
