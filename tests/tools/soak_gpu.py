@@ -198,13 +198,13 @@ def soak_cameras():
             for _ in range(150):
                 w, h, frames, kw = int(rng.choice([33, 96, 200])), int(rng.choice([17, 64, 120])), int(rng.choice([1, 4, 9])), random_camera(rng)
                 res = []
-                for variant, pipelined in ((0, True), (1, False)):
+                for variant, pipelined in ((0, True), (1, False), (14, True)):          # (round 6: + the eight-wide walk)
                     ctx.set_kernel_variant(variant)
                     ctx.set_pipelining(pipelined)
                     res.append(render(ctx, sc, w, h, frames, **kw))
-                (a, ca), (b, cb) = res
+                (a, ca), (b, cb), (c8, cc8) = res
                 n += 1
-                if not (pc.same_bits(a, b) and all(ca[k] == cb[k] for k in pc.PATH_COUNTERS)):
+                if not (pc.same_bits(a, b) and pc.same_bits(c8, b) and all(ca[k] == cb[k] == cc8[k] for k in pc.PATH_COUNTERS)):
                     fails += 1
                     print("FAIL", name, w, h, kw, pc.describe_diff(a, b)[:200], flush=True)
     return report("cameras", n, fails, t0)
