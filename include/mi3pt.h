@@ -346,6 +346,11 @@ typedef enum mi3pt_option {
     MI3PT_OPT_LAST_BUILD = 29,      /* READ-ONLY: which instantiation of the state-machine kernel the most recent raytrace launch ran, beside
                                    * mi3pt_debug_last_launch: waves per SIMD it is compiled for (bits 0-7), the one-axis culling condition (bit 8),
                                    * the walk threshold (bits 16-23) -- the template arguments rocprofv3 prints */
+    MI3PT_OPT_WALK_ADAPT = 30,      /* the walk threshold by the VIEW (round 6): a launch of the shipped walk reports what it cost -- box tests per ray --
+                                   * through host-visible memory, and later launches run the deep-walk build (made for very large trees: walk_min 44,
+                                   * a longer leaf list) while that is above 40, the ordinary one again below 30: the 870 k-triangle scene from close
+                                   * up +4.4 %, its stated view (17 boxes per ray) unchanged.  No wait, no effect on any bit; MI3PT_OPT_WALK_MIN != 0
+                                   * overrides it (1) */
     MI3PT_OPT_COLLAPSE = 28,        /* how the reference tree's nodes are grouped into the walks' wide packets: 1 = the SAH-optimal collapse (round 6:
                                    * fewest expected packet visits; 5.9 instead of 4.0 children per 8-ary packet), 0 = rounds 2 - 5's greedy one (open
                                    * the child with the largest area until the packet is full: packets of two at the bottom of the tree), -1 = greedy

@@ -257,6 +257,50 @@ def test_config3_dragon_class_1080p_256spp(gpu_ctx, orc, dragon, env):
     ctx.resize(64, 64)
 
 
+def test_walk_threshold_follows_the_view(built, dragon, env):
+    """MI3PT_OPT_WALK_ADAPT (round 6): a launch of the shipped walk reports what it cost per ray, and later launches run the deep-walk build
+    (walk_min 44: made for very large trees) while the view tests more than 40 boxes per ray -- the 870 k-triangle mesh from close up: 68 --
+    and the ordinary one again below 30 (its stated view: 17).  Which build runs never changes a bit: every image equals the per-pixel
+    kernel's.  Own context: the test changes options."""
+    w, h, per = 960, 544, 32                 # 120 x 68 tiles x 32 frames = 261 k jobs per launch: above the 250 k a deep launch needs
+    mask = capi.SUBMIT_RAYTRACE | capi.SUBMIT_ACCUMULATE
+    close = np.array([0.55, 0.62, 1.15]), np.array([0.0, 0.5, 0.0])
+    views = {"close": dict(position=tuple(close[0]), direction=tuple((close[1] - close[0]) / np.linalg.norm(close[1] - close[0]))), "stated": {}}
+    with capi.Context(0) as ctx:
+        pc.upload_scene(ctx, dragon, env)
+        ctx.set_option(capi.OPT_BATCH, per)
+        ctx.resize(w, h)
+        assert ctx.get_option(capi.OPT_WALK_ADAPT) == 1
+
+        def launch(view, frame0, variant=0):
+            ctx.set_kernel_variant(variant)
+            ctx.reset()
+            ctx.reset_counters()
+            ctx.set_uniforms(capi.PASS_RAYTRACE, pc.rt_uniforms(dragon, w, h, frame=frame0, bounces=8, **views[view]).tobytes())
+            ctx.set_uniforms(capi.PASS_ACCUMULATE, pc.acc_uniforms(w, h, frame0).tobytes())
+            ctx.submit_frames(mask, per)
+            img = ctx.read_texture(capi.TEX_ACCUMULATION)          # (waits: the launch's report has arrived when this returns)
+            c = ctx.counters()
+            return img, c["box_tests"] / max(c["rays"], 1), ctx.last_launch()
+
+        seen = []
+        for view, frame0 in (("close", 2), ("close", 40), ("close", 80), ("stated", 2), ("stated", 40), ("close", 120)):
+            img, per_ray, last = launch(view, frame0)
+            ref, _, _ = launch(view, frame0, variant=2)
+            assert pc.same_bits(img, ref), f"{view} from frame {frame0}: " + pc.describe_diff(img, ref)
+            assert last["variant"] == 13 and last["lean"]
+            seen.append((view, round(per_ray), last["walk_min"]))
+        # the first close-up launch runs the ordinary build and reports ~68 boxes per ray; the next ones run the deep build; the first launch of
+        # the stated view still does (nothing has reported on it yet), reports ~17, and the ordinary build is back; then the close-up again
+        assert [s[2] for s in seen] == [32, 44, 44, 44, 32, 32], seen
+        assert seen[0][1] > 40 and seen[3][1] < 30, seen
+        ctx.set_option(capi.OPT_WALK_ADAPT, 0)
+        for frame0 in (2, 40):
+            _, _, last = launch("close", frame0)
+            assert last["walk_min"] == 32
+        ctx.set_kernel_variant(0)
+
+
 def test_config4_dragon_dof_4k_1024spp_one_rank_of_4(gpu_ctx, orc, dragon, env):
     """Config 4 at its stated 1024 spp, for one rank of the 4-way tile split (the ranks share nothing
     but the final gather; the reassembly is tested above): thin lens on, 512-frame launches; one

@@ -154,6 +154,16 @@ struct mi3pt_ctx {
     bool debug_suppress_drain = false;    // MI3PT_OPT_DEBUG_SUPPRESS_DRAIN (tests): the gate is armed but no kernel publishes its drain mark
     hipStream_t gate_release_stream = nullptr;
     volatile uint32_t *h_drain_flag = nullptr;   // the drain word as the host sees it, where signal memory is host memory (hipPointerGetAttributes at create); else null
+    // The walk threshold by the VIEW (round 6): after every launch of the shipped walk a one-block kernel leaves what the launch cost -- box
+    // tests and rays -- in host-visible memory; the next launch the host builds runs the deep-walk build (walk_min 44, its own leaf constants:
+    // made for very large trees) when the last launch seen tested more than WALK_ADAPT_ENTER boxes per ray, the ordinary one again below
+    // WALK_ADAPT_LEAVE.  The 870 k-triangle scene: its stated view 17 boxes per ray (deep build -5.6 %), its close-up 68 (+4.4 %).  Same bits.
+    int walk_adapt = 1;                   // MI3PT_OPT_WALK_ADAPT
+    bool deep_by_view = false;
+    uint64_t *h_walk_stats = nullptr;     // pinned host memory, [2 parities][4]: seq, box tests, rays of that parity's last launch
+    uint64_t *d_walk_stats = nullptr;     // ... as the device addresses it
+    uint64_t *d_walk_prev = nullptr;      // [2 parities][2] the counter sets' sums at the previous call (device)
+    uint64_t walk_stats_seq = 0, walk_stats_seen = 0;
     float *d_park = nullptr;              // [2 parities][PT_MAX_RESIDENT_WAVES][6][64] parked path state of the builds that keep it in memory (RtLaunch::park)
     uint32_t *d_stack_overflow = nullptr; // [2 parities][PT_MAX_RESIDENT_WAVES][SM_OVERFLOW_ENTRIES][64] overflow stack entries
     void *d_fs_taps = nullptr;            // the de-noise pass's tap table (pt::launch_fullscreen), built for fs_taps_res
@@ -524,6 +534,16 @@ extern "C" int mi3pt_create(int device, mi3pt_ctx **out_ctx)
     CREATE_TRY(hipMalloc((void **)&ctx->d_tile_counter, 256));
     CREATE_TRY(hipMalloc((void **)&ctx->d_stack_overflow, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * pt::SM_OVERFLOW_ENTRIES * 64 * 4));
     CREATE_TRY(hipMalloc((void **)&ctx->d_park, (size_t)2 * pt::PT_MAX_RESIDENT_WAVES * 6 * 64 * sizeof(float)));
+    if (hipHostMalloc((void **)&ctx->h_walk_stats, 64, hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer((void **)&ctx->d_walk_stats, ctx->h_walk_stats, 0) == hipSuccess &&
+        hipMalloc((void **)&ctx->d_walk_prev, 32) == hipSuccess) {
+        std::memset(ctx->h_walk_stats, 0, 64);
+        CREATE_TRY(hipMemsetAsync(ctx->d_walk_prev, 0, 32, ctx->stream));
+    } else {          // (no host-visible memory for it: the threshold goes by the size of the tree alone, as before round 6)
+        (void)hipGetLastError();
+        if (ctx->h_walk_stats) (void)hipHostFree(ctx->h_walk_stats);
+        ctx->h_walk_stats = nullptr; ctx->d_walk_stats = nullptr;
+    }
     CREATE_TRY(hipMalloc((void **)&ctx->d_service, (size_t)(SERVICE_SLOTS + 1) * service_slot_bytes()));      // (+ 1: the launches mi3pt_submit runs at once on the main stream)
     CREATE_TRY(hipMalloc(&ctx->d_fs_taps, pt::fullscreen_taps_bytes()));
     CREATE_TRY(hipMemsetAsync(ctx->d_tile_counter, 0, 256, ctx->stream));     // self-cleaning afterwards
@@ -611,6 +631,8 @@ extern "C" int mi3pt_destroy(mi3pt_ctx *ctx)
     for (int k = 0; k < 2; k++)
         if (ctx->rt_stream[k]) (void)hipStreamSynchronize(ctx->rt_stream[k]);
     if (ctx->gate_release_stream) (void)hipStreamDestroy(ctx->gate_release_stream);
+    if (ctx->h_walk_stats) (void)hipHostFree(ctx->h_walk_stats);
+    if (ctx->d_walk_prev) (void)hipFree(ctx->d_walk_prev);
     free_textures(ctx);
     for (void *p : { ctx->d_cw8, ctx->d_tripk8, ctx->d_cwide, ctx->d_tripk64, ctx->d_wide, ctx->d_tris, ctx->d_tris_perm, ctx->d_nodes, ctx->d_mats, ctx->d_env, ctx->d_cdf, ctx->d_packets, ctx->d_tripk, ctx->d_leaf_rank,
                      (void *)ctx->d_tile_counter, (void *)ctx->d_drain_flag, (void *)ctx->d_wave_times, (void *)ctx->d_stack_overflow, (void *)ctx->d_park, (void *)ctx->d_service, ctx->d_fs_taps })
@@ -735,6 +757,7 @@ extern "C" int mi3pt_debug_set_option(mi3pt_ctx *ctx, int option, int value)
     case MI3PT_OPT_GATE: ctx->gate_enabled = value != 0 && ctx->d_drain_flag != nullptr; if (ctx->gate_enabled) { ctx->gate_releases = 0; ctx->gate_stalls_in_a_row = 0; } break;
     case MI3PT_OPT_CAMERA_BASE: ctx->cam_base_enabled = value != 0; break;
     case MI3PT_OPT_SIX_WAVES: ctx->six_waves = value < 0 ? -1 : (value != 0 ? 1 : 0); break;
+    case MI3PT_OPT_WALK_ADAPT: ctx->walk_adapt = value != 0; if (!ctx->walk_adapt) ctx->deep_by_view = false; break;
     case MI3PT_OPT_COLLAPSE:
         if (value < -1 || value > 1) return pt_set_error(MI3PT_ERR_INVALID, "collapse: 0 greedy, 1 optimal, -1 by the packet width");
         if (ctx->collapse != value) { ctx->collapse = value; ctx->cull_dirty = true; }
@@ -801,6 +824,7 @@ extern "C" int mi3pt_debug_get_option(mi3pt_ctx *ctx, int option, int *value)
     case MI3PT_OPT_CAMERA_BASE: *value = ctx->cam_base_enabled ? 1 : 0; break;
     case MI3PT_OPT_SIX_WAVES: *value = ctx->six_waves; break;
     case MI3PT_OPT_COLLAPSE: *value = ctx->collapse; break;
+    case MI3PT_OPT_WALK_ADAPT: *value = ctx->walk_adapt; break;
     case MI3PT_OPT_LAST_BUILD: *value = ctx->last_route.waves | (ctx->last_route.ymax ? 0x100 : 0) | (ctx->last_route.walk_min << 16); break;
     case MI3PT_OPT_PACKET_ORDER: *value = ctx->packet_order; break;
     case MI3PT_OPT_GATE_TIMEOUT_MS: *value = ctx->gate_timeout_ms; break;
@@ -2323,6 +2347,7 @@ static int prepare_cull(mi3pt_ctx *ctx)
         if (thin_per_step < 0.25) ctx->auto_wide_variant = margin < std::ldexp(1.0, -10) ? 12 : 11;
     }
     ctx->cull_ok = true;
+    ctx->deep_by_view = false;           // (another scene: judged anew from its first launch)
     ctx->cull_dirty = false;
     ctx->main_dirty = true;
     ctx->scene_epoch++;
@@ -2609,8 +2634,31 @@ static int cost_order_prepare(mi3pt_ctx *ctx, pt::RtLaunch &L, const uint8_t *u_
 // main stream.
 static int run_fullscreen(mi3pt_ctx *ctx, const uint8_t *u_fs);
 
+// The walk threshold by the view: reads what the most recent launch that has reported cost per ray (no wait: whatever has arrived).
+#define WALK_ADAPT_ENTER 40.0
+#define WALK_ADAPT_LEAVE 30.0
+static void adapt_walk(mi3pt_ctx *ctx)
+{
+    if (!ctx->walk_adapt || !ctx->h_walk_stats) { ctx->deep_by_view = false; return; }
+    volatile uint64_t *h = ctx->h_walk_stats;
+    uint64_t best_seq = ctx->walk_stats_seen, box = 0, rays = 0;
+    for (int par = 0; par < 2; par++) {
+        const uint64_t s0 = __atomic_load_n(&ctx->h_walk_stats[4 * par], __ATOMIC_ACQUIRE);
+        const uint64_t b = h[4 * par + 1], r = h[4 * par + 2];
+        const uint64_t s1 = __atomic_load_n(&ctx->h_walk_stats[4 * par], __ATOMIC_ACQUIRE);
+        if (s0 == s1 && s0 > best_seq && s0 <= ctx->walk_stats_seq) { best_seq = s0; box = b; rays = r; }
+    }
+    if (best_seq == ctx->walk_stats_seen) return;
+    ctx->walk_stats_seen = best_seq;
+    if (rays < 65536) return;              // (too small a launch to judge a view by)
+    const double per_ray = (double)box / (double)rays;
+    if (per_ray >= WALK_ADAPT_ENTER) ctx->deep_by_view = true;
+    else if (per_ray <= WALK_ADAPT_LEAVE) ctx->deep_by_view = false;
+}
+
 static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame *frames, int n)
 {
+    adapt_walk(ctx);
     const mi3pt_ctx::PendingFrame &first = frames[0];
     const pt::AccUniforms acc = acc_from(first.u_acc);
     pt::RtLaunch L = build_launch(ctx, first.u_rt, acc);
@@ -2635,6 +2683,11 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame *frames, i
     if (ctx->acc_done_valid[set]) HIP_TRY(hipStreamWaitEvent(rs, ctx->acc_done[set], 0));
     L.radiance = ctx->d_slots[set];
     L.nframes = n;
+    // the walk threshold by the view (adapt_walk): the deep-walk build for a launch of the shipped walk long enough to run its six-wave form
+    // (>= 250 k jobs: a short launch -- an interactive host's single frames -- is all ramp and drain, and keeps the ordinary build)
+    if (ctx->deep_by_view && ctx->walk_min == 0 && L.walk_min == PT_DEFAULT_WALK_MIN && pick_variant(ctx) == 13 &&
+        (long long)pt::raytrace_grid_blocks(L.tile) * n >= 250000)
+        L.walk_min = PT_DEEP_WALK_MIN;
     L.block_counters = ctx->d_block_counters + (size_t)par * ctx->nblocks * pt::CNT_COUNT;
     L.tile_counter = ctx->d_tile_counter + par * 32;
     L.stack_overflow = ctx->d_stack_overflow + (size_t)par * pt::PT_MAX_RESIDENT_WAVES * pt::SM_OVERFLOW_ENTRIES * 64;
@@ -2725,6 +2778,12 @@ static int launch_batch(mi3pt_ctx *ctx, const mi3pt_ctx::PendingFrame *frames, i
     }
     HIP_TRY(hipEventRecord(ctx->rt_done[par], rs));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->rt_done[par], 0));
+    // what this launch cost per ray, for the choice of a later launch's build (adapt_walk): behind the launch on its own stream, after the event
+    // the ordered mean waits for
+    if (ctx->walk_adapt && ctx->h_walk_stats && launches && ctx->last_route.kind == 1 && ctx->last_route.lean && ctx->last_route.variant == 13 && ctx->walk_min == 0) {
+        pt::launch_walk_stats(L.block_counters, ctx->nblocks, ctx->d_walk_prev + 2 * par, ctx->d_walk_stats + 4 * par, ++ctx->walk_stats_seq, rs);
+        (void)hipGetLastError();
+    }
     // The ordered mean, a run of frames at a time: a run ends with a frame whose canvas is wanted (EXACT presentation) or
     // with the launch -- all n frames in one pass unless frames present, one pass + one fullscreen pass per presenting frame.
     ctx->last_radiance = L.radiance + (size_t)(n - 1) * L.slot_pixels;

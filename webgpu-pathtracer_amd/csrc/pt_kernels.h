@@ -319,6 +319,9 @@ void launch_fullscreen(const FsUniforms &fs, const float4 *tex, int tex_w, int t
 void launch_debug_intersect(const SceneRefs &scene, const float *rays, size_t n, float *out, int variant,
                             hipStream_t s);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t s);
+// Box tests and rays of one counter set ([nblocks][CNT_COUNT]) since the previous call for that set, into host-visible memory:
+// out[1] = box tests, out[2] = rays, then (after a system-scope fence) out[0] = seq.  `prev` (2 x u64, device) carries the sums.
+void launch_walk_stats(const uint64_t *counters, int nblocks, uint64_t *prev, uint64_t *out, uint64_t seq, hipStream_t s);
 int raytrace_grid_blocks(const Tile &tile);
 int raytrace_persistent_blocks(const Tile &tile, int nframes, int waves_per_cu, int num_cus, bool tuned = false, int waves_per_simd = 0);
 // packs the three position vectors of `ntris` 112-byte triangle records into 48-byte rows (the context's cull analysis)

@@ -3228,6 +3228,39 @@ __global__ void __launch_bounds__(256) k_debug_math(int fn, const float *__restr
     out[i] = r;
 }
 
+// What the launch that has just run COST per ray, for the host's choice of the next launch's build (pt_context.hip: adapt_walk): the
+// counter set's box tests and rays, summed over its blocks, as the difference to the previous call for that set.  A reset of the
+// counters in between (sums below the previous ones) restarts the difference.  One block; microseconds.
+__global__ void __launch_bounds__(256) k_walk_stats(const uint64_t *__restrict__ counters, int nblocks, uint64_t *prev, uint64_t *out, uint64_t seq)
+{
+    __shared__ uint64_t sb[256], sr[256];
+    uint64_t b = 0, r = 0;
+    for (int i = (int)threadIdx.x; i < nblocks; i += 256) {
+        b += counters[(size_t)i * CNT_COUNT + CNT_BOX];
+        r += counters[(size_t)i * CNT_COUNT + CNT_RAYS];
+    }
+    sb[threadIdx.x] = b; sr[threadIdx.x] = r;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sb[threadIdx.x] += sb[threadIdx.x + s]; sr[threadIdx.x] += sr[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t tb = sb[0], tr = sr[0], pb = prev[0], pr = prev[1];
+        const bool restarted = tb < pb || tr < pr;
+        prev[0] = tb; prev[1] = tr;
+        __hip_atomic_store(out + 1, restarted ? tb : tb - pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(out + 2, restarted ? tr : tr - pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(out + 0, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+void launch_walk_stats(const uint64_t *counters, int nblocks, uint64_t *prev, uint64_t *out, uint64_t seq, hipStream_t s)
+{
+    if (nblocks <= 0 || !counters || !prev || !out) return;
+    hipLaunchKernelGGL(k_walk_stats, dim3(1), dim3(256), 0, s, counters, nblocks, prev, out, seq);
+}
+
 __global__ void __launch_bounds__(256) k_patch_cull(float4 *__restrict__ packets, const uint32_t *__restrict__ cull, uint32_t n)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;

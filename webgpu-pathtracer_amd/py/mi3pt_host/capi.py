@@ -24,7 +24,7 @@ PRESENT_EXACT, PRESENT_LATEST = 0, 1
 (OPT_WALK_MIN, OPT_LEAF_MIN, OPT_SHADE_SPLIT, OPT_TAIL_POLICY, OPT_TOP_PACKETS, OPT_TRI_PAIR, OPT_JOB_REVERSE, OPT_JOB_GROUP,
  OPT_JOB_CHUNK, OPT_BATCH_LIMIT, OPT_BATCH, OPT_WAVES_PER_CU, OPT_CULL, OPT_WIDE, OPT_GATE, OPT_SLOT_SETS, OPT_PIPELINE,
  OPT_COST_ORDER, OPT_PRESENT_DEPTH, OPT_HOST_ANALYSES, OPT_GATHER_STAGED, OPT_DIAG_LITE,
- OPT_GATE_TIMEOUT_MS, OPT_GATE_RELEASES, OPT_DEBUG_SUPPRESS_DRAIN, OPT_CAMERA_BASE, OPT_PACKET_ORDER, OPT_SIX_WAVES, OPT_COLLAPSE, OPT_LAST_BUILD) = range(30)
+ OPT_GATE_TIMEOUT_MS, OPT_GATE_RELEASES, OPT_DEBUG_SUPPRESS_DRAIN, OPT_CAMERA_BASE, OPT_PACKET_ORDER, OPT_SIX_WAVES, OPT_COLLAPSE, OPT_LAST_BUILD, OPT_WALK_ADAPT) = range(31)
 COUNTER_NAMES = ("rays", "box_tests", "tri_tests", "hits", "misses", "stack_overflows", "pixels", "reserved")
 
 # every symbol include/mi3pt.h declares; tests/test_capi_symbols.py checks the header
