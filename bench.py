@@ -761,7 +761,7 @@ def main():
                        + (", filtered slab test" if v in (11, 12) else "") + (", one-axis culling condition" if v == 12 else "")
                        + (": COMPRESSED packets (64 B, boxes on an 8-bit grid rounded outward, conservative test; the exact test on the leaf's own box in the triangle step)" if v == 13 else "")
                        + (" on EIGHT-wide compressed packets (80 B; hit masks in octant order, one 64-bit node entry and one 32-bit leaf entry per step: the experiment of round 6, not the default)" if v == 14 else "")
-                       + f"; lean build, {waves if waves else 'five or six'} waves per SIMD" + (" (80 registers: launches of >= 2.5 M jobs)" if waves == 6 else " (96 registers)" if waves == 5 else "")
+                       + f"; lean build, {waves if waves else 'five or six'} waves per SIMD" + (" (80 registers: launches of >= 1.5 M jobs)" if waves == 6 else " (96 registers)" if waves == 5 else "")
                        + "; YMAX = the one-axis culling condition where the scene's margins allow it; batched frames)")
         m["lean"], m["waves_per_simd"], m["workgroups"] = last["lean"], waves, wg
         # ---- is the gathered image the right image?  (outside the timed region; round-4 verdict: the N > 1 line gathered and

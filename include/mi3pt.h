@@ -288,7 +288,7 @@ int mi3pt_reset_counters(mi3pt_ctx *ctx);
  * (one v_cvt_f32_ubyte + one fma per quotient); the leaf's own box is tested EXACTLY in the triangle step, and only leaves that
  * pass it count as triangle tests.  Half the bytes and half the loads of 10 per node step.  Instantiations: culling condition
  * (one axis / three axes, chosen per scene like 12 / 11) x walk threshold (32 lanes; 44 for very large trees) x waves per SIMD (six:
- * 80 registers, for launches of >= 2.5 M jobs; five: 96 registers; MI3PT_OPT_SIX_WAVES).
+ * 80 registers, for launches of >= 1.5 M jobs; five: 96 registers; MI3PT_OPT_SIX_WAVES).
  * Needs every box of the tree nested in its parent's and finite (any tree of the reference's builder); otherwise 10 runs.
  * 14 = the EIGHT-wide walk (round 6; measured, NOT the default -- profiles/r06_a_ab_eight_wide.log): 13's conservative test on 80-byte packets
  * of up to eight children whose slots are chosen by position, so that `slot ^ octant of the ray's direction signs` is a front-to-back
@@ -341,7 +341,7 @@ typedef enum mi3pt_option {
                                    * same bits.  Applied at the next scene analysis (0) */
     MI3PT_OPT_SIX_WAVES = 27,       /* the shipped walk's build: 1 = six waves per SIMD (80 registers, a 19-entry LDS stack -- 25 for very large trees,
                                    * whose parked path state then lives in memory), 0 = five (96 registers, 24 entries), -1 = by the size of
-                                   * the launch: six from 2.5 M jobs (tiles x frames) on -- long launches gain 2 .. 5 % from the extra wave, a
+                                   * the launch: six from 1.5 M jobs (tiles x frames) on -- long launches gain 2 .. 5 % from the extra wave, a
                                    * rank of an 8-way split's 10 ms launches lose 2 .. 3 % to the longer drain (-1) */
     MI3PT_OPT_LAST_BUILD = 29,      /* READ-ONLY: which instantiation of the state-machine kernel the most recent raytrace launch ran, beside
                                    * mi3pt_debug_last_launch: waves per SIMD it is compiled for (bits 0-7), the one-axis culling condition (bit 8),

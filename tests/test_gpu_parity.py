@@ -1293,7 +1293,7 @@ def test_packet_numbering_in_memory_does_not_change_a_bit(built, orc, demo, env,
 @pytest.mark.parametrize("six", [0, 1])
 def test_five_and_six_wave_builds_render_the_oracles_bits(gpu_ctx, orc, demo, env, six):
     """MI3PT_OPT_SIX_WAVES forced: the small images of this file would only ever run the five-wave build (the six-wave one is taken
-    from 2.5 M jobs per launch on) -- here every frame case, multi-sample frames, the lens, F16 storage and a tile split on both."""
+    from 1.5 M jobs per launch on) -- here every frame case, multi-sample frames, the lens, F16 storage and a tile split on both."""
     ctx = gpu_ctx
     pc.upload_scene(ctx, demo, env)
     osc = pc.oracle_scene(orc, demo, env)

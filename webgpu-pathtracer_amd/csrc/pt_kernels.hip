@@ -2603,7 +2603,7 @@ bool raytrace_variant_fuses(int variant)
 // 8-way split (a 10 ms launch) is 2 .. 3 % SLOWER with six (profiles/r05_i_six_waves_by_launch_size.log).  So the choice goes by the size of
 // the launch: jobs (tiles x frames) per resident wave.  L.six_waves forces it (MI3PT_OPT_SIX_WAVES).  Other lean builds: five; twins: four.
 #ifndef PT_SIX_WAVES_MIN_JOBS
-#define PT_SIX_WAVES_MIN_JOBS 2500000
+#define PT_SIX_WAVES_MIN_JOBS 1500000      // (round 6, re-swept on the cheaper node step: six waves win from ~1.3 M jobs on -- profiles/r06_i_six_waves_threshold.log; was 2.5 M)
 #endif
 static int route_waves_per_simd(const RtLaunch &L, const RtRoute &r)
 {
