@@ -1262,6 +1262,9 @@ PT_DEV T uniform_block(const T &v)
 #define PT_CW_NO_PAIR_TEST 0
 #endif
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
+#ifndef PT_LONG_QUEUE
+#define PT_LONG_QUEUE 4
+#endif
 #ifndef PT_DEEP_LEAF_MIN
 #define PT_DEEP_LEAF_MIN 32
 #endif
@@ -1477,7 +1480,11 @@ __global__ void __launch_bounds__(64, DIAG ? SM_OTHER_WAVES_PER_SIMD : WAVES) k_
     int have = 0, have_at = 0;           // tickets in hand: have_at, have_at + 1, ... (`have` of them)
     auto draw = [&](const RtService &S) {
         const int ntiles = S.ntiles;
-        const int c = (ntiles - have_at > 2 * k_job_chunk * (int)gridDim.x) ? k_job_chunk : 1;
+        // (round 6: twice the tickets per draw while the queue is VERY long -- more than PT_LONG_QUEUE draws of that size per wave left: the
+        // head's atomic paces a 5 M-job launch measurably (+1 % with eight per draw), while a launch of a few hundred thousand jobs loses to it)
+        const int left = ntiles - have_at;
+        const int c = (TUNED && left > PT_LONG_QUEUE * 2 * k_job_chunk * (int)gridDim.x) ? 2 * k_job_chunk
+                      : (left > 2 * k_job_chunk * (int)gridDim.x ? k_job_chunk : 1);
         int t = 0;
         if (lane == 0) {
             t = (int)atomicAdd(S.L.tile_counter, (uint32_t)c);
