@@ -1263,7 +1263,7 @@ PT_DEV T uniform_block(const T &v)
 #endif
 #define PT_SM_LDS_DEPTH pt::SM_LDS_DEPTH
 #ifndef PT_LONG_QUEUE
-#define PT_LONG_QUEUE 4
+#define PT_LONG_QUEUE 16
 #endif
 #ifndef PT_DEEP_LEAF_MIN
 #define PT_DEEP_LEAF_MIN 32
