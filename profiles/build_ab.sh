@@ -7,4 +7,4 @@ mkdir -p $ROOT/_ab
 cd $ROOT/webgpu-pathtracer_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
   -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function "$@" -shared -o $ROOT/_ab/lib$NAME.so \
-  pt_kernels.hip pt_context.hip pt_lbvh.hip pt_host_scene.cpp -lpthread && echo "built _ab/lib$NAME.so ($*)"
+  pt_kernels.hip pt_context.hip pt_lbvh.hip pt_host_scene.cpp pt_host_wide.cpp -lpthread && echo "built _ab/lib$NAME.so ($*)"

@@ -1,6 +1,7 @@
 #!/bin/bash
 # AddressSanitizer + UndefinedBehaviorSanitizer over the CPU-side native code (no GPU sanitizer exists on this pool):
-# the host scene compile of libmi3pt.so (csrc/pt_host_scene.cpp: the reference's BVH builder and env CDF) and the CPU
+# the host scene compile of libmi3pt.so (csrc/pt_host_scene.cpp: the reference's BVH builder and env CDF; csrc/pt_host_wide.cpp: the
+# SAH-optimal collapse and the eight-wide packets of kernel variant 14 with their self-check) and the CPU
 # oracle (oracle/pt_oracle.c: raytrace, accumulate, fullscreen).  Builds instrumented copies under /tmp and drives them
 # through ctypes.   usage: bash tests/tools/sanitize_cpu.sh        (about a minute; prints two "ok" lines)
 set -eu
@@ -13,7 +14,7 @@ cat > $W/stub.cpp <<'CPP'
 #include <cstdio>
 int pt_set_error(int code, const std::string &msg) { fprintf(stderr, "(expected) error %d: %s\n", code, msg.c_str()); return code; }
 CPP
-g++ $SAN -std=c++17 -w -I$ROOT/include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ $ROOT/webgpu-pathtracer_amd/csrc/pt_host_scene.cpp $W/stub.cpp -o $W/libhost.so -lpthread
+g++ $SAN -std=c++17 -w -I$ROOT/include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ $ROOT/webgpu-pathtracer_amd/csrc/pt_host_scene.cpp $ROOT/webgpu-pathtracer_amd/csrc/pt_host_wide.cpp $W/stub.cpp -o $W/libhost.so -lpthread
 gcc $SAN -std=c11 -ffp-contract=off -fno-fast-math -fopenmp $(grep -q -m1 fma /proc/cpuinfo && echo -mfma) -o $W/libptoracle.so $ROOT/oracle/pt_oracle.c -lm
 export LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1
 python3 - $W $ROOT <<'PY'
@@ -35,6 +36,11 @@ for n in (1, 2, 3, 7, 100, 5000, 200000):
     tri = np.zeros((n, 28), np.float32)
     tri[:, 0:3], tri[:, 4:7], tri[:, 8:11] = pos[:, 0:3], pos[:, 3:6], pos[:, 6:9]
     assert lib.mi3pt_host_build_bvh(tri.ctypes.data_as(P), S(n), nodes.ctypes.data_as(P), S(nodes.nbytes), ctypes.byref(nn), 0) == 0
+    # the eight-wide packets of kernel variant 14 over that tree, both groupings, built and verified (pt_host_wide.cpp)
+    out = np.zeros(6, np.uint64)
+    for greedy in (0, 1):
+        rc = lib.mi3pt_host_eight_wide_check(nodes.ctypes.data_as(P), S(nodes.nbytes), tri.ctypes.data_as(P), S(tri.nbytes), greedy, out.ctypes.data_as(P))
+        assert (rc == 0 and out[4] == n) if n > 1 else rc != 0, (n, greedy, rc, out)
 for w, h in ((1, 1), (2, 1), (64, 32), (333, 77)):
     img = rng.random((h, w, 4), dtype=np.float32) * 10
     if w > 2:
@@ -42,7 +48,7 @@ for w, h in ((1, 1), (2, 1), (64, 32), (333, 77)):
     cdf = np.zeros((h, w, 4), np.float32)
     assert lib.mi3pt_host_env_cdf(img.ctypes.data_as(P), w, h, cdf.ctypes.data_as(P)) == 0
 assert lib.mi3pt_host_build_bvh_f64(None, S(0), None, S(0), ctypes.byref(S()), 1) != 0
-print("host scene compile under ASan + UBSan: ok")
+print("host scene compile + wide packets under ASan + UBSan: ok")
 
 sys.path[:0] = [ROOT + "/oracle", ROOT + "/tests", ROOT + "/webgpu-pathtracer_amd/py"]
 import pt_oracle as orc
