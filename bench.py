@@ -587,6 +587,13 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     elif world != args.gpus:
         args.gpus = world
+    # ONE JSON line on stdout, whatever the libraries underneath print: from here on file descriptor 1 is stderr (gloo announces its
+    # connections on stdout -- "[Gloo] Rank 0 is connected to ..." -- and a backend's C++ side does not ask Python), and the line is
+    # written to the real stdout, kept aside, at the end.  (The launcher parent of a plain multi-GPU run has returned above: its ranks
+    # each do this for themselves.)
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     if os.environ.get("MI3PT_BENCH_ECHO_RANK") == "1":      # (tests/test_bench_launcher.py)
         print(f"bench.py rank {rank}/{world} local {local_rank} rendezvous {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
@@ -934,7 +941,8 @@ def main():
             out["config"]["parallelism"] = f"EXPERIMENT: rank {args.tile} of a tile split rendered alone on one GPU, no gather"
         if world == 1 and not args.no_cpu_baseline and not args.tile:
             out["cpu_baseline"] = cpu_baseline(job)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -14,6 +14,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _line(out):
+    """ONE line on stdout, the JSON one (round 6: gloo's "[Gloo] Rank 0 is connected ..." used to share rank 0's stdout with it -- bench.py now
+    keeps the real stdout aside and points file descriptor 1 at stderr while it runs)."""
+    assert out.strip().count("\n") == 0, out[-2000:]
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
     return json.loads(lines[0])
